@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the REFERENCE (/root/reference) in the build
+container and running its own functions on small synthetic inputs.
+
+Only data is committed: inputs and the reference's outputs.  No reference source is copied.
+Run:  python tests/golden/make_golden.py     (needs /root/reference; never runs on the GPU box)
+
+Shims:
+  * pysam is absent -> a dummy module so `import wisecondorx.main` works (convert is not on
+    the path).
+  * predict_tools.project_pc raises on scikit-learn >= 1.5 -> patched with the <=1.4.2
+    transform semantics the reference pins (setup.cfg:42).
+  * CBS needs R/DNAcopy (absent) -> exec_R patched with hand-made segments.
+"""
+import argparse
+import os
+import random
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+sys.modules.setdefault("pysam", types.ModuleType("pysam"))
+warnings.filterwarnings("ignore")
+
+import wisecondorx.main as ref_main                      # noqa: E402
+import wisecondorx.newref_tools as ref_nt                # noqa: E402
+import wisecondorx.predict_tools as ref_pt               # noqa: E402
+import wisecondorx.predict_control as ref_pc             # noqa: E402
+import wisecondorx.overall_tools as ref_ot               # noqa: E402
+
+from wisecondorx_amd.synth import Cohort, corrected_matrix   # noqa: E402
+
+
+def _project_pc_le14(sample_data, ref_file, ap):
+    comp = ref_file["pca_components{}".format(ap)]
+    mean = ref_file["pca_mean{}".format(ap)]
+    t = np.dot(np.array([sample_data]) - mean, comp.T)
+    rec = (np.dot(t, comp) + mean)[0]
+    return sample_data / rec
+
+
+ref_pt.project_pc = _project_pc_le14
+ref_pc.project_pc = _project_pc_le14
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **kw)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+# --------------------------------------------------------------------------- newref search
+def golden_newref_search():
+    out = {}
+    # realistic values; 24 chromosomes so A / F-style / M-style passes all exist
+    mb24 = [70, 66, 55, 52, 50, 47, 44, 40, 38, 37, 37, 36, 31, 29, 28, 25, 23, 22, 16, 18,
+            13, 14, 43, 16]
+    X, _, _ = corrected_matrix(mb24, 30, seed=7)
+    assert X.flags["F_CONTIGUOUS"]
+    out["Xs"] = np.ascontiguousarray(X.T)      # sample-major bytes of the F-ordered (B,S)
+    for tag, nchr, part, parts in (("A", 22, 2, 3), ("A1", 22, 1, 1), ("F", 23, 1, 1),
+                                   ("M", 24, 1, 1), ("M2", 24, 2, 2)):
+        mb = mb24[:nchr]
+        cum = np.cumsum(mb).tolist()
+        Xp = X[:cum[-1], :]
+        assert Xp.flags["F_CONTIGUOUS"] or True
+        Xp = np.asfortranarray(Xp)
+        random.seed(1000 + nchr + part)
+        idx, dist, nr = ref_nt.get_reference(Xp, mb, cum, 40, part, parts)
+        random.seed(1000 + nchr + part)
+        ids = random.sample(range(Xp.shape[1]), min(Xp.shape[1], 100))
+        out[tag + "_mb"] = np.array(mb)
+        out[tag + "_part"] = np.array([part, parts])
+        out[tag + "_idx"] = idx
+        out[tag + "_dist"] = dist
+        out[tag + "_nr"] = nr
+        out[tag + "_ids"] = np.array(ids)
+    # tie-heavy integer case (many exactly equal distances), direct get_ref_for_bins
+    rng = np.random.default_rng(3)
+    Xi = np.asfortranarray(rng.integers(0, 3, (120, 6)).astype(np.float64))
+    chr_data = np.concatenate((Xi[:20, :], Xi[50:, :]))
+    ti, td = ref_nt.get_ref_for_bins(25, 20, 50, Xi, chr_data)
+    out["tie_Xs"] = np.ascontiguousarray(Xi.T)
+    out["tie_idx"], out["tie_dist"] = ti, td
+    # fewer than k candidates -> -1 / 1e10 padding
+    Xf = np.asfortranarray(1.0 + 0.05 * rng.standard_normal((30, 8)))
+    chr_data = np.concatenate((Xf[:10, :], Xf[18:, :]))
+    fi, fd = ref_nt.get_ref_for_bins(40, 10, 18, Xf, chr_data)
+    out["few_Xs"] = np.ascontiguousarray(Xf.T)
+    out["few_idx"], out["few_dist"] = fi, fd
+    # NaN / inf / huge candidates are never admitted
+    Xn = np.asfortranarray(1.0 + 0.05 * rng.standard_normal((60, 8)))
+    Xn[5, 3] = np.nan
+    Xn[40, 0] = np.inf
+    Xn[41, 2] = 3e5          # d ~ 9e10 >= 1e10 -> not admitted
+    Xn[25, 1] = np.nan       # a NaN TARGET row: all distances NaN -> all padding
+    chr_data = np.concatenate((Xn[:20, :], Xn[30:, :]))
+    ni, nd = ref_nt.get_ref_for_bins(45, 20, 30, Xn, chr_data)
+    out["nan_Xs"] = np.ascontiguousarray(Xn.T)
+    out["nan_idx"], out["nan_dist"] = ni, nd
+    save("newref_search.npz", **out)
+
+
+# --------------------------------------------------------------------------- end-to-end
+def write_sample(path, sample, binsize):
+    np.savez_compressed(path, binsize=binsize, sample=sample, quality={})
+
+
+def golden_pipeline():
+    binsize = 4000000
+    co = Cohort(binsize, struct_seed=11, female_y=0.1)
+    samples, genders = co.cohort(24, seed0=500, reads=4e6)
+    tmp = tempfile.mkdtemp(prefix="wcx_golden_")
+    infiles = []
+    for i, s in enumerate(samples):
+        p = os.path.join(tmp, "s{}.npz".format(i))
+        write_sample(p, s, binsize)
+        infiles.append(p)
+    args = argparse.Namespace(infiles=infiles, outfile=os.path.join(tmp, "ref.npz"),
+                              nipt=False, yfrac=0.004, plotyfrac=None, refsize=60,
+                              binsize=binsize, cpus=1)
+    np.random.seed(5)
+    random.seed(5)
+    try:
+        ref_main.tool_newref(args)
+    except NameError as e:          # main.py:135 qc_reference never imported
+        print("expected reference bug:", e)
+    ref = np.load(args.outfile, encoding="latin1", allow_pickle=True)
+    ref_dict = {k: ref[k] for k in ref.files}
+    print({k: (v.shape, v.dtype) for k, v in ref_dict.items()})
+
+    out = {"ref__" + k: v for k, v in ref_dict.items()}
+    # cohort counts so the build's own newref can be run on identical inputs
+    out["cohort_counts"] = np.stack([np.concatenate([s[str(c)] for c in range(1, 25)])
+                                     for s in samples])
+    out["cohort_genders"] = np.array(genders)
+    out["cohort_bpc"] = np.array(co.bpc)
+
+    pargs = argparse.Namespace(maskrepeats=5, minrefbins=20)
+    tests = {
+        "t0": co.sample(9001, "M", reads=4e6, cnv=[(3, 10, 25, 1.5)]),
+        "t1": co.sample(9002, "F", reads=4e6, cnv=[(7, 5, 15, 0.5), (23, 10, 20, 1.5)]),
+        "t2": co.sample(9003, "M", reads=4e6),
+    }
+    # t2: zeros + wild outliers to trigger the -1 masking and degenerate bins
+    t2 = tests["t2"]
+    t2["5"][3:9] = 0
+    t2["9"][7] *= 40
+    for name, sample0 in tests.items():
+        gender = ref_pt.predict_gender(sample0, ref["trained_cutoff"])
+        sample = {k: v.copy() for k, v in sample0.items()}
+        sample = ref_ot.gender_correct(sample, gender)
+        out[name + "_counts"] = np.concatenate([sample0[str(c)] for c in range(1, 25)])
+        out[name + "_gender"] = np.array(gender)
+        rA = ref_pc.normalize(pargs, sample, ref, "A")
+        rG = ref_pc.normalize(pargs, sample, ref, gender)
+        for tag, res in (("A", rA), ("G", rG)):
+            for nm, v in zip(("r", "z", "w", "n", "mlr", "mz"), res):
+                out["{}_{}_{}".format(name, tag, nm)] = np.asarray(v)
+        # stage values feeding normalize_repeat
+        ap = ""
+        xA = ref_pt.coverage_normalize_and_mask(sample, ref, ap)
+        out[name + "_A_cov"] = xA
+        out[name + "_A_x"] = ref_pt.project_pc(xA, ref, ap)
+        ap = "." + gender
+        xG = ref_pt.coverage_normalize_and_mask(sample, ref, ap)
+        out[name + "_G_x"] = ref_pt.project_pc(xG, ref, ap)
+        out[name + "_cutoff"] = np.array(ref_pt.get_optimal_cutoff(ref, 5))
+
+        # merge + post-processing exactly as main.py:216-275
+        results_r, results_z, results_w, ref_sizes, m_lr, m_z = rA
+        results_r_2, results_z_2, results_w_2, ref_sizes_2, _, _ = rG
+        nr_aut = ref["null_ratios"]
+        nr_gon = ref["null_ratios.{}".format(gender)][len(nr_aut):]
+        rem_input = {
+            "args": pargs, "binsize": int(ref["binsize"]), "ref_gender": gender,
+            "mask": ref["mask.{}".format(gender)],
+            "bins_per_chr": ref["bins_per_chr.{}".format(gender)],
+        }
+        results_r = np.append(results_r, results_r_2)
+        results_z = np.append(results_z, results_z_2) - m_z
+        results_w = np.append(results_w * np.nanmean(results_w_2),
+                              results_w_2 * np.nanmean(results_w))
+        results_w = results_w / np.nanmean(results_w)
+        ref_sizes = np.append(ref_sizes, ref_sizes_2)
+        null_ratios = np.array([x.tolist() for x in nr_aut] + [x.tolist() for x in nr_gon],
+                               dtype=object)
+        results = {"results_r": results_r, "results_z": results_z, "results_w": results_w,
+                   "results_nr": null_ratios}
+        for k in results.keys():
+            results[k] = ref_pc.get_post_processed_result(pargs, results[k], ref_sizes,
+                                                          rem_input)
+        ref_pt.log_trans(results, m_lr)
+        if name == "t1":
+            bl = os.path.join(tmp, "bl.bed")
+            with open(bl, "w") as fh:
+                fh.write("chr2\t8000000\t19000000\nX\t0\t7900000\nchrY\t0\t100\n")
+            pargs.blacklist = bl
+            rem_input["args"] = pargs
+            ref_pt.apply_blacklist(rem_input, results)
+            out["t1_blacklist"] = np.array([["chr2", "8000000", "19000000"],
+                                            ["X", "0", "7900000"], ["chrY", "0", "100"]])
+        flat = lambda key: np.concatenate([np.asarray(c, dtype=float) for c in results[key]])
+        out[name + "_post_r"] = flat("results_r")
+        out[name + "_post_z"] = flat("results_z")
+        out[name + "_post_w"] = flat("results_w")
+        nchr = len(results["results_r"])
+        # null ratios are ragged in the reference (autosomal rows have min(S,100) columns,
+        # gonosomal rows min(S_gender,100)); store one matrix per group, zero rows where the
+        # reference holds the int 0 placeholder (predict_tools.py:164).
+        def nr_block(chrs, m):
+            rows = []
+            for c in chrs:
+                for row in results["results_nr"][c]:
+                    rows.append(np.asarray(row, dtype=float) if isinstance(row, (list, np.ndarray))
+                                else np.zeros(m))
+            return np.array(rows)
+        out[name + "_post_nrA"] = nr_block(range(22), nr_aut.shape[1])
+        out[name + "_post_nrG"] = nr_block(range(22, nchr), nr_gon.shape[1])
+        # segment z on hand-made segments (CBS itself needs R/DNAcopy: unpinned)
+        bpc = list(rem_input["bins_per_chr"])
+        segs = []
+        for c in range(nchr):
+            n = bpc[c]
+            cuts = [0, n // 3, n // 3 + 2, n] if c % 2 == 0 else [0, n]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                if b - a < 1:
+                    continue
+                rr = np.asarray(results["results_r"][c][a:b], dtype=float)
+                ww = np.asarray(results["results_w"][c][a:b], dtype=float)
+                keep = rr != 0
+                segr = float(np.sum(rr[keep] * ww[keep]) / np.sum(ww[keep])) if keep.any() else 0.0
+                segs.append([c, a, b, segr])
+        segs.append([0, 0, 1, 50.0])      # clipping to +1000
+        zs = ref_ot.get_z_score([list(s) for s in segs], results)
+        out[name + "_segs"] = np.array(segs, dtype=float)
+        out[name + "_segz"] = np.array([np.nan if isinstance(z, str) else float(z) for z in zs])
+        out[name + "_segz_isstr"] = np.array([isinstance(z, str) for z in zs])
+    save("pipeline.npz", **out)
+
+
+if __name__ == "__main__":
+    golden_newref_search()
+    golden_pipeline()
