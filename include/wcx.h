@@ -1,0 +1,139 @@
+/* wcx.h -- C-ABI of libwcx_hip.so: the MI355X (gfx950) implementation of the WisecondorX
+ * newref / predict hot path.  Plain pointers and sizes only; every entry point returns an
+ * int status (0 = WCX_OK) and records a message retrievable with wcx_last_error().
+ *
+ * The reference (CenterForMedicalGeneticsGhent/WisecondorX v1.2.10) has no FFI: its seams
+ * are Python functions.  Each entry point below names the reference call site it replaces
+ * (paths relative to src/wisecondorx/).  INTEGRATION.md shows the ctypes binding a
+ * maintainer would add at each of those call sites.
+ *
+ * Conventions
+ *  - "Xs" is the PCA-corrected bin-feature matrix in SAMPLE-MAJOR layout double[S][B]; these
+ *    are exactly the bytes of the Fortran-ordered (B,S) array newref_tools.train_pca returns
+ *    (newref_tools.py:147) and newref_control saves (newref_control.py:68), so a NumPy
+ *    F-ordered array is passed zero-copy.
+ *  - chr_cum[n_chr] = masked_bins_per_chr_cum (newref_control.py:64-66); chromosome c owns
+ *    rows [chr_cum[c-1], chr_cum[c]).
+ *  - Reference-bin indices are in the reference's "own chromosome removed" index space
+ *    (newref_tools.py:192-202): candidate row g of a target in chromosome [cs,ce) is stored
+ *    as g if g < cs, else g-(ce-cs).
+ *  - *_dev entry points take DEVICE pointers and are asynchronous on the context's stream;
+ *    the others take HOST pointers and are synchronous.
+ */
+#ifndef WCX_H
+#define WCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WCX_OK 0
+#define WCX_ERR_ARG 1
+#define WCX_ERR_HIP 2
+#define WCX_ERR_NOMEM 3
+#define WCX_ERR_UNSUPPORTED 4
+
+typedef struct wcx_ctx wcx_ctx; /* one per (process, GPU): device id, stream, scratch */
+typedef struct wcx_ref wcx_ref; /* a reference (indexes/distances) resident in HBM    */
+
+int wcx_version(void);
+const char *wcx_last_error(void); /* thread-local, never NULL */
+
+/* ---- context / memory ------------------------------------------------------------- */
+/* stream == NULL: the context creates (and owns) its own HIP stream; otherwise the caller's
+ * hipStream_t is used (e.g. torch.cuda.current_stream().cuda_stream). */
+int wcx_ctx_create(int device, void *stream, wcx_ctx **out);
+int wcx_ctx_destroy(wcx_ctx *ctx);
+int wcx_sync(wcx_ctx *ctx);
+int wcx_malloc(wcx_ctx *ctx, size_t bytes, void **dptr);
+int wcx_free(wcx_ctx *ctx, void *dptr);
+int wcx_memcpy_h2d(wcx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int wcx_memcpy_d2h(wcx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* Duration in ms of the last launch of the named kernel group on this context, measured
+ * with hipEvents on the context's stream ("topk", "null_ratios", "normalize", "cutoff",
+ * "weights", "cbs", "segment_z"); synchronises the stream.  <0 if never launched. */
+double wcx_last_kernel_ms(wcx_ctx *ctx, const char *name);
+/* Counters of the last wcx_newref_topk*: [0] rows searched, [1] candidate pairs evaluated,
+ * [2] shortlist compactions, [3] rows that fell back to the exact brute-force path. */
+int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[4]);
+
+/* ---- newref: reference-bin search ------------------------------------------------- */
+/* Replaces newref_tools.get_ref_for_bins (newref_tools.py:255-278) as driven by
+ * newref_tools.get_reference (newref_tools.py:176-206) for target rows
+ * [row_begin,row_end): for every target row, the k candidate rows outside its own
+ * chromosome with the smallest squared Euclidean distance
+ *   d = sum_{j=0..S-1} (X[c][j]-X[t][j])^2   (sequential fp64, separately rounded -- the
+ *   value NumPy produces at newref_tools.py:260 on the F-ordered matrix),
+ * ordered by (d, candidate index) ascending; candidates with d >= 1e10 or NaN are never
+ * admitted; short rows are padded with index -1 / distance 1e10.
+ * As in newref_tools.py:186-191, when n_chr > 22 (a gonosomal pass) only rows of chromosome
+ * index 22/23 (X/Y) are searched; other rows get index 0 / distance 1.
+ * mode: 0 = auto, 1 = exact fp64 brute force, 2 = MFMA screen + exact fp64 refine.
+ * out_idx int32[row_end-row_begin][k], out_dist double[row_end-row_begin][k]. */
+int wcx_newref_topk(wcx_ctx *ctx, const double *Xs, int64_t B, int S, const int64_t *chr_cum,
+                    int n_chr, int64_t row_begin, int64_t row_end, int k, int mode,
+                    int32_t *out_idx, double *out_dist);
+int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                        const int64_t *chr_cum /*host*/, int n_chr, int64_t row_begin,
+                        int64_t row_end, int k, int mode, int32_t *d_out_idx,
+                        double *d_out_dist);
+
+/* Replaces the null-ratio loop newref_tools.py:210-223: out[r][m] =
+ * log2(X[row_begin+r][sid[m]] / median_k X[idx[r][k]][sid[m]]), the index row applied to the
+ * FULL bin vector without re-offsetting (reference quirk, newref_tools.py:219-221; index -1
+ * wraps to the last bin as in NumPy).  sample_ids are chosen by the host (random.sample,
+ * newref_tools.py:214-217).  idx int32[n][k]; out double[n][n_ids]. */
+int wcx_null_ratios(wcx_ctx *ctx, const double *Xs, int64_t B, int S, const int32_t *idx,
+                    int64_t row_begin, int64_t row_end, int k, const int32_t *sample_ids,
+                    int n_ids, double *out);
+int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                        const int32_t *d_idx, int64_t row_begin, int64_t row_end, int k,
+                        const int32_t *sample_ids /*host*/, int n_ids, double *d_out);
+
+/* ---- predict ---------------------------------------------------------------------- */
+/* Upload a reference's indexes/distances (reference .npz keys "indexes{ap}",
+ * "distances{ap}", "masked_bins_per_chr_cum{ap}") once per batch. */
+int wcx_ref_upload(wcx_ctx *ctx, const int32_t *idx, const double *dist, int64_t B, int k,
+                   const int64_t *chr_cum, int n_chr, wcx_ref **out);
+int wcx_ref_wrap_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, int64_t B,
+                     int k, const int64_t *chr_cum /*host*/, int n_chr, wcx_ref **out);
+int wcx_ref_free(wcx_ctx *ctx, wcx_ref *ref);
+
+/* Replaces predict_tools.get_optimal_cutoff (predict_tools.py:74-82). */
+int wcx_cutoff(wcx_ctx *ctx, const wcx_ref *ref, int repeats, double *cutoff);
+/* Replaces predict_tools.get_weights (predict_tools.py:152-155): out[B]. */
+int wcx_weights(wcx_ctx *ctx, const wcx_ref *ref, double *out);
+/* Replaces predict_tools.normalize_repeat (predict_tools.py:94-142) for a batch of
+ * n_samples projected sample vectors x double[n_samples][B]: three masked passes, rows from
+ * `ct` (first row of chromosome index `cp`).  Outputs per sample: z,r,n double[B-ct];
+ * m_lr, m_z double[n_samples]. */
+int wcx_predict_normalize(wcx_ctx *ctx, const wcx_ref *ref, const double *x, int n_samples,
+                          double cutoff, int64_t ct, int cp, double *out_z, double *out_r,
+                          double *out_n, double *out_mlr, double *out_mz);
+int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_x,
+                              int n_samples, double cutoff, int64_t ct, int cp,
+                              double *d_out_z, double *d_out_r, double *d_out_n,
+                              double *d_out_mlr, double *d_out_mz);
+
+/* Replaces predict_tools.exec_cbs -> overall_tools.exec_R -> include/CBS.R (main.py:279,
+ * predict_tools.py:242-257, CBS.R:21-132): weighted circular binary segmentation of the
+ * per-chromosome log2 ratios.  r,w double[n_bins] (0 = missing), chr_off int64[n_chr+1].
+ * out_seg: rows of 4 doubles {chr (0-based), start (0-based), end (exclusive), ratio};
+ * *out_count receives the number of segments (<= cap). */
+int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_off, int n_chr,
+            double alpha, int64_t binsize, uint64_t seed, double *out_seg, int cap,
+            int *out_count);
+/* Replaces overall_tools.get_z_score (overall_tools.py:88-119).  nr double[n_bins][m]
+ * (rows of masked bins ignored), seg as produced by wcx_cbs; out_z double[n_seg], NaN where
+ * the reference returns the string "nan". */
+int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
+                  const int64_t *chr_off, int n_chr, const double *seg, int n_seg,
+                  double *out_z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WCX_H */

@@ -1,0 +1,115 @@
+"""GPU parity tests of the newref hot path: HIP (through the C-ABI) vs the oracle / golden
+fixtures.  Bit-exact for indices AND distances; null ratios to 1e-12 (log2 is not correctly
+rounded on either side)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from oracle import wcx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nt():
+    from wisecondorx_amd import newref_tools
+    return newref_tools
+
+
+def _X(g, key="Xs", nb=None):
+    X = g[key].T
+    return X if nb is None else np.asfortranarray(X[:nb])
+
+
+@pytest.mark.parametrize("tag", ["A", "A1", "F", "M", "M2"])
+def test_get_reference_golden(nt, g_search, tag):
+    g = g_search
+    mb = g[tag + "_mb"].tolist()
+    cum = np.cumsum(mb).tolist()
+    part, parts = g[tag + "_part"].tolist()
+    X = _X(g, nb=cum[-1])
+    # same seed as tests/golden/make_golden.py so random.sample picks the same null samples
+    random.seed(1000 + len(mb) + part)
+    idx, dist, nr = nt.get_reference(X, mb, cum, 40, part, parts)
+    assert idx.dtype == np.int32 and dist.dtype == np.float64
+    assert np.array_equal(idx, g[tag + "_idx"])
+    assert np.array_equal(dist, g[tag + "_dist"])
+    np.testing.assert_allclose(nr, g[tag + "_nr"], rtol=1e-12, atol=1e-13, equal_nan=True)
+
+
+@pytest.mark.parametrize("tag,cs,ce,k", [("tie", 20, 50, 25), ("few", 10, 18, 40),
+                                         ("nan", 20, 30, 45)])
+def test_edge_cases_golden(nt, g_search, tag, cs, ce, k):
+    """ties (stable by index), fewer than k candidates (-1/1e10 padding), NaN/inf/>=1e10
+    candidates never admitted, NaN target row -> all padding."""
+    X = _X(g_search, tag + "_Xs")
+    B = X.shape[0]
+    idx, dist = nt.get_ref_for_rows(X, [cs, ce, B], k, cs, ce)
+    assert np.array_equal(idx, g_search[tag + "_idx"])
+    assert np.array_equal(dist, g_search[tag + "_dist"])
+
+
+@pytest.mark.parametrize("S,k,seed", [(100, 300, 0), (500, 300, 1), (33, 64, 2), (7, 1, 3)])
+def test_seeded_vs_c_oracle(nt, S, k, seed):
+    from wisecondorx_amd.synth import corrected_matrix
+    rng = np.random.default_rng(seed)
+    mb = rng.integers(40, 400, 24).tolist()
+    mb[5] = 0                      # an empty chromosome
+    X, mbpc, cum = corrected_matrix(mb, S, seed=seed)
+    B = cum[-1]
+    for n_chr in (22, 24):
+        Xp = np.asfortranarray(X[:cum[n_chr - 1]])
+        c = cum[:n_chr]
+        s, e = O.get_part(1, 3, c[-1]) if n_chr == 22 else (0, c[-1])
+        idx, dist = nt.get_ref_for_rows(Xp, c, k, s, e)
+        oi, od = CO.get_reference_rows(np.ascontiguousarray(Xp.T), c, s, e, k)
+        assert np.array_equal(idx, oi)
+        assert np.array_equal(dist, od)
+
+
+def test_empty_row_range(nt):
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([30, 30, 30], 8, seed=5)
+    idx, dist = nt.get_ref_for_rows(X, cum, 10, 17, 17)
+    assert idx.shape == (0, 10) and dist.shape == (0, 10)
+
+
+def test_config1_size_properties(nt):
+    """BASELINE config[1] shape (100 kb bins, S=100, k=300): size-independent properties on
+    all rows + bit-exact oracle agreement on a row subsample."""
+    from wisecondorx_amd.synth import bins_per_chr, corrected_matrix
+    bpc = [int(b * 0.93) for b in bins_per_chr(100000)[:22]]
+    X, mbpc, cum = corrected_matrix(bpc, 100, seed=11)
+    B, k = cum[-1], 300
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, B)
+    assert (np.diff(dist, axis=1) >= 0).all()                      # ascending
+    assert (idx >= 0).all()
+    own = np.repeat(np.array(mbpc), np.array(mbpc))
+    assert (idx < (B - own)[:, None]).all()                        # chr-excluded index space
+    srt = np.sort(idx, axis=1)
+    assert (np.diff(srt, axis=1) > 0).all()                        # no duplicates
+    Xs = np.ascontiguousarray(X.T)
+    rows = np.random.default_rng(0).choice(B, 40, replace=False)
+    for t in rows:
+        c = int(np.searchsorted(cum, t, side="right"))
+        cs = cum[c - 1] if c else 0
+        oi, od = CO.topk_rows(Xs, cs, cum[c], int(t), int(t) + 1, k)
+        assert np.array_equal(idx[t], oi[0]) and np.array_equal(dist[t], od[0])
+
+
+def test_null_ratio_index_space_quirk(nt):
+    """The reference applies chr-excluded indices to the FULL vector (newref_tools.py:219-221)."""
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([50, 40, 30], 12, seed=9)
+    idx, dist = nt.get_ref_for_rows(X, cum, 20, 0, cum[-1])
+    ids = list(range(12))
+    nr = nt.get_null_ratios(X, idx, 0, cum[-1], ids)
+    onr = O.null_ratios(X, idx, 0, cum[-1], ids)
+    np.testing.assert_allclose(nr, onr, rtol=1e-12, atol=1e-13)
+    # padding index -1 wraps to the last bin like NumPy
+    idx2 = idx.copy()
+    idx2[:, -3:] = -1
+    np.testing.assert_allclose(nt.get_null_ratios(X, idx2, 0, cum[-1], ids),
+                               O.null_ratios(X, idx2, 0, cum[-1], ids), rtol=1e-12, atol=1e-13)

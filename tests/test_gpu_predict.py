@@ -1,0 +1,92 @@
+"""GPU parity tests of the predict hot path against the reference-generated fixtures
+(tests/golden/pipeline.npz) and the oracle.  Tolerance: north_star states 1e-5 relative for
+z-scores / ratios; the kernels compute in fp64 and differ from NumPy only by summation order,
+so the tests assert 1e-9."""
+import argparse
+
+import numpy as np
+import pytest
+
+from conftest import ref_dict_from_golden, sample_from_counts
+from oracle import wcx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def pt():
+    from wisecondorx_amd import predict_tools
+    return predict_tools
+
+
+@pytest.mark.parametrize("name", ["t0", "t1", "t2"])
+def test_normalize_golden(pt, g_pipe, name):
+    g = g_pipe
+    ref = ref_dict_from_golden(g)
+    gender = str(g[name + "_gender"])
+    sample = sample_from_counts(g[name + "_counts"], g["cohort_bpc"])
+    if gender == "M":
+        sample["23"] = sample["23"] * 2
+        sample["24"] = sample["24"] * 2
+    args = argparse.Namespace(maskrepeats=5)
+    cache = {}
+    for tag, rg in (("A", "A"), ("G", gender)):
+        r, z, w, n, mlr, mz = pt.normalize(args, sample, ref, rg, cache)
+        exp = {k: g["{}_{}_{}".format(name, tag, k)] for k in ("r", "z", "w", "n", "mlr", "mz")}
+        assert np.array_equal(n, exp["n"])
+        np.testing.assert_allclose(r, exp["r"], rtol=RTOL, equal_nan=True)
+        np.testing.assert_allclose(z, exp["z"], rtol=RTOL, atol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(w, exp["w"], rtol=1e-12)
+        np.testing.assert_allclose(mlr, exp["mlr"], rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(mz, exp["mz"], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(pt.get_optimal_cutoff(ref, 5, cache), g[name + "_cutoff"],
+                               rtol=1e-12)
+
+
+def test_batch_equals_single(pt, g_pipe):
+    g = g_pipe
+    ref = ref_dict_from_golden(g)
+    xs = np.stack([g["t0_A_x"], g["t1_A_x"], g["t2_A_x"]])
+    cache = {}
+    cutoff = pt.get_optimal_cutoff(ref, 5, cache)
+    zb, rb, nb, mlrb, mzb = pt.normalize_repeat_batch(xs, ref, cutoff, 0, 0, "", cache)
+    for i in range(3):
+        z, r, n, mlr, mz = pt.normalize_repeat(xs[i], ref, cutoff, 0, 0, "", cache)
+        assert np.array_equal(z, zb[i], equal_nan=True) and np.array_equal(r, rb[i], equal_nan=True)
+        assert np.array_equal(n, nb[i]) and mlr == mlrb[i] and mz == mzb[i]
+
+
+def test_seeded_k300_vs_oracle(pt):
+    """k=300 (8 values per lane), masked bins, degenerate rows."""
+    rng = np.random.default_rng(4)
+    mb = [300, 260, 220, 200, 180, 160, 150, 140, 130, 120, 110, 100, 90, 80, 70, 60, 50, 50,
+          40, 40, 30, 30]
+    cum = np.cumsum(mb)
+    B, k = int(cum[-1]), 300
+    idx = np.empty((B, k), dtype=np.int32)
+    dist = np.sort(rng.gamma(4.0, 0.05, (B, k)), axis=1)
+    for c in range(22):
+        cs = cum[c - 1] if c else 0
+        n_cd = B - mb[c]
+        for i in range(cs, cum[c]):
+            idx[i] = rng.choice(n_cd, k, replace=False)
+    dist[7, :] = 1e10            # a row with no reference bin under the cut-off
+    idx[7, :] = -1
+    ref = {"indexes": idx, "distances": dist, "masked_bins_per_chr": np.array(mb),
+           "masked_bins_per_chr_cum": cum}
+    x = 1.0 + 0.03 * rng.standard_normal(B)
+    x[500:560] *= 1.5            # a gain -> |z| > 2.33 -> masked in later passes
+    x[1000:1010] = 0.0
+    cache = {}
+    cutoff = pt.get_optimal_cutoff(ref, 5, cache)
+    np.testing.assert_allclose(cutoff, O.get_optimal_cutoff(dist, 5), rtol=1e-12)
+    np.testing.assert_allclose(pt.get_weights(ref, "", cache), O.get_weights(dist), rtol=1e-12)
+    z, r, n, mlr, mz = pt.normalize_repeat(x, ref, cutoff, 0, 0, "", cache)
+    oz, orr, on, omlr, omz = O.normalize_repeat(x, mb, cum, idx, dist, cutoff, 0, 0)
+    assert np.array_equal(n, on)
+    np.testing.assert_allclose(r, orr, rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(z, oz, rtol=RTOL, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose([mlr, mz], [omlr, omz], rtol=RTOL, atol=1e-12)
+    assert np.isnan(z[7]) and n[7] == 0

@@ -1,0 +1,146 @@
+"""ctypes binding of libwcx_hip.so (include/wcx.h).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is visible when
+a context is created, the product path raises.  The library is built in-tree by
+`__graft_entry__.build()` / `make -C wisecondorx_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwcx_hip.so")
+
+c_i64 = C.c_int64
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/wcx.h declares.
+SIGNATURES = {
+    "wcx_version": (C.c_int, []),
+    "wcx_last_error": (C.c_char_p, []),
+    "wcx_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "wcx_ctx_destroy": (C.c_int, [vp]),
+    "wcx_sync": (C.c_int, [vp]),
+    "wcx_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "wcx_free": (C.c_int, [vp, vp]),
+    "wcx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "wcx_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "wcx_last_kernel_ms": (C.c_double, [vp, C.c_char_p]),
+    "wcx_last_topk_stats": (C.c_int, [vp, c_i64p]),
+    "wcx_newref_topk": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64p, C.c_int, c_i64, c_i64,
+                                  C.c_int, C.c_int, vp, vp]),
+    "wcx_newref_topk_dev": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64p, C.c_int, c_i64, c_i64,
+                                      C.c_int, C.c_int, vp, vp]),
+    "wcx_null_ratios": (C.c_int, [vp, vp, c_i64, C.c_int, vp, c_i64, c_i64, C.c_int, c_i32p,
+                                  C.c_int, vp]),
+    "wcx_null_ratios_dev": (C.c_int, [vp, vp, c_i64, C.c_int, vp, c_i64, c_i64, C.c_int,
+                                      c_i32p, C.c_int, vp]),
+    "wcx_ref_upload": (C.c_int, [vp, vp, vp, c_i64, C.c_int, c_i64p, C.c_int, C.POINTER(vp)]),
+    "wcx_ref_wrap_dev": (C.c_int, [vp, vp, vp, c_i64, C.c_int, c_i64p, C.c_int, C.POINTER(vp)]),
+    "wcx_ref_free": (C.c_int, [vp, vp]),
+    "wcx_cutoff": (C.c_int, [vp, vp, C.c_int, c_f64p]),
+    "wcx_weights": (C.c_int, [vp, vp, vp]),
+    "wcx_predict_normalize": (C.c_int, [vp, vp, vp, C.c_int, C.c_double, c_i64, C.c_int, vp, vp,
+                                        vp, vp, vp]),
+    "wcx_predict_normalize_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_double, c_i64, C.c_int, vp,
+                                            vp, vp, vp, vp]),
+    "wcx_cbs": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64, vp,
+                          C.c_int, C.POINTER(C.c_int)]),
+    "wcx_segment_z": (C.c_int, [vp, vp, vp, vp, C.c_int, c_i64p, C.c_int, vp, C.c_int, vp]),
+}
+
+
+class WcxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libwcx_hip.so and bind every declared symbol.  Raises if absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WcxError(
+            "{} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C wisecondorx_amd/csrc`. There is no CPU fallback.".format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise WcxError("libwcx_hip error {}: {}".format(rc, load().wcx_last_error().decode()))
+
+
+def ptr(a):
+    """Raw pointer of a NumPy array (must stay alive for the call) or an int address."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(vp)
+    return vp(int(a))
+
+
+def i64_array(v):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.int64))
+    return a, a.ctypes.data_as(c_i64p)
+
+
+def i32_array(v):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.int32))
+    return a, a.ctypes.data_as(c_i32p)
+
+
+class Context:
+    """One per (process, GPU).  `stream` may be a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so launches order with the caller's work."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = vp()
+        check(self.lib.wcx_ctx_create(int(device), vp(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wcx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.wcx_sync(self.h))
+
+    def kernel_ms(self, name):
+        return float(self.lib.wcx_last_kernel_ms(self.h, name.encode()))
+
+    def topk_stats(self):
+        out = (C.c_int64 * 4)()
+        check(self.lib.wcx_last_topk_stats(self.h, out))
+        return {"rows": out[0], "pairs": out[1], "compactions": out[2], "fallback_rows": out[3]}
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,263 @@
+// C-ABI entry points of libwcx_hip.so (see include/wcx.h): context, memory, and the host-side
+// orchestration of the newref search.  Kernels live in the sibling .hip files.
+#include "wcx_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void wcx_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int wcx_scratch(wcx_ctx *ctx, size_t bytes, void **out) {
+  if (bytes > ctx->scratch_bytes) {
+    if (ctx->scratch) {
+      WCX_HIP(hipStreamSynchronize(ctx->stream));
+      WCX_HIP(hipFree(ctx->scratch));
+      ctx->scratch = nullptr;
+      ctx->scratch_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ctx->scratch, bytes);
+    if (e != hipSuccess) {
+      wcx_set_error("hipMalloc(%zu bytes scratch) failed: %s", bytes, hipGetErrorString(e));
+      return WCX_ERR_NOMEM;
+    }
+    ctx->scratch_bytes = bytes;
+  }
+  *out = ctx->scratch;
+  return WCX_OK;
+}
+
+int wcx_scratch2(wcx_ctx *ctx, size_t bytes, void **out) {
+  if (bytes > ctx->scratch2_bytes) {
+    if (ctx->scratch2) {
+      WCX_HIP(hipStreamSynchronize(ctx->stream));
+      WCX_HIP(hipFree(ctx->scratch2));
+      ctx->scratch2 = nullptr;
+      ctx->scratch2_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ctx->scratch2, bytes);
+    if (e != hipSuccess) {
+      wcx_set_error("hipMalloc(%zu bytes scratch2) failed: %s", bytes, hipGetErrorString(e));
+      return WCX_ERR_NOMEM;
+    }
+    ctx->scratch2_bytes = bytes;
+  }
+  *out = ctx->scratch2;
+  return WCX_OK;
+}
+
+int wcx_upload_small(wcx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+  if (ctx->stage.size() > 64) {
+    WCX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stage.clear();
+  }
+  ctx->stage.emplace_back((const unsigned char *)src_host, (const unsigned char *)src_host + bytes);
+  WCX_HIP(hipMemcpyAsync(dst_dev, ctx->stage.back().data(), bytes, hipMemcpyHostToDevice,
+                         ctx->stream));
+  return WCX_OK;
+}
+
+int wcx_timer_begin(wcx_ctx *ctx, const char *name) {
+  KernelTimer &t = ctx->timers[name];
+  if (!t.start) {
+    WCX_HIP(hipEventCreate(&t.start));
+    WCX_HIP(hipEventCreate(&t.stop));
+  }
+  WCX_HIP(hipEventRecord(t.start, ctx->stream));
+  return WCX_OK;
+}
+
+int wcx_timer_end(wcx_ctx *ctx, const char *name) {
+  KernelTimer &t = ctx->timers[name];
+  WCX_HIP(hipEventRecord(t.stop, ctx->stream));
+  t.used = true;
+  return WCX_OK;
+}
+
+extern "C" {
+
+int wcx_version(void) { return 100; }
+
+const char *wcx_last_error(void) { return g_err; }
+
+int wcx_ctx_create(int device, void *stream, wcx_ctx **out) {
+  WCX_ARG(out != nullptr, "out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    wcx_set_error("no HIP device available (%s); libwcx_hip.so has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    return WCX_ERR_HIP;
+  }
+  WCX_ARG(device >= 0 && device < n, "device index out of range");
+  WCX_HIP(hipSetDevice(device));
+  wcx_ctx *ctx = new wcx_ctx();
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    ctx->own_stream = false;
+  } else {
+    WCX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  WCX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 64));
+  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
+  *out = ctx;
+  return WCX_OK;
+}
+
+int wcx_ctx_destroy(wcx_ctx *ctx) {
+  if (!ctx) return WCX_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->timers) {
+    if (kv.second.start) hipEventDestroy(kv.second.start);
+    if (kv.second.stop) hipEventDestroy(kv.second.stop);
+  }
+  if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->scratch2) hipFree(ctx->scratch2);
+  if (ctx->d_stats) hipFree(ctx->d_stats);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return WCX_OK;
+}
+
+int wcx_sync(wcx_ctx *ctx) {
+  WCX_ARG(ctx, "ctx is NULL");
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+int wcx_malloc(wcx_ctx *ctx, size_t bytes, void **dptr) {
+  WCX_ARG(ctx && dptr, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    wcx_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return WCX_ERR_NOMEM;
+  }
+  return WCX_OK;
+}
+
+int wcx_free(wcx_ctx *ctx, void *dptr) {
+  WCX_ARG(ctx, "ctx is NULL");
+  if (dptr) {
+    WCX_HIP(hipStreamSynchronize(ctx->stream));
+    WCX_HIP(hipFree(dptr));
+  }
+  return WCX_OK;
+}
+
+int wcx_memcpy_h2d(wcx_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  WCX_ARG(ctx && dst && src, "NULL argument");
+  WCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+int wcx_memcpy_d2h(wcx_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  WCX_ARG(ctx && dst && src, "NULL argument");
+  WCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+double wcx_last_kernel_ms(wcx_ctx *ctx, const char *name) {
+  if (!ctx || !name) return -1.0;
+  auto it = ctx->timers.find(name);
+  if (it == ctx->timers.end() || !it->second.used) return -1.0;
+  if (hipEventSynchronize(it->second.stop) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, it->second.start, it->second.stop) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[4]) {
+  WCX_ARG(ctx && out, "NULL argument");
+  unsigned long long h[4] = {0, 0, 0, 0};
+  WCX_HIP(hipMemcpyAsync(h, ctx->d_stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  out[0] = ctx->topk_stats[0];
+  out[1] = ctx->topk_stats[1];
+  out[2] = (int64_t)h[2];
+  out[3] = (int64_t)h[3];
+  return WCX_OK;
+}
+
+// ------------------------------------------------------------------ newref search (a4-a6)
+int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                        const int64_t *chr_cum, int n_chr, int64_t row_begin, int64_t row_end,
+                        int k, int mode, int32_t *d_out_idx, double *d_out_dist) {
+  WCX_ARG(ctx && dXs && chr_cum && d_out_idx && d_out_dist, "NULL argument");
+  WCX_ARG(B > 0 && S > 0 && n_chr > 0 && k > 0, "B, S, n_chr, k must be positive");
+  WCX_ARG(chr_cum[n_chr - 1] == B, "chr_cum[n_chr-1] must equal B");
+  WCX_ARG(0 <= row_begin && row_begin <= row_end && row_end <= B, "bad row range");
+  WCX_ARG(B < (int64_t)0x7fffffff, "B must fit in int32 (indices are int32)");
+  WCX_ARG(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+  WCX_HIP(hipSetDevice(ctx->device));
+  const int64_t n_rows = row_end - row_begin;
+  if (n_rows == 0) return WCX_OK;
+
+  // Split the row range into per-chromosome blocks of <= 64 target rows
+  // (newref_tools._split_by_chr + the clamps at newref_tools.py:181-184).
+  std::vector<TopkBlock> blocks;
+  int64_t pairs = 0, searched = 0;
+  for (int c = 0; c < n_chr; ++c) {
+    const int64_t cs = c ? chr_cum[c - 1] : 0, ce = chr_cum[c];
+    WCX_ARG(ce >= cs, "chr_cum must be non-decreasing");
+    const int64_t lo = cs > row_begin ? cs : row_begin;
+    const int64_t hi = ce < row_end ? ce : row_end;
+    if (lo >= hi) continue;
+    if (n_chr > 22 && c != 22 && c != 23) {  // newref_tools.py:186-191
+      int rc = wcx_fill_dummy_rows(ctx, d_out_idx, d_out_dist, lo - row_begin, hi - row_begin, k);
+      if (rc) return rc;
+      continue;
+    }
+    for (int64_t r = lo; r < hi; r += 64) {
+      TopkBlock b;
+      b.row0 = r;
+      b.nrows = (int32_t)((hi - r) < 64 ? (hi - r) : 64);
+      b.pad = 0;
+      b.cs = cs;
+      b.ce = ce;
+      blocks.push_back(b);
+    }
+    searched += hi - lo;
+    pairs += (hi - lo) * (B - (ce - cs));
+  }
+  ctx->topk_stats[0] = searched;
+  ctx->topk_stats[1] = pairs;
+  (void)mode;
+  return wcx_topk_exact_launch(ctx, dXs, B, S, blocks, row_begin, n_rows, k, d_out_idx,
+                               d_out_dist);
+}
+
+int wcx_newref_topk(wcx_ctx *ctx, const double *Xs, int64_t B, int S, const int64_t *chr_cum,
+                    int n_chr, int64_t row_begin, int64_t row_end, int k, int mode,
+                    int32_t *out_idx, double *out_dist) {
+  WCX_ARG(ctx && Xs && out_idx && out_dist, "NULL argument");
+  WCX_ARG(B > 0 && S > 0 && k > 0 && row_end >= row_begin, "bad sizes");
+  WCX_HIP(hipSetDevice(ctx->device));
+  const int64_t n_rows = row_end - row_begin;
+  const size_t xb = (size_t)B * S * 8, ib = (size_t)n_rows * k * 4, db = (size_t)n_rows * k * 8;
+  void *buf = nullptr;
+  int rc = wcx_scratch2(ctx, xb + ib + db + 64, &buf);
+  if (rc) return rc;
+  double *dX = reinterpret_cast<double *>(buf);
+  double *dD = reinterpret_cast<double *>(reinterpret_cast<char *>(buf) + xb);
+  int32_t *dI = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(buf) + xb + db);
+  WCX_HIP(hipMemcpyAsync(dX, Xs, xb, hipMemcpyHostToDevice, ctx->stream));
+  rc = wcx_newref_topk_dev(ctx, dX, B, S, chr_cum, n_chr, row_begin, row_end, k, mode, dI, dD);
+  if (rc) return rc;
+  if (n_rows) {
+    WCX_HIP(hipMemcpyAsync(out_idx, dI, ib, hipMemcpyDeviceToHost, ctx->stream));
+    WCX_HIP(hipMemcpyAsync(out_dist, dD, db, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+}  // extern "C"

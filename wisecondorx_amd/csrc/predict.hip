@@ -1,0 +1,444 @@
+// predict hot path: distance cut-off, weights, and the three
+// masked within-sample normalisation passes.  All kernels are gather/scan work over the
+// reference's indexes/distances held in HBM: HBM-bandwidth bound (B*k*4 bytes of indices per
+// pass, B*k*8 bytes of distances per cut-off sweep).
+#include "wave_sort.h"
+#include "wcx_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr double Z_MASK = 2.3263478740408408;  // scipy.stats.norm.ppf(0.99), predict_tools.py:104
+
+// ------------------------------------------------------------------------------------------
+// a11 get_optimal_cutoff (predict_tools.py:74-82): repeats x { mean, std of dist < cutoff }.
+// state[0]=cutoff state[1]=mean state[2]=count
+__global__ __launch_bounds__(NT) void k_cut_partial(const double *__restrict__ d, int64_t n,
+                                                    const double *__restrict__ state, int phase,
+                                                    double *__restrict__ part_sum,
+                                                    double *__restrict__ part_cnt) {
+  const double cutoff = state[0];
+  const double mean = state[1];
+  double s = 0.0, c = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * NT * 2;
+  for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 2; i < n; i += stride) {
+    double2 v;
+    if (i + 1 < n) v = *reinterpret_cast<const double2 *>(d + i);
+    else { v.x = d[i]; v.y = __builtin_nan(""); }
+    if (v.x < cutoff) { if (phase == 0) { s += v.x; c += 1.0; } else { double e = v.x - mean; s += e * e; } }
+    if (v.y < cutoff) { if (phase == 0) { s += v.y; c += 1.0; } else { double e = v.y - mean; s += e * e; } }
+  }
+  __shared__ double sh_s[NT / 64], sh_c[NT / 64];
+  s = wcx::wave_sum(s);
+  c = wcx::wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { sh_s[threadIdx.x >> 6] = s; sh_c[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (int w = 0; w < NT / 64; ++w) { ts += sh_s[w]; tc += sh_c[w]; }
+    part_sum[blockIdx.x] = ts;
+    part_cnt[blockIdx.x] = tc;
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_cut_final(double *__restrict__ state, int phase,
+                                                  const double *__restrict__ part_sum,
+                                                  const double *__restrict__ part_cnt, int nparts) {
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += NT) { s += part_sum[i]; c += part_cnt[i]; }
+  __shared__ double sh_s[NT / 64], sh_c[NT / 64];
+  s = wcx::wave_sum(s);
+  c = wcx::wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { sh_s[threadIdx.x >> 6] = s; sh_c[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (int w = 0; w < NT / 64; ++w) { ts += sh_s[w]; tc += sh_c[w]; }
+    if (phase == 0) {
+      state[2] = tc;
+      state[1] = ts / tc;                       // np.average
+    } else {
+      const double sd = sqrt(ts / state[2]);    // np.std (population)
+      state[0] = state[1] + 3.0 * sd;           // predict_tools.py:81
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a12 get_weights (predict_tools.py:152-155): w_i = 1 / mean_k sqrt(dist[i][k]); wave per row.
+__global__ __launch_bounds__(NT) void k_weights(const double *__restrict__ dist, int64_t B, int k,
+                                                double *__restrict__ out) {
+  const int lane = wcx::lane_id();
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  for (int64_t i = w0; i < B; i += nw) {
+    double s = 0.0;
+    for (int t = lane; t < k; t += 64) s += sqrt(dist[i * (int64_t)k + t]);
+    s = wcx::wave_sum(s);
+    if (lane == 0) out[i] = 1.0 / (s / (double)k);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a13: selection mask  sel[i][q] = ballot( dist[i][q*64+lane] < cutoff )   (predict_tools.py:133)
+__global__ __launch_bounds__(NT) void k_select_mask(const double *__restrict__ dist, int64_t B,
+                                                    int k, int ipl, double cutoff, int64_t ct,
+                                                    unsigned long long *__restrict__ sel) {
+  const int lane = wcx::lane_id();
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  for (int64_t i = ct + w0; i < B; i += nw) {
+    for (int q = 0; q < ipl; ++q) {
+      const int t = q * 64 + lane;
+      const bool s = (t < k) && (dist[i * (int64_t)k + t] < cutoff);
+      const unsigned long long m = __ballot(s);
+      if (lane == 0) sel[i * ipl + q] = m;
+    }
+  }
+}
+
+struct ChrTable {
+  int n_chr;
+  int64_t cum[32];
+};
+
+// One masked pass of _normalize_once (predict_tools.py:111-142) for a batch of samples.
+// grid.y = sample.  copy_in/copy_out: ping-pong of test_copy (predict_tools.py:98,104).
+template <int IPL>
+__global__ __launch_bounds__(NT) void k_normalize_pass(
+    const double *__restrict__ x, const double *__restrict__ copy_in,
+    double *__restrict__ copy_out, const int32_t *__restrict__ idx,
+    const unsigned long long *__restrict__ sel, int64_t B, int k, int64_t ct, ChrTable chr,
+    double *__restrict__ out_z, double *__restrict__ out_r, double *__restrict__ out_n,
+    double *__restrict__ out_lr, int last_pass) {
+  const int lane = wcx::lane_id();
+  const int s = blockIdx.y;
+  const double *xs = x + (int64_t)s * B;
+  const double *cin = copy_in + (int64_t)s * B;
+  double *cout = copy_out + (int64_t)s * B;
+  const int64_t Bp = B - ct;
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  for (int64_t i = ct + w0; i < B; i += nw) {
+    // own chromosome [cs,ce) of row i
+    int64_t cs = 0, ce = chr.cum[0];
+    for (int c = 1; c < chr.n_chr && i >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+    const int64_t own = ce - cs;
+    const int64_t len_cd = B - own;  // len(chr_data), predict_tools.py:125-130
+    double v[IPL];
+    int nloc = 0;
+    unsigned int keepmask = 0;
+    double sloc = 0.0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const int t = q * 64 + lane;
+      const bool selq = (t < k) && ((sel[i * IPL + q] >> lane) & 1ull);
+      double val = HUGE_VAL;
+      bool keep = false;
+      if (selq) {
+        int64_t c = idx[i * (int64_t)k + t];
+        if (c < 0) c += len_cd;                       // NumPy negative index
+        const int64_t g = c < cs ? c : c + own;       // chr_data index -> row
+        const double cv = cin[g];
+        keep = cv >= 0.0;                             // predict_tools.py:134
+        if (keep) val = cv;
+      }
+      v[q] = val;
+      if (keep) { nloc += 1; sloc += val; keepmask |= 1u << q; }
+    }
+    const int n = wcx::wave_sum_i(nloc);
+    const double mean = wcx::wave_sum(sloc) / (double)n;
+    double ssl = 0.0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      if ((keepmask >> q) & 1u) { const double e = v[q] - mean; ssl += e * e; }
+    }
+    const double sd = sqrt(wcx::wave_sum(ssl) / (double)n);
+    wcx::wave_bitonic_sort<IPL>(v);
+    const double med = wcx::wave_median_sorted<IPL>(v, n);
+    if (lane == 0) {
+      const double xi = xs[i];
+      const double z = (xi - mean) / sd;              // predict_tools.py:136
+      const double r = xi / med;                      // predict_tools.py:137
+      const int64_t o = (int64_t)s * Bp + (i - ct);
+      out_z[o] = z;
+      out_r[o] = r;
+      out_n[o] = (double)n;
+      if (last_pass) out_lr[o] = log2(r);
+      cout[i] = (fabs(z) >= Z_MASK) ? -1.0 : cin[i];  // predict_tools.py:104
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// np.nanmedian of a double array by 8-bit MSD radix select (one workgroup per array).
+__device__ __forceinline__ unsigned long long f64_key(double x) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long kx) {
+  unsigned long long b = (kx >> 63) ? (kx & 0x7fffffffffffffffull) : ~kx;
+  return __longlong_as_double((long long)b);
+}
+
+constexpr int NTM = 1024;
+
+__global__ __launch_bounds__(NTM) void k_nanmedian(const double *__restrict__ a0, int64_t n,
+                                                   int64_t array_stride, double *__restrict__ out) {
+  const double *a = a0 + (int64_t)blockIdx.x * array_stride;
+  __shared__ unsigned int hist[2][256];
+  __shared__ unsigned long long prefix[2];
+  __shared__ long long rank[2];
+  __shared__ long long nvalid;
+  const int tid = threadIdx.x;
+  if (tid == 0) nvalid = 0;
+  __syncthreads();
+  long long loc = 0;
+  for (int64_t i = tid; i < n; i += NTM) { const double x = a[i]; loc += (x == x); }
+  loc = (long long)wcx::wave_sum_i((int)loc);
+  if ((tid & 63) == 0) atomicAdd((unsigned long long *)&nvalid, (unsigned long long)loc);
+  __syncthreads();
+  const long long nv = nvalid;
+  if (nv == 0) { if (tid == 0) out[blockIdx.x] = __builtin_nan(""); return; }
+  if (tid == 0) { rank[0] = (nv - 1) / 2; rank[1] = nv / 2; prefix[0] = 0; prefix[1] = 0; }
+  unsigned long long himask = 0;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (tid < 256) { hist[0][tid] = 0; hist[1][tid] = 0; }
+    __syncthreads();
+    const unsigned long long p0 = prefix[0], p1 = prefix[1];
+    for (int64_t i = tid; i < n; i += NTM) {
+      const double x = a[i];
+      if (x == x) {
+        const unsigned long long kx = f64_key(x);
+        const unsigned int dg = (unsigned int)((kx >> shift) & 255ull);
+        if ((kx & himask) == p0) atomicAdd(&hist[0][dg], 1u);
+        if ((kx & himask) == p1) atomicAdd(&hist[1][dg], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < 2) {
+      long long rk = rank[tid];
+      int dg = 0;
+      for (; dg < 256; ++dg) {
+        const long long h = hist[tid][dg];
+        if (rk < h) break;
+        rk -= h;
+      }
+      rank[tid] = rk;
+      prefix[tid] |= ((unsigned long long)dg) << shift;
+    }
+    himask |= 255ull << shift;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double lo = key_f64(prefix[0]), hi = key_f64(prefix[1]);
+    out[blockIdx.x] = (nv & 1) ? lo : (lo + hi) / 2.0;
+  }
+}
+
+__global__ void k_copy2(const double *__restrict__ src, double *__restrict__ a,
+                        double *__restrict__ b, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const double v = src[i]; a[i] = v; b[i] = v; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int wcx_ref_wrap_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, int64_t B, int k,
+                     const int64_t *chr_cum, int n_chr, wcx_ref **out) {
+  WCX_ARG(ctx && d_idx && d_dist && chr_cum && out, "NULL argument");
+  WCX_ARG(B > 0 && k > 0 && n_chr > 0 && n_chr <= 32, "bad sizes (n_chr <= 32)");
+  WCX_ARG(chr_cum[n_chr - 1] == B, "chr_cum[n_chr-1] must equal B");
+  wcx_ref *r = new wcx_ref();
+  r->d_idx = d_idx;
+  r->d_dist = d_dist;
+  r->owned = false;
+  r->B = B;
+  r->k = k;
+  r->chr_cum.assign(chr_cum, chr_cum + n_chr);
+  *out = r;
+  return WCX_OK;
+}
+
+int wcx_ref_upload(wcx_ctx *ctx, const int32_t *idx, const double *dist, int64_t B, int k,
+                   const int64_t *chr_cum, int n_chr, wcx_ref **out) {
+  WCX_ARG(ctx && idx && dist && chr_cum && out, "NULL argument");
+  WCX_ARG(B > 0 && k > 0, "bad sizes");
+  WCX_HIP(hipSetDevice(ctx->device));
+  void *di = nullptr, *dd = nullptr;
+  const size_t ib = (size_t)B * k * 4, db = (size_t)B * k * 8;
+  if (hipMalloc(&di, ib) != hipSuccess || hipMalloc(&dd, db) != hipSuccess) {
+    if (di) hipFree(di);
+    wcx_set_error("hipMalloc failed for a %lld x %d reference", (long long)B, k);
+    return WCX_ERR_NOMEM;
+  }
+  WCX_HIP(hipMemcpyAsync(di, idx, ib, hipMemcpyHostToDevice, ctx->stream));
+  WCX_HIP(hipMemcpyAsync(dd, dist, db, hipMemcpyHostToDevice, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  int rc = wcx_ref_wrap_dev(ctx, (const int32_t *)di, (const double *)dd, B, k, chr_cum, n_chr, out);
+  if (rc) { hipFree(di); hipFree(dd); return rc; }
+  (*out)->owned = true;
+  return WCX_OK;
+}
+
+int wcx_ref_free(wcx_ctx *ctx, wcx_ref *ref) {
+  if (!ref) return WCX_OK;
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (ref->owned) {
+    hipFree(const_cast<int32_t *>(ref->d_idx));
+    hipFree(const_cast<double *>(ref->d_dist));
+  }
+  delete ref;
+  return WCX_OK;
+}
+
+int wcx_cutoff(wcx_ctx *ctx, const wcx_ref *ref, int repeats, double *cutoff) {
+  WCX_ARG(ctx && ref && cutoff, "NULL argument");
+  WCX_ARG(repeats >= 0, "repeats must be >= 0");
+  WCX_HIP(hipSetDevice(ctx->device));
+  const int64_t n = ref->B * (int64_t)ref->k;
+  const int nparts = 2048;
+  void *scr = nullptr;
+  int rc = wcx_scratch(ctx, (size_t)(2 * nparts + 8) * 8, &scr);
+  if (rc) return rc;
+  double *state = reinterpret_cast<double *>(scr);
+  double *ps = state + 8, *pc = ps + nparts;
+  const double init[3] = {HUGE_VAL, 0.0, 0.0};
+  rc = wcx_upload_small(ctx, state, init, sizeof(init));
+  if (rc) return rc;
+  rc = wcx_timer_begin(ctx, "cutoff");
+  if (rc) return rc;
+  for (int rep = 0; rep < repeats; ++rep) {
+    for (int phase = 0; phase < 2; ++phase) {
+      k_cut_partial<<<nparts, NT, 0, ctx->stream>>>(ref->d_dist, n, state, phase, ps, pc);
+      k_cut_final<<<1, NT, 0, ctx->stream>>>(state, phase, ps, pc, nparts);
+    }
+  }
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "cutoff");
+  if (rc) return rc;
+  WCX_HIP(hipMemcpyAsync(cutoff, state, 8, hipMemcpyDeviceToHost, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+int wcx_weights(wcx_ctx *ctx, const wcx_ref *ref, double *out) {
+  WCX_ARG(ctx && ref && out, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  void *scr = nullptr;
+  int rc = wcx_scratch(ctx, (size_t)ref->B * 8, &scr);
+  if (rc) return rc;
+  rc = wcx_timer_begin(ctx, "weights");
+  if (rc) return rc;
+  const unsigned grid = (unsigned)((ref->B + 3) / 4 < 8192 ? (ref->B + 3) / 4 : 8192);
+  k_weights<<<grid, NT, 0, ctx->stream>>>(ref->d_dist, ref->B, ref->k, (double *)scr);
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "weights");
+  if (rc) return rc;
+  WCX_HIP(hipMemcpyAsync(out, scr, (size_t)ref->B * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_x, int n_samples,
+                              double cutoff, int64_t ct, int cp, double *d_out_z,
+                              double *d_out_r, double *d_out_n, double *d_out_mlr,
+                              double *d_out_mz) {
+  WCX_ARG(ctx && ref && d_x && d_out_z && d_out_r && d_out_n && d_out_mlr && d_out_mz,
+          "NULL argument");
+  WCX_ARG(n_samples > 0, "n_samples must be positive");
+  const int64_t B = ref->B;
+  const int k = ref->k;
+  const int n_chr = (int)ref->chr_cum.size();
+  WCX_ARG(cp >= 0 && cp < n_chr, "cp out of range");
+  WCX_ARG(ct == (cp ? ref->chr_cum[cp - 1] : 0), "ct must be the first row of chromosome cp");
+  WCX_HIP(hipSetDevice(ctx->device));
+  if (k > 64 * 32) {
+    wcx_set_error("refsize %d too large for the normalise kernel (max 2048)", k);
+    return WCX_ERR_UNSUPPORTED;
+  }
+  int ipl = 1;
+  while (64 * ipl < k) ipl <<= 1;
+  const int64_t Bp = B - ct;
+  if (Bp <= 0) return WCX_OK;
+
+  // scratch: sel[B][ipl] u64 | copyA[n][B] | copyB[n][B] | lr[n][Bp]
+  const size_t sel_b = (size_t)B * ipl * 8;
+  const size_t cp_b = (size_t)n_samples * B * 8;
+  const size_t lr_b = (size_t)n_samples * Bp * 8;
+  void *scr = nullptr;
+  int rc = wcx_scratch(ctx, sel_b + 2 * cp_b + lr_b, &scr);
+  if (rc) return rc;
+  unsigned long long *sel = reinterpret_cast<unsigned long long *>(scr);
+  double *cA = reinterpret_cast<double *>(reinterpret_cast<char *>(scr) + sel_b);
+  double *cB = cA + (size_t)n_samples * B;
+  double *lr = cB + (size_t)n_samples * B;
+
+  ChrTable tab;
+  tab.n_chr = n_chr;
+  for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? ref->chr_cum[c] : B;
+
+  rc = wcx_timer_begin(ctx, "normalize");
+  if (rc) return rc;
+  const int64_t ntot = (int64_t)n_samples * B;
+  k_copy2<<<(unsigned)((ntot + 255) / 256), 256, 0, ctx->stream>>>(d_x, cA, cB, ntot);
+  const unsigned gsel = (unsigned)((Bp + 3) / 4 < 16384 ? (Bp + 3) / 4 : 16384);
+  k_select_mask<<<gsel, NT, 0, ctx->stream>>>(ref->d_dist, B, k, ipl, cutoff, ct, sel);
+  dim3 grid((unsigned)((Bp + 3) / 4 < 16384 ? (Bp + 3) / 4 : 16384), (unsigned)n_samples);
+  for (int pass = 0; pass < 3; ++pass) {  // predict_tools.py:99
+    const double *cin = (pass & 1) ? cB : cA;
+    double *cout = (pass & 1) ? cA : cB;
+    const int last = pass == 2;
+#define WCX_NORM_LAUNCH(IPL)                                                                   \
+  k_normalize_pass<IPL><<<grid, NT, 0, ctx->stream>>>(d_x, cin, cout, ref->d_idx, sel, B, k, ct, \
+                                                      tab, d_out_z, d_out_r, d_out_n, lr, last)
+    switch (ipl) {
+      case 1: WCX_NORM_LAUNCH(1); break;
+      case 2: WCX_NORM_LAUNCH(2); break;
+      case 4: WCX_NORM_LAUNCH(4); break;
+      case 8: WCX_NORM_LAUNCH(8); break;
+      case 16: WCX_NORM_LAUNCH(16); break;
+      default: WCX_NORM_LAUNCH(32); break;
+    }
+#undef WCX_NORM_LAUNCH
+  }
+  // m_lr = nanmedian(log2 r), m_z = nanmedian(z)   (predict_tools.py:105-106)
+  k_nanmedian<<<(unsigned)n_samples, NTM, 0, ctx->stream>>>(lr, Bp, Bp, d_out_mlr);
+  k_nanmedian<<<(unsigned)n_samples, NTM, 0, ctx->stream>>>(d_out_z, Bp, Bp, d_out_mz);
+  WCX_HIP(hipGetLastError());
+  return wcx_timer_end(ctx, "normalize");
+}
+
+int wcx_predict_normalize(wcx_ctx *ctx, const wcx_ref *ref, const double *x, int n_samples,
+                          double cutoff, int64_t ct, int cp, double *out_z, double *out_r,
+                          double *out_n, double *out_mlr, double *out_mz) {
+  WCX_ARG(ctx && ref && x && out_z && out_r && out_n && out_mlr && out_mz, "NULL argument");
+  WCX_ARG(n_samples > 0, "n_samples must be positive");
+  WCX_HIP(hipSetDevice(ctx->device));
+  const int64_t B = ref->B, Bp = B - ct;
+  WCX_ARG(Bp >= 0, "ct beyond the last row");
+  const size_t xb = (size_t)n_samples * B * 8, ob = (size_t)n_samples * (Bp > 0 ? Bp : 0) * 8;
+  void *buf = nullptr;
+  int rc = wcx_scratch2(ctx, xb + 3 * ob + (size_t)n_samples * 16 + 64, &buf);
+  if (rc) return rc;
+  double *dx = reinterpret_cast<double *>(buf);
+  double *dz = dx + (size_t)n_samples * B;
+  double *dr = dz + ob / 8, *dn = dr + ob / 8;
+  double *dmlr = dn + ob / 8, *dmz = dmlr + n_samples;
+  WCX_HIP(hipMemcpyAsync(dx, x, xb, hipMemcpyHostToDevice, ctx->stream));
+  rc = wcx_predict_normalize_dev(ctx, ref, dx, n_samples, cutoff, ct, cp, dz, dr, dn, dmlr, dmz);
+  if (rc) return rc;
+  if (ob) {
+    WCX_HIP(hipMemcpyAsync(out_z, dz, ob, hipMemcpyDeviceToHost, ctx->stream));
+    WCX_HIP(hipMemcpyAsync(out_r, dr, ob, hipMemcpyDeviceToHost, ctx->stream));
+    WCX_HIP(hipMemcpyAsync(out_n, dn, ob, hipMemcpyDeviceToHost, ctx->stream));
+    WCX_HIP(hipMemcpyAsync(out_mlr, dmlr, (size_t)n_samples * 8, hipMemcpyDeviceToHost, ctx->stream));
+    WCX_HIP(hipMemcpyAsync(out_mz, dmz, (size_t)n_samples * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Internal shared declarations for libwcx_hip.so (gfx950 only; no CUDA/HIP dual path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/wcx.h"
+
+void wcx_set_error(const char *fmt, ...);
+
+#define WCX_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      wcx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return WCX_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+#define WCX_ARG(cond, msg)                          \
+  do {                                              \
+    if (!(cond)) {                                  \
+      wcx_set_error("bad argument: %s", msg);       \
+      return WCX_ERR_ARG;                           \
+    }                                               \
+  } while (0)
+
+struct KernelTimer {
+  hipEvent_t start = nullptr, stop = nullptr;
+  bool used = false;
+};
+
+struct wcx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::map<std::string, KernelTimer> timers;
+  int64_t topk_stats[4] = {0, 0, 0, 0};
+  unsigned long long *d_stats = nullptr;  // 4 device counters
+  // growable device scratch owned by the context
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void *scratch2 = nullptr;
+  size_t scratch2_bytes = 0;
+  // host staging for small async uploads (kept alive until the next stream sync)
+  std::vector<std::vector<unsigned char>> stage;
+};
+
+struct wcx_ref {
+  const int32_t *d_idx = nullptr;
+  const double *d_dist = nullptr;
+  bool owned = false;
+  int64_t B = 0;
+  int k = 0;
+  std::vector<int64_t> chr_cum;
+  int64_t *d_chr_cum = nullptr;
+};
+
+int wcx_scratch(wcx_ctx *ctx, size_t bytes, void **out);
+int wcx_scratch2(wcx_ctx *ctx, size_t bytes, void **out);
+int wcx_upload_small(wcx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int wcx_timer_begin(wcx_ctx *ctx, const char *name);
+int wcx_timer_end(wcx_ctx *ctx, const char *name);
+
+// Own-chromosome row range of a block of target rows, built on the host.
+struct TopkBlock {
+  int64_t row0;  // first target row (global row id)
+  int32_t nrows; // <= TM
+  int32_t pad;
+  int64_t cs, ce; // own chromosome [cs,ce): excluded from the candidates
+};
+
+int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                          const std::vector<TopkBlock> &blocks, int64_t row_begin,
+                          int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist);
+int wcx_fill_dummy_rows(wcx_ctx *ctx, int32_t *d_idx, double *d_dist, int64_t row_lo,
+                        int64_t row_hi, int k);

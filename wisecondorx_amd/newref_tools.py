@@ -1,0 +1,107 @@
+"""Host-side mirror of the reference's newref numerical layer (newref_tools.py) for the hot
+path: same function names, argument meaning and return values, with the per-bin search and
+the null-ratio loop executed by libwcx_hip.so on the MI355X.
+
+Reference seam (newref_control.py:136-143):
+    indexes, distances, null_ratios = get_reference(pca_corrected_data, masked_bins_per_chr,
+                                                    masked_bins_per_chr_cum, ref_size=...,
+                                                    part=..., split_parts=...)
+"""
+import logging
+import random
+
+import numpy as np
+
+from . import _lib
+
+
+def _get_part(partnum, outof, bincount):
+    """Row range of part `partnum` (0-based) of `outof` -- newref_tools.py:244-247."""
+    start_bin = int(bincount / float(outof) * partnum)
+    end_bin = int(bincount / float(outof) * (partnum + 1))
+    return start_bin, end_bin
+
+
+def _split_by_chr(start, end, chr_bin_sums):
+    """Per-chromosome regions [chr_idx, start, end] of a row range -- same results as
+    newref_tools.py:227-241.  Kept for callers that want the reference's region list; the
+    GPU path derives its own per-chromosome workgroups from the cumulative bin counts."""
+    areas = []
+    cur = [0, start, 0]
+    for i, val in enumerate(chr_bin_sums):
+        cur[0] = i
+        if val >= end:
+            break
+        if start < val < end:
+            cur[2] = val
+            areas.append(cur)
+            cur = [i, val, 0]
+        cur[1] = val
+    cur[2] = end
+    areas.append(cur)
+    return areas
+
+
+def as_sample_major(pca_corrected_data):
+    """(B,S) matrix -> C-contiguous float64 [S][B] sharing memory when the input is the
+    Fortran-ordered array train_pca returns (newref_tools.py:147)."""
+    X = np.asarray(pca_corrected_data)
+    if X.ndim != 2:
+        raise ValueError("pca_corrected_data must be 2-D (bins x samples)")
+    Xs = X.T
+    if Xs.dtype != np.float64 or not Xs.flags["C_CONTIGUOUS"]:
+        Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+    return Xs
+
+
+def get_ref_for_rows(pca_corrected_data, masked_bins_per_chr_cum, ref_size, start, end,
+                     ctx=None, mode=0):
+    """Reference bins of target rows [start,end): the GPU form of get_ref_for_bins
+    (newref_tools.py:255-278) + the region loop of get_reference (:176-206).  Returns
+    (int32[n,k] indexes in own-chromosome-excluded index space, float64[n,k] distances)."""
+    ctx = ctx or _lib.default_context()
+    Xs = as_sample_major(pca_corrected_data)
+    S, B = Xs.shape
+    cum, cum_p = _lib.i64_array(masked_bins_per_chr_cum)
+    n = end - start
+    idx = np.empty((n, ref_size), dtype=np.int32)
+    dist = np.empty((n, ref_size), dtype=np.float64)
+    _lib.check(ctx.lib.wcx_newref_topk(ctx.h, _lib.ptr(Xs), B, S, cum_p, len(cum), start, end,
+                                       int(ref_size), int(mode), _lib.ptr(idx), _lib.ptr(dist)))
+    return idx, dist
+
+
+def get_null_ratios(pca_corrected_data, index_array, start_num, end_num, sample_ids, ctx=None):
+    """The null-ratio table of newref_tools.py:210-223 for already chosen sample ids."""
+    ctx = ctx or _lib.default_context()
+    Xs = as_sample_major(pca_corrected_data)
+    S, B = Xs.shape
+    idx = np.ascontiguousarray(index_array, dtype=np.int32)
+    ids, ids_p = _lib.i32_array(sample_ids)
+    out = np.zeros((end_num - start_num, len(ids)), dtype=np.float64)
+    if out.size:
+        _lib.check(ctx.lib.wcx_null_ratios(ctx.h, _lib.ptr(Xs), B, S, _lib.ptr(idx), start_num,
+                                           end_num, idx.shape[1], ids_p, len(ids),
+                                           _lib.ptr(out)))
+    return out
+
+
+def get_reference(pca_corrected_data, masked_bins_per_chr, masked_bins_per_chr_cum, ref_size,
+                  part, split_parts, ctx=None, mode=0):
+    """Within-sample reference of one row part -- newref_tools.py:155-224.
+
+    Same contract as the reference: `part` is 1-based; returns (index_array int32[n,k],
+    distance_array float64[n,k], null_ratio_array float64[n,min(S,100)]).  The null samples
+    are drawn with random.sample exactly like newref_tools.py:214-217, so seeding `random`
+    reproduces the reference's choice."""
+    bincount = masked_bins_per_chr_cum[-1]
+    start_num, end_num = _get_part(part - 1, split_parts, bincount)
+    logging.info("Working on thread {} of {}, meaning bins {} up to {}".format(
+        part, split_parts, start_num, end_num))
+    index_array, distance_array = get_ref_for_rows(
+        pca_corrected_data, masked_bins_per_chr_cum, ref_size, start_num, end_num, ctx, mode)
+    n_samples = np.asarray(pca_corrected_data).shape[1]
+    sample_ids = random.sample(range(n_samples), min(n_samples, 100))
+    null_ratio_array = get_null_ratios(pca_corrected_data, index_array, start_num, end_num,
+                                       sample_ids, ctx)
+    return index_array, distance_array, null_ratio_array
