@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- the WisecondorX newref+predict hot path on MI355X.
+
+Contract (see the task prompt): `python bench.py --gpus N --steps K --warmup W` prints ONE
+JSON line on rank 0.  A "step" = one pass of the hot path over one synthetic batch:
+  newref   reference-bin search of every autosomal bin (all-pairs distance + top-k, k=300)
+           + the null-ratio table, target rows split over the N ranks with the reference's
+           own _get_part formula (newref_tools.py:244-247) after an RCCL all-gather of the
+           row-sharded bin-feature matrix X;
+  predict  cut-off + three masked normalisation passes of one test sample against the rows
+           this rank just built.
+Default workload = BASELINE.json configs[2]: 15 kb bins (hg38, ~5 % of bins masked), 100
+reference samples, refsize 300.  Inputs are resident in HBM when the timed region starts.
+value = candidate bin pairs evaluated per second over the whole job ("bins x refs / s").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 vector == matrix (not in the guide)
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+
+
+def make_workload(binsize, n_samples, seed=0):
+    """Synthetic cohort -> masked, depth-normalised, PCA-corrected X (host, untimed)."""
+    from wisecondorx_amd import prep
+    from wisecondorx_amd.synth import Cohort
+    co = Cohort(binsize, struct_seed=1234 + seed)
+    samples, genders = co.cohort(n_samples, seed0=100 + seed)
+    mask, bpc = prep.get_mask(samples)
+    p = prep.prepare(samples, "A", mask, bpc)
+    test = co.sample(777 + seed, "F", cnv=[(3, 100, 100 + max(4, int(4e7 // binsize)), 1.5)])
+    return co, p, test
+
+
+def cpu_baseline(Xs, chr_cum, k, budget_s=12.0):
+    """The C oracle (port of newref_tools.py:255-278) on a bounded row sample, 1 core."""
+    from oracle import c_oracle as CO
+    B = Xs.shape[1]
+    rng = np.random.default_rng(0)
+    rows = rng.choice(B, 4096, replace=False)
+    t0 = time.perf_counter()
+    pairs = 0
+    n = 0
+    for t in rows:
+        c = int(np.searchsorted(chr_cum, t, side="right"))
+        cs = int(chr_cum[c - 1]) if c else 0
+        ce = int(chr_cum[c])
+        CO.topk_rows(Xs, cs, ce, int(t), int(t) + 1, k)
+        pairs += B - (ce - cs)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": pairs / dt, "unit": "bin-pairs/s", "cores": 1, "kind": "port",
+            "sample": "{} random target rows x all {} candidate rows, S={}, k={} "
+                      "(oracle/wcx_oracle.c, newref search only; {:.1f} s)".format(
+                          n, B, Xs.shape[0], k, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--binsize", type=int, default=15000)
+    ap.add_argument("--samples", type=int, default=100)
+    ap.add_argument("--refsize", type=int, default=300)
+    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact fp64, 2 MFMA screen")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wisecondorx_amd import _lib, predict_tools
+    from wisecondorx_amd.newref_tools import _get_part
+
+    # ---------------------------------------------------------------- inputs (untimed)
+    co, p, test = make_workload(args.binsize, args.samples)
+    X = p["X"]                                   # (B, S) Fortran order
+    Xs_host = np.ascontiguousarray(X.T)          # [S][B]
+    S, B = Xs_host.shape
+    k = args.refsize
+    cum = np.asarray(p["masked_bins_per_chr_cum"], dtype=np.int64)
+    mb = np.asarray(p["masked_bins_per_chr"], dtype=np.int64)
+    row_begin, row_end = _get_part(rank, world, B)
+    n_rows = row_end - row_begin
+    pairs_total = int(np.sum(mb * (B - mb)))
+    # this rank's row shard of X^T (what it would have produced itself), resident in HBM
+    sh0, sh1 = _get_part(rank, world, B)
+    shard_rows = max(_get_part(r, world, B)[1] - _get_part(r, world, B)[0] for r in range(world))
+    Xrow = torch.zeros((shard_rows, S), dtype=torch.float64, device=dev)   # row-major shard
+    Xrow[: sh1 - sh0] = torch.from_numpy(np.ascontiguousarray(X[sh0:sh1])).to(dev)
+    x_test = predict_tools.project_pc(
+        predict_tools.coverage_normalize_and_mask(test, p, ""), p, "")
+    d_x = torch.from_numpy(np.ascontiguousarray(x_test)).to(dev)
+    null_ids = np.ascontiguousarray(np.random.default_rng(5).permutation(S)[:min(S, 100)],
+                                    dtype=np.int32)
+    m = len(null_ids)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = _lib.Context(local_rank, stream)
+    lib = ctx.lib
+    d_idx = torch.empty((max(n_rows, 1), k), dtype=torch.int32, device=dev)
+    d_dist = torch.empty((max(n_rows, 1), k), dtype=torch.float64, device=dev)
+    d_nr = torch.empty((max(n_rows, 1), m), dtype=torch.float64, device=dev)
+    Bp = n_rows
+    d_z = torch.empty(max(Bp, 1), dtype=torch.float64, device=dev)
+    d_r = torch.empty_like(d_z)
+    d_n = torch.empty_like(d_z)
+    d_med = torch.empty(2, dtype=torch.float64, device=dev)
+    cum_p = cum.ctypes.data_as(_lib.c_i64p)
+    ids_p = null_ids.ctypes.data_as(_lib.c_i32p)
+    gathered = torch.empty((world * shard_rows, S), dtype=torch.float64, device=dev)
+    d_Xs = torch.empty((S, B), dtype=torch.float64, device=dev)
+
+    # predict on this rank's rows: a row-sliced view of the reference just built
+    sub_cum = np.clip(cum, row_begin, row_end) - row_begin
+    topk_ms, nr_ms, norm_ms = [], [], []
+
+    def step(record):
+        # (1) exchange: every rank needs all candidate rows -> all-gather of the row shards
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, Xrow)
+            rows = []
+            for r in range(world):
+                a, b = _get_part(r, world, B)
+                rows.append(gathered[r * shard_rows: r * shard_rows + (b - a)])
+            full = torch.cat(rows, 0)
+        else:
+            full = Xrow[:B]
+        d_Xs.copy_(full.t())                       # sample-major [S][B]
+        # (2) newref search + null ratios for this rank's target rows
+        _lib.check(lib.wcx_newref_topk_dev(ctx.h, d_Xs.data_ptr(), B, S, cum_p, len(cum),
+                                           row_begin, row_end, k, args.mode,
+                                           d_idx.data_ptr(), d_dist.data_ptr()))
+        _lib.check(lib.wcx_null_ratios_dev(ctx.h, d_Xs.data_ptr(), B, S, d_idx.data_ptr(),
+                                           row_begin, row_end, k, ids_p, m, d_nr.data_ptr()))
+        # (3) predict: cut-off + 3 normalisation passes of one sample on these rows
+        if n_rows > 0 and world == 1:
+            h = _lib.vp()
+            _lib.check(lib.wcx_ref_wrap_dev(ctx.h, d_idx.data_ptr(), d_dist.data_ptr(), B, k,
+                                            cum_p, len(cum), C.byref(h)))
+            cut = C.c_double()
+            _lib.check(lib.wcx_cutoff(ctx.h, h, 5, C.byref(cut)))
+            _lib.check(lib.wcx_predict_normalize_dev(
+                ctx.h, h, d_x.data_ptr(), 1, cut.value, 0, 0, d_z.data_ptr(), d_r.data_ptr(),
+                d_n.data_ptr(), d_med.data_ptr(), d_med.data_ptr() + 8))
+            lib.wcx_ref_free(ctx.h, h)
+        if record:
+            topk_ms.append(ctx.kernel_ms("topk"))
+            nr_ms.append(ctx.kernel_ms("null_ratios"))
+            if world == 1:
+                norm_ms.append(ctx.kernel_ms("normalize"))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---------------------------------------------------------------- roofline (dominant kernel)
+    stats = ctx.topk_stats()
+    k_ms = float(np.mean(topk_ms))
+    flops = 3.0 * S * stats["pairs"]             # exact path: sub, mul, add per (pair, sample)
+    achieved = flops / (k_ms * 1e-3) / 1e12
+    roofline = {"kernel": "k_topk_exact (fp64 VALU, 3 flop per pair-sample)", "bound": "mfma",
+                "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                "kernel_ms": k_ms, "pairs_per_launch": stats["pairs"],
+                "null_ratios_ms": float(np.mean(nr_ms)),
+                "normalize_ms": float(np.mean(norm_ms)) if norm_ms else None,
+                "compactions": stats["compactions"]}
+
+    out = {
+        "metric": "newref+predict throughput @{}kb bins (bins x refs per second)".format(
+            args.binsize // 1000),
+        "value": pairs_total / (ms_per_step * 1e-3),
+        "unit": "bin-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "newref {} kb bins: B={} masked autosomal bins x S={} samples, "
+                               "refsize={} (search + null ratios), + predict normalise of 1 "
+                               "sample{}".format(args.binsize // 1000, B, S, k,
+                                                 "" if world == 1 else " (predict leg: N=1 only)"),
+                   "bins": int(B), "samples": int(S), "refsize": int(k),
+                   "pairs": pairs_total, "bin_samples_per_s": B * S / (ms_per_step * 1e-3),
+                   "mode": args.mode, "partition": "row-block x{} + all-gather(X)".format(world)},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(Xs_host, cum, k)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
