@@ -199,15 +199,32 @@ def main():
     # ---------------------------------------------------------------- roofline (dominant kernel)
     stats = ctx.topk_stats()
     k_ms = float(np.mean(topk_ms))
-    flops = 3.0 * S * stats["pairs"]             # exact path: sub, mul, add per (pair, sample)
-    achieved = flops / (k_ms * 1e-3) / 1e12
-    roofline = {"kernel": "k_topk_exact (fp64 VALU, 3 flop per pair-sample)", "bound": "mfma",
-                "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                "kernel_ms": k_ms, "pairs_per_launch": stats["pairs"],
-                "null_ratios_ms": float(np.mean(nr_ms)),
-                "normalize_ms": float(np.mean(norm_ms)) if norm_ms else None,
-                "compactions": stats["compactions"]}
+    screen_ms = ctx.kernel_ms("topk_screen")
+    if screen_ms >= 0:
+        # MFMA screen: algorithmic work = the -2 X^T X Gram GEMM, 2*S flop per candidate pair
+        # (SURVEY.md §8d).  The kernel executes 3 fp16 MFMA products (hi.hi+hi.lo+lo.hi) over
+        # K padded to a multiple of 16, reported as executed_tflops.
+        kpad = (S + 15) // 16 * 16
+        flops = 2.0 * S * stats["pairs"]
+        achieved = flops / (screen_ms * 1e-3) / 1e12
+        roofline = {"kernel": "k_screen (v_mfma_f32_32x32x16_f16 x3, fp32 acc) + fused top-k filter",
+                    "bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "kernel_ms": screen_ms,
+                    "executed_tflops": 3.0 * 2.0 * kpad * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
+                    "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
+                    "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
+                    "fallback_rows": stats["fallback_rows"], "compactions": stats["compactions"]}
+    else:
+        flops = 3.0 * S * stats["pairs"]         # exact path: sub, mul, add per (pair, sample)
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        roofline = {"kernel": "k_topk_exact (fp64 VALU, 3 flop per pair-sample)", "bound": "mfma",
+                    "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                    "kernel_ms": k_ms, "pairs_per_launch": stats["pairs"],
+                    "compactions": stats["compactions"]}
+    roofline["null_ratios_ms"] = float(np.mean(nr_ms))
+    roofline["normalize_ms"] = float(np.mean(norm_ms)) if norm_ms else None
 
     out = {
         "metric": "newref+predict throughput @{}kb bins (bins x refs per second)".format(

@@ -113,3 +113,53 @@ def test_null_ratio_index_space_quirk(nt):
     idx2[:, -3:] = -1
     np.testing.assert_allclose(nt.get_null_ratios(X, idx2, 0, cum[-1], ids),
                                O.null_ratios(X, idx2, 0, cum[-1], ids), rtol=1e-12, atol=1e-13)
+
+
+# ---------------------------------------------------------------- MFMA screen path (mode 2)
+def _check_vs_c(nt, X, cum, k, s, e, mode):
+    idx, dist = nt.get_ref_for_rows(X, cum, k, s, e, mode=mode)
+    oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, s, e, k)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+
+
+@pytest.mark.parametrize("S,k,seed", [(100, 300, 0), (33, 64, 2), (128, 512, 4), (16, 7, 5)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_screen_and_exact_modes_vs_c_oracle(nt, S, k, seed, mode):
+    from wisecondorx_amd.synth import corrected_matrix
+    rng = np.random.default_rng(seed)
+    mb = rng.integers(60, 420, 24).tolist()
+    mb[7] = 0
+    X, mbpc, cum = corrected_matrix(mb, S, seed=seed)
+    _check_vs_c(nt, np.asfortranarray(X[:cum[21]]), cum[:22], k, 100, cum[21] - 37, mode)
+    _check_vs_c(nt, X, cum, k, 0, cum[-1], mode)      # gonosomal pass (24 chromosomes)
+
+
+def test_screen_ties_nan_inf_outliers(nt):
+    """Screen path on data with exact ties (integers), NaN/inf rows, huge outliers and
+    duplicated rows: the refine must reproduce the reference's order exactly."""
+    rng = np.random.default_rng(12)
+    mb = [700, 650, 600, 500, 450]
+    cum = np.cumsum(mb).tolist()
+    B, S, k = cum[-1], 24, 40
+    X = np.asfortranarray(rng.integers(0, 4, (B, S)).astype(np.float64))
+    X[5, 3] = np.nan
+    X[900, 0] = np.inf
+    X[1500, 2] = -np.inf
+    X[2000, 1] = 3e5                 # d ~ 9e10 -> never admitted
+    X[2100] = X[10]                  # duplicate rows -> zero distances
+    X[2101] = X[10]
+    X[800] = np.nan                  # NaN target row
+    for mode in (1, 2):
+        _check_vs_c(nt, X, cum, k, 0, B, mode)
+
+
+def test_screen_real_valued_outlier_scale(nt):
+    """A few rows 100x larger than the rest inflate the error budget (bigger shortlists) but
+    must not change the result."""
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([900, 800, 700, 600], 64, seed=21)
+    X = np.array(X, order="F")
+    X[[3, 1000, 2500]] *= 100.0
+    X[[7, 1200]] = 1.0               # zero-norm rows after centring
+    _check_vs_c(nt, X, cum, 100, 0, cum[-1], 2)

@@ -230,7 +230,15 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   }
   ctx->topk_stats[0] = searched;
   ctx->topk_stats[1] = pairs;
-  (void)mode;
+  const bool can_screen = wcx_screen_supported(B, S, k);
+  if (mode == 2 && !can_screen) {
+    wcx_set_error("mode 2 (MFMA screen) needs S <= 128, refsize <= 512, B >= 2048 "
+                  "(got B=%lld S=%d k=%d)", (long long)B, S, k);
+    return WCX_ERR_UNSUPPORTED;
+  }
+  if (mode == 2 || (mode == 0 && can_screen))
+    return wcx_topk_screen_launch(ctx, dXs, B, S, chr_cum, n_chr, blocks, row_begin, n_rows, k,
+                                  d_out_idx, d_out_dist);
   return wcx_topk_exact_launch(ctx, dXs, B, S, blocks, row_begin, n_rows, k, d_out_idx,
                                d_out_dist);
 }

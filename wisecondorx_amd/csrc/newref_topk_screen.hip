@@ -1,0 +1,670 @@
+// MFMA screen + exact fp64 refine for the reference-bin search (SURVEY.md §8a row a6;
+// replaces newref_tools.py:255-278).  Results are identical to the exact kernel
+// (newref_topk_exact.hip): the screen only decides WHICH candidates get the exact treatment.
+//
+// Pipeline (all on one stream):
+//   k_col_stats    per-sample mean c_j and max |x - c_j|           (centring + fp16 scale)
+//   k_transpose    Xs [S][B] -> Xr [B][S]                           (rows contiguous for refine)
+//   k_screen_prep  a = 2^p (x - c) split into fp16 hi + lo, written in MFMA-fragment order;
+//                  per row: |a~|^2, representation error norms      (rigorous error budget)
+//   k_screen       -2 a~.b~ Gram tiles on the matrix cores: v_mfma_f32_32x32x16_f16 x3
+//                  (hi.hi + hi.lo + lo.hi), fp32 accumulate; targets stay in registers as the
+//                  B operand, candidates stream through LDS as the A operand; the epilogue
+//                  adds the squared norms and appends (screen distance, index) to the target's
+//                  shortlist whenever the pair could still be among the k nearest given the
+//                  error budget; shortlists are cut back by a wave-level bisection select.
+//   k_refine       exact sequential fp64 distance (newref_tools.py:260 arithmetic) of every
+//                  shortlisted pair, sort by (distance, index), emit the first k.
+//   rows whose shortlist overflowed (never seen on real data) are redone by the exact kernel.
+//
+// Error budget (t = |b~|^2 - 2 g~, screen distance d~ = t + |a~|^2, all in scaled units):
+//   sqrt(d) in [sqrt(dh) - E, sqrt(dh) + E],  dh = |a~ - b~|^2,  E = e_a + e_max  (e = |a - a~|)
+//   |d~ - dh| <= Q = 2 L_a L_max + 2 gamma N_a N_max + 2^-21 (N_a^2 + N_max^2)
+//     (dropped lo.lo term; fp32 accumulation of 3*16*NK products, gamma = n 2^-23; fp32 roundings)
+//   T = (sqrt(d~_(k) + Q) + E)^2 bounds the true k-th distance; a pair can be among the k nearest
+//   only if d~ <= F = (sqrt(T) + E)^2 + Q.  Everything with d~ <= F is kept and refined exactly.
+//
+// Roofline: MFMA bound, 3 * 2*32*32*16 flop per instruction, dense f16 peak ~2.5 PFLOP/s.
+#include "wave_sort.h"
+#include "wcx_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NT = 256;      // 4 waves per workgroup
+constexpr int TGT = 128;     // target rows per workgroup (32 per wave)
+constexpr int CT = 64;       // candidate rows per main-loop iteration (2 MFMA tiles)
+constexpr int CAP = 1024;    // shortlist capacity per target
+constexpr int LIM = CAP - CT;
+
+struct RowInfo {
+  float nb;  // |a~|^2
+  float e;   // >= |a - a~|
+  float L;   // >= |a_lo|
+  float N;   // >= |a~|
+};
+
+struct ScreenGlobals {
+  unsigned long long amax_bits;  // max |x - c| over finite entries (double bits)
+  unsigned int e_max, L_max, N_max;  // float bits, finite rows only
+  unsigned int n_overflow;
+};
+
+__device__ __forceinline__ unsigned int f32_key(float t) {
+  const unsigned int u = __float_as_uint(t);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned int kx) {
+  const unsigned int u = (kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ float up(float v) {  // a float strictly above v (v >= 0, finite)
+  return v * 1.0000005f + 1e-37f;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_col_stats(const double *__restrict__ Xs, int64_t B,
+                                                  double *__restrict__ cmean,
+                                                  ScreenGlobals *__restrict__ glob) {
+  const double *x = Xs + (int64_t)blockIdx.x * B;
+  __shared__ double sh[NT / 64], shc[NT / 64];
+  __shared__ double mean_s;
+  double s = 0.0, c = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += NT) {
+    const double v = x[i];
+    if (fabs(v) < HUGE_VAL) { s += v; c += 1.0; }  // finite only
+  }
+  s = wcx::wave_sum(s);
+  c = wcx::wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; shc[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0, tc = 0;
+    for (int w = 0; w < NT / 64; ++w) { ts += sh[w]; tc += shc[w]; }
+    mean_s = tc > 0 ? ts / tc : 0.0;
+    cmean[blockIdx.x] = mean_s;
+  }
+  __syncthreads();
+  const double m = mean_s;
+  double mx = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += NT) {
+    const double a = fabs(x[i] - m);
+    if (a < HUGE_VAL && a > mx) mx = a;
+  }
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) { const double o = wcx::shfl_xor_f64(mx, k); mx = o > mx ? o : mx; }
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(&glob->amax_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+__global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S,
+                            double *__restrict__ Xr) {
+  __shared__ double tile[32][33];
+  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int j0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int r = ty; r < 32; r += 8) {
+    const int j = j0 + r;
+    const int64_t b = b0 + tx;
+    tile[r][tx] = (j < S && b < B) ? Xs[(int64_t)j * B + b] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t b = b0 + r;
+    const int j = j0 + tx;
+    if (b < B && j < S) Xr[b * S + j] = tile[tx][r];
+  }
+}
+
+// One thread per (padded) row: centre, scale, split into fp16 hi/lo in MFMA fragment order.
+// Fragment array F: half8[tile = row/32][ks][plane][lane'], lane' = (row%32) + 32*(k/8 % 2),
+// the 8 halfs are k = ks*16 + 8*(lane'/32) + 0..7 -- exactly the A/B operand of
+// v_mfma_f32_32x32x16_f16, so one wave-wide 16-byte load per (ks, plane) is fully coalesced.
+template <int NK>
+__global__ __launch_bounds__(NT) void k_screen_prep(
+    const double *__restrict__ Xr, int64_t B, int64_t Bpad, int S,
+    const double *__restrict__ cmean, ScreenGlobals *__restrict__ glob,
+    half8 *__restrict__ F, RowInfo *__restrict__ info) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (b >= Bpad) return;
+  // scale 2^p so that the largest |a| lands in [8192, 16384)  (fp16 max 65504)
+  const double amax = __longlong_as_double((long long)glob->amax_bits);
+  int ex = 0;
+  double scale = 1.0;
+  if (amax > 0.0) {
+    frexp(amax, &ex);            // amax = m 2^ex, m in [0.5,1)
+    scale = ldexp(1.0, 14 - ex);
+  }
+  const int64_t tile = b >> 5;
+  const int rl = (int)(b & 31);
+  double n2 = 0.0, e2 = 0.0, l2 = 0.0;
+  bool bad = false;
+  for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      half8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = ks * 16 + h * 8 + e;
+        double a = 0.0;
+        if (b < B && j < S) a = (Xr[b * S + j] - cmean[j]) * scale;
+        const _Float16 hh = (_Float16)a;
+        const double r1 = a - (double)hh;
+        const _Float16 ll = (_Float16)r1;
+        const double res = r1 - (double)ll;
+        const double at = (double)hh + (double)ll;
+        n2 += at * at;
+        e2 += res * res;
+        l2 += (double)ll * (double)ll;
+        bad |= !(fabs(a) < HUGE_VAL);
+        hi[e] = hh;
+        lo[e] = ll;
+      }
+      const int64_t base = ((tile * NK + ks) * 2) * 64 + rl + 32 * h;
+      F[base] = hi;
+      F[base + 64] = lo;
+    }
+  }
+  RowInfo ri;
+  if (b >= B) {            // padding row: NaN norm -> every screen test fails
+    ri.nb = __builtin_nanf(""); ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
+  } else if (bad) {        // NaN/inf row: as in the reference it is never admitted / finds nothing
+    ri.nb = __builtin_nanf(""); ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
+  } else {
+    ri.nb = (float)n2;
+    // representation error also covers the fp64 rounding of (x - c) * scale
+    ri.e = up((float)(sqrt(e2) + 1e-15 * sqrt(n2)));
+    ri.L = up((float)sqrt(l2));
+    ri.N = up((float)sqrt(n2));
+    atomicMax(&glob->e_max, __float_as_uint(ri.e));
+    atomicMax(&glob->L_max, __float_as_uint(ri.L));
+    atomicMax(&glob->N_max, __float_as_uint(ri.N));
+  }
+  info[b] = ri;
+}
+
+// ------------------------------------------------------------------------------------------
+struct ScreenBlock {
+  int64_t row0;
+  int32_t nrows;  // <= TGT
+  int32_t pad;
+  int64_t cs, ce;
+};
+
+// Wave-level shortlist compaction of target `c` (0..31) of this wave.
+// Returns the new threshold G (t-space) for that target; updates cnt in LDS.
+__device__ __forceinline__ float compact_target(uint2 *__restrict__ sl_row, int *cnt_p, int k,
+                                                float na, float E, float Q, float G_old,
+                                                unsigned int *overflow_flag) {
+  const int lane = wcx::lane_id();
+  // the entries were stored by (other lanes of) this wave: make them visible before re-reading
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  const int n = *cnt_p;
+  unsigned int key[CAP / 64], idx[CAP / 64];
+#pragma unroll
+  for (int q = 0; q < CAP / 64; ++q) {
+    const int e = q * 64 + lane;
+    uint2 v = make_uint2(0xffffffffu, 0u);
+    if (e < n) v = sl_row[e];
+    key[q] = v.x;
+    idx[q] = v.y;
+  }
+  float G = G_old;
+  if (n >= k) {
+    // k-th smallest key by bitwise bisection: largest v with #(key < v) < k
+    unsigned int prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = prefix | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int q = 0; q < CAP / 64; ++q) c += (key[q] < trial) ? 1 : 0;
+      c = wcx::wave_sum_i(c);
+      if (c < k) prefix = trial;
+    }
+    const float tk = key_f32(prefix);
+    // T-space -> distance space -> filter bound F -> back to t-space, rounded outwards
+    float dk = tk + na;
+    dk = dk > 0.f ? dk : 0.f;
+    const float rt = sqrtf(up(dk + Q)) * 1.0000005f + 2.f * E;
+    const float Fb = up(up(rt * rt) + Q);
+    const float Gn = (Fb - na) + 4e-7f * (Fb + na);
+    G = Gn < G_old ? Gn : G_old;
+  }
+  // keep entries with t <= G
+  const unsigned int gkey = f32_key(G);
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < CAP / 64; ++q) {
+    const bool keep = (q * 64 + lane < n) && (key[q] <= gkey);
+    const unsigned long long m = __ballot(keep);
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) sl_row[pos] = make_uint2(key[q], idx[q]);
+    base += __popcll(m);
+  }
+  if (base > LIM) {   // cannot make room: hand the row to the exact kernel
+    if (lane == 0) { *overflow_flag = 1u; *cnt_p = 0; }
+    return -HUGE_VALF;
+  }
+  if (lane == 0) *cnt_p = base;
+  return G;
+}
+
+template <int NK>
+__global__ __launch_bounds__(NT, 2) void k_screen(
+    const half8 *__restrict__ F, const RowInfo *__restrict__ info,
+    const ScreenGlobals *__restrict__ glob, int64_t B, int64_t Bpad,
+    const ScreenBlock *__restrict__ blocks, int k, int64_t row_begin,
+    uint2 *__restrict__ sl, int *__restrict__ cnt_out, unsigned int *__restrict__ flags,
+    unsigned long long *__restrict__ stats) {
+  constexpr int TILE_H8 = CT / 32 * NK * 2 * 64;   // half8 elements per staged candidate group
+  extern __shared__ __align__(16) unsigned char smem[];
+  half8 *sbuf = reinterpret_cast<half8 *>(smem);                       // [2][TILE_H8]
+  float *snb = reinterpret_cast<float *>(smem + 2 * TILE_H8 * 16);     // [2][CT]
+  int *cnt = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16 + 2 * CT * 4);  // [TGT]
+
+  const ScreenBlock blk = blocks[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tl = wave * 32 + (lane & 31);        // local target of this lane
+  const int hf = lane >> 5;
+  const int64_t own = blk.ce - blk.cs;
+  const bool tvalid = tl < blk.nrows;
+  const int64_t trow = tvalid ? blk.row0 + tl : blk.row0;
+  const int64_t srow = trow - row_begin;
+
+  if (tid < TGT) cnt[tid] = 0;
+
+  // target operand (B operand of the MFMA) stays in registers for the whole sweep
+  half8 th[NK], tlo[NK];
+  {
+    const int64_t ttile = trow >> 5;
+    const int trl = (int)(trow & 31);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int64_t base = ((ttile * NK + ks) * 2) * 64 + trl + 32 * hf;
+      th[ks] = F[base];
+      tlo[ks] = F[base + 64];
+    }
+  }
+  const RowInfo ti = info[trow];
+  const float e_max = __uint_as_float(glob->e_max), L_max = __uint_as_float(glob->L_max),
+              N_max = __uint_as_float(glob->N_max);
+  const float na = ti.nb;
+  const float E = up(ti.e + e_max);
+  const float gamma = (float)(3 * 16 * NK + 8) * 1.1920929e-7f;   // n * 2^-23
+  const float Q = up(2.f * ti.L * L_max + 2.f * gamma * ti.N * N_max +
+                     4.8e-7f * (ti.N * ti.N + N_max * N_max));
+  float G = tvalid ? HUGE_VALF : -HUGE_VALF;     // NaN target: na is NaN -> every test fails
+  uint2 *sl_row = sl + srow * (int64_t)CAP;
+  unsigned long long n_compact = 0;
+
+  const int64_t n_groups = Bpad / CT;
+  // first group that is not entirely inside the own chromosome
+  auto skip = [&](int64_t gi) {
+    const int64_t g0 = gi * CT;
+    return g0 >= blk.cs && g0 + CT <= blk.ce;
+  };
+  half8 pre[NK];
+  float pre_nb = 0.f;
+  auto fetch = [&](int64_t gi) {
+    const half8 *src = F + gi * (int64_t)TILE_H8;
+#pragma unroll
+    for (int p = 0; p < NK; ++p) pre[p] = src[p * NT + tid];
+    if (tid < CT) pre_nb = info[gi * CT + tid].nb;
+  };
+  int64_t gi = 0;
+  while (gi < n_groups && skip(gi)) ++gi;
+  if (gi < n_groups) fetch(gi);
+  int buf = 0;
+  __syncthreads();
+  while (gi < n_groups) {
+    half8 *sb = sbuf + buf * TILE_H8;
+    float *nbb = snb + buf * CT;
+#pragma unroll
+    for (int p = 0; p < NK; ++p) sb[p * NT + tid] = pre[p];
+    if (tid < CT) nbb[tid] = pre_nb;
+    __syncthreads();
+    const int64_t g_base = gi * CT;
+    int64_t gn = gi + 1;
+    while (gn < n_groups && skip(gn)) ++gn;
+    if (gn < n_groups) fetch(gn);
+
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const half8 c0h = sb[((0 * NK + ks) * 2 + 0) * 64 + lane];
+      const half8 c0l = sb[((0 * NK + ks) * 2 + 1) * 64 + lane];
+      const half8 c1h = sb[((1 * NK + ks) * 2 + 0) * 64 + lane];
+      const half8 c1l = sb[((1 * NK + ks) * 2 + 1) * 64 + lane];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0h, th[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1h, th[ks], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0h, tlo[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1h, tlo[ks], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0l, th[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1l, th[ks], acc1, 0, 0, 0);
+    }
+    // epilogue: C[row = candidate][col = target]; row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const f32x16 &acc = sub ? acc1 : acc0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
+        const float nbv[4] = {nb4.x, nb4.y, nb4.z, nb4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float t = fmaf(-2.f, acc[4 * j + i], nbv[i]);
+          if (t <= G) {
+            const int64_t g = g_base + sub * 32 + 8 * j + 4 * hf + i;
+            if (g < blk.cs || g >= blk.ce) {
+              const int pos = atomicAdd(&cnt[tl], 1);
+              if (pos < CAP)
+                sl_row[pos] = make_uint2(f32_key(t), (unsigned int)(g < blk.cs ? g : g - own));
+            }
+          }
+        }
+      }
+    }
+    // shortlist maintenance: wave-private (this wave's 32 targets)
+    {
+      const int my_cnt = cnt[tl];
+      unsigned long long need = __ballot(tvalid && my_cnt > LIM) & 0xffffffffull;
+      while (need) {
+        const int c = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int64_t crow_s = (blk.row0 + wave * 32 + c) - row_begin;
+        const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
+                    G_c = __shfl(G, c, 64);
+        const float Gn = compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c,
+                                        E_c, Q_c, G_c, &flags[crow_s]);
+        if ((lane & 31) == c) G = Gn;
+        ++n_compact;
+      }
+    }
+    buf ^= 1;
+    gi = gn;
+  }
+  // final cut of every target's shortlist with its final threshold
+  for (int c = 0; c < 32; ++c) {
+    if (wave * 32 + c >= blk.nrows) break;
+    const int64_t crow_s = (blk.row0 + wave * 32 + c) - row_begin;
+    const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
+                G_c = __shfl(G, c, 64);
+    (void)compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c, E_c, Q_c, G_c,
+                         &flags[crow_s]);
+    if (lane == 0) cnt_out[crow_s] = cnt[wave * 32 + c];
+  }
+  if (lane == 0 && stats) atomicAdd(&stats[2], n_compact);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pair (distance, index) wave bitonic sort, lane-minor layout (see wave_sort.h).
+template <int IPL>
+__device__ __forceinline__ void wave_sort_pairs(double (&d)[IPL], int (&ix)[IPL]) {
+  constexpr int N = 64 * IPL;
+  const int lane = wcx::lane_id();
+#pragma unroll
+  for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+      if (stride >= 64) {
+        const int rs = stride >> 6;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          if ((r & rs) == 0) {
+            const bool asc = (((r * 64) & size) == 0);
+            const double a = d[r], b = d[r | rs];
+            const int ia = ix[r], ib = ix[r | rs];
+            const bool b_less = (b < a) || (b == a && ib < ia);
+            if (b_less == asc) { d[r] = b; d[r | rs] = a; ix[r] = ib; ix[r | rs] = ia; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const bool asc = (((r * 64 + lane) & size) == 0);
+          const bool lower = ((lane & stride) == 0);
+          const double pd = wcx::shfl_xor_f64(d[r], stride);
+          const int pi = __shfl_xor(ix[r], stride, 64);
+          const bool p_less = (pd < d[r]) || (pd == d[r] && pi < ix[r]);
+          const bool want_min = (lower == asc);
+          const bool take = want_min ? p_less : !p_less;
+          if (take) { d[r] = pd; ix[r] = pi; }
+        }
+      }
+    }
+  }
+}
+
+struct ChrTab {
+  int n_chr;
+  int64_t cum[32];
+};
+
+// One wave per target row: exact distances of the shortlisted candidates, sort, emit top k.
+template <int IPL>
+__device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S, int64_t row,
+                                           int64_t cs, int64_t own, const uint2 *__restrict__ sl_row,
+                                           int n, int k, int32_t *__restrict__ oi,
+                                           double *__restrict__ od) {
+  const int lane = wcx::lane_id();
+  double d[IPL];
+  int ix[IPL];
+  const double *xt = Xr + row * (int64_t)S;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int e = q * 64 + lane;
+    d[q] = HUGE_VAL;
+    ix[q] = 0x7fffffff;
+    if (e < n) {
+      const int ci = (int)sl_row[e].y;
+      const int64_t g = ci < cs ? (int64_t)ci : (int64_t)ci + own;
+      const double *xc = Xr + g * (int64_t)S;
+      double acc = 0.0;
+      for (int j = 0; j < S; ++j) {
+        const double diff = xc[j] - xt[j];     // newref_tools.py:260, sequential, unfused
+        const double sq = diff * diff;
+        acc = acc + sq;
+      }
+      if (acc < 1e10) { d[q] = acc; ix[q] = ci; }   // NaN / >= 1e10 never admitted
+    }
+  }
+  wave_sort_pairs<IPL>(d, ix);
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int e = q * 64 + lane;
+    if (e < k) {
+      const bool ok = d[q] < 1e10;
+      oi[e] = ok ? ix[q] : -1;
+      od[e] = ok ? d[q] : 1e10;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, int S, ChrTab chr,
+                                               int64_t row_begin, int64_t n_rows,
+                                               const unsigned char *__restrict__ searched,
+                                               const uint2 *__restrict__ sl,
+                                               const int *__restrict__ cnt_out,
+                                               const unsigned int *__restrict__ flags, int k,
+                                               int32_t *__restrict__ out_idx,
+                                               double *__restrict__ out_dist,
+                                               ScreenGlobals *__restrict__ glob) {
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  for (int64_t r = w0; r < n_rows; r += nw) {
+    if (!searched[r]) continue;
+    if (flags[r]) {
+      if (wcx::lane_id() == 0) atomicAdd(&glob->n_overflow, 1u);
+      continue;
+    }
+    const int64_t row = row_begin + r;
+    int64_t cs = 0, ce = chr.cum[0];
+    for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+    const int n = cnt_out[r];
+    const uint2 *sl_row = sl + r * (int64_t)CAP;
+    int32_t *oi = out_idx + r * (int64_t)k;
+    double *od = out_dist + r * (int64_t)k;
+    if (n <= 512 && k <= 512) refine_row<8>(Xr, S, row, cs, ce - cs, sl_row, n, k, oi, od);
+    else refine_row<16>(Xr, S, row, cs, ce - cs, sl_row, n, k, oi, od);
+  }
+}
+
+__global__ void k_mark(unsigned char *searched, int64_t lo, int64_t hi) {
+  int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < hi) searched[i] = 1;
+}
+
+}  // namespace
+
+// Host side --------------------------------------------------------------------------------
+bool wcx_screen_supported(int64_t B, int S, int k) {
+  return S <= 128 && k <= 512 && k <= LIM && B >= 2048;
+}
+
+int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                           const int64_t *chr_cum, int n_chr,
+                           const std::vector<TopkBlock> &exact_blocks, int64_t row_begin,
+                           int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist) {
+  if (exact_blocks.empty()) return WCX_OK;
+  const int NK = (S + 15) / 16;
+  const int64_t Bpad = (B + CT - 1) / CT * CT;
+  // regroup the searched row ranges into workgroups of <= 128 rows (same chromosome)
+  std::vector<ScreenBlock> blocks;
+  {
+    size_t i = 0;
+    while (i < exact_blocks.size()) {
+      ScreenBlock sb;
+      sb.row0 = exact_blocks[i].row0;
+      sb.nrows = exact_blocks[i].nrows;
+      sb.pad = 0;
+      sb.cs = exact_blocks[i].cs;
+      sb.ce = exact_blocks[i].ce;
+      size_t j = i + 1;
+      while (j < exact_blocks.size() && exact_blocks[j].cs == sb.cs &&
+             exact_blocks[j].row0 == sb.row0 + sb.nrows && sb.nrows + exact_blocks[j].nrows <= TGT) {
+        sb.nrows += exact_blocks[j].nrows;
+        ++j;
+      }
+      blocks.push_back(sb);
+      i = j;
+    }
+  }
+  // scratch layout
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_glob = carve(sizeof(ScreenGlobals));
+  const size_t o_mean = carve((size_t)S * 8);
+  const size_t o_xr = carve((size_t)B * S * 8);
+  const size_t o_F = carve((size_t)Bpad * NK * 64);  // Bpad/32 tiles * NK * 2 planes * 1 KiB
+  const size_t o_info = carve((size_t)Bpad * sizeof(RowInfo));
+  const size_t o_sl = carve((size_t)n_rows * CAP * 8);
+  const size_t o_cnt = carve((size_t)n_rows * 4);
+  const size_t o_flag = carve((size_t)n_rows * 4);
+  const size_t o_srch = carve((size_t)n_rows);
+  const size_t o_blk = carve(blocks.size() * sizeof(ScreenBlock));
+  void *scr = nullptr;
+  int rc = wcx_scratch(ctx, off, &scr);
+  if (rc) return rc;
+  char *base = reinterpret_cast<char *>(scr);
+  ScreenGlobals *glob = reinterpret_cast<ScreenGlobals *>(base + o_glob);
+  double *cmean = reinterpret_cast<double *>(base + o_mean);
+  double *Xr = reinterpret_cast<double *>(base + o_xr);
+  half8 *F = reinterpret_cast<half8 *>(base + o_F);
+  RowInfo *info = reinterpret_cast<RowInfo *>(base + o_info);
+  uint2 *sl = reinterpret_cast<uint2 *>(base + o_sl);
+  int *cnt_out = reinterpret_cast<int *>(base + o_cnt);
+  unsigned int *flags = reinterpret_cast<unsigned int *>(base + o_flag);
+  unsigned char *searched = reinterpret_cast<unsigned char *>(base + o_srch);
+  ScreenBlock *d_blocks = reinterpret_cast<ScreenBlock *>(base + o_blk);
+
+  hipStream_t st = ctx->stream;
+  WCX_HIP(hipMemsetAsync(glob, 0, sizeof(ScreenGlobals), st));
+  WCX_HIP(hipMemsetAsync(cnt_out, 0, (size_t)n_rows * 4, st));
+  WCX_HIP(hipMemsetAsync(flags, 0, (size_t)n_rows * 4, st));
+  WCX_HIP(hipMemsetAsync(searched, 0, (size_t)n_rows, st));
+  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 32, st));
+  rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
+  if (rc) return rc;
+  for (const ScreenBlock &sb : blocks)
+    k_mark<<<(unsigned)((sb.nrows + 255) / 256), 256, 0, st>>>(searched, sb.row0 - row_begin,
+                                                              sb.row0 - row_begin + sb.nrows);
+
+  rc = wcx_timer_begin(ctx, "topk");
+  if (rc) return rc;
+  rc = wcx_timer_begin(ctx, "topk_prep");
+  if (rc) return rc;
+  k_col_stats<<<S, NT, 0, st>>>(dXs, B, cmean, glob);
+  k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((S + 31) / 32)), 256, 0, st>>>(dXs, B, S, Xr);
+  const unsigned gprep = (unsigned)((Bpad + NT - 1) / NT);
+  const size_t lds = 2 * (size_t)(CT / 32 * NK * 2 * 64) * 16 + 2 * CT * 4 + TGT * 4;
+#define WCX_SCREEN_CASE(N)                                                                    \
+  case N:                                                                                     \
+    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, B, Bpad, S, cmean, glob, F, info);              \
+    rc = wcx_timer_end(ctx, "topk_prep");                                                     \
+    if (rc) return rc;                                                                        \
+    rc = wcx_timer_begin(ctx, "topk_screen");                                                 \
+    if (rc) return rc;                                                                        \
+    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<N>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+    k_screen<N><<<(unsigned)blocks.size(), NT, lds, st>>>(F, info, glob, B, Bpad, d_blocks, k, \
+                                                         row_begin, sl, cnt_out, flags,        \
+                                                         ctx->d_stats);                        \
+    break;
+  switch (NK) {
+    WCX_SCREEN_CASE(1) WCX_SCREEN_CASE(2) WCX_SCREEN_CASE(3) WCX_SCREEN_CASE(4)
+    WCX_SCREEN_CASE(5) WCX_SCREEN_CASE(6) WCX_SCREEN_CASE(7) WCX_SCREEN_CASE(8)
+    default:
+      wcx_set_error("screen path supports S <= 128 (got %d)", S);
+      return WCX_ERR_UNSUPPORTED;
+  }
+#undef WCX_SCREEN_CASE
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "topk_screen");
+  if (rc) return rc;
+  rc = wcx_timer_begin(ctx, "topk_refine");
+  if (rc) return rc;
+  ChrTab tab;
+  tab.n_chr = n_chr;
+  for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
+  const unsigned gref = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
+  k_refine<<<gref, NT, 0, st>>>(Xr, S, tab, row_begin, n_rows, searched, sl, cnt_out, flags, k,
+                                d_out_idx, d_out_dist, glob);
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "topk_refine");
+  if (rc) return rc;
+  rc = wcx_timer_end(ctx, "topk");
+  if (rc) return rc;
+
+  // overflowed rows (if any) are redone exactly
+  ScreenGlobals hg;
+  WCX_HIP(hipMemcpyAsync(&hg, glob, sizeof(hg), hipMemcpyDeviceToHost, st));
+  WCX_HIP(hipStreamSynchronize(st));
+  ctx->stage.clear();
+  if (hg.n_overflow) {
+    std::vector<unsigned int> hflags((size_t)n_rows);
+    WCX_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)n_rows * 4, hipMemcpyDeviceToHost, st));
+    WCX_HIP(hipStreamSynchronize(st));
+    std::vector<TopkBlock> redo;
+    for (const TopkBlock &eb : exact_blocks)
+      for (int r = 0; r < eb.nrows; ++r)
+        if (hflags[(size_t)(eb.row0 + r - row_begin)]) {
+          TopkBlock one = eb;
+          one.row0 = eb.row0 + r;
+          one.nrows = 1;
+          redo.push_back(one);
+        }
+    // NOTE: wcx_topk_exact_launch re-uses ctx->scratch; the screen scratch is dead by now.
+    rc = wcx_topk_exact_launch(ctx, dXs, B, S, redo, row_begin, n_rows, k, d_out_idx, d_out_dist);
+    if (rc) return rc;
+    WCX_HIP(hipStreamSynchronize(st));
+    unsigned long long fb = redo.size();
+    WCX_HIP(hipMemcpyAsync(ctx->d_stats + 3, &fb, 8, hipMemcpyHostToDevice, st));
+    WCX_HIP(hipStreamSynchronize(st));
+  }
+  return WCX_OK;
+}

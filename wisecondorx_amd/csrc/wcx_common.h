@@ -79,5 +79,10 @@ struct TopkBlock {
 int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                           const std::vector<TopkBlock> &blocks, int64_t row_begin,
                           int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist);
+bool wcx_screen_supported(int64_t B, int S, int k);
+int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                           const int64_t *chr_cum, int n_chr,
+                           const std::vector<TopkBlock> &exact_blocks, int64_t row_begin,
+                           int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist);
 int wcx_fill_dummy_rows(wcx_ctx *ctx, int32_t *d_idx, double *d_dist, int64_t row_lo,
                         int64_t row_hi, int k);
