@@ -1,0 +1,226 @@
+// Exact fp64 refine of the screened shortlists (see newref_topk_screen.hip for the pipeline).
+#include "wave_sort.h"
+#include "wcx_common.h"
+#include "screen_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Pair (distance, index) wave bitonic sort, lane-minor layout (see wave_sort.h).
+template <int IPL>
+__device__ __forceinline__ void wave_sort_pairs(double (&d)[IPL], int (&ix)[IPL]) {
+  constexpr int N = 64 * IPL;
+  const int lane = wcx::lane_id();
+#pragma unroll
+  for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+      if (stride >= 64) {
+        const int rs = stride >> 6;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          if ((r & rs) == 0) {
+            const bool asc = (((r * 64) & size) == 0);
+            const double a = d[r], b = d[r | rs];
+            const int ia = ix[r], ib = ix[r | rs];
+            const bool b_less = (b < a) || (b == a && ib < ia);
+            if (b_less == asc) { d[r] = b; d[r | rs] = a; ix[r] = ib; ix[r | rs] = ia; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const bool asc = (((r * 64 + lane) & size) == 0);
+          const bool lower = ((lane & stride) == 0);
+          const double pd = wcx::shfl_xor_f64(d[r], stride);
+          const int pi = __shfl_xor(ix[r], stride, 64);
+          const bool p_less = (pd < d[r]) || (pd == d[r] && pi < ix[r]);
+          const bool want_min = (lower == asc);
+          const bool take = want_min ? p_less : !p_less;
+          if (take) { d[r] = pd; ix[r] = pi; }
+        }
+      }
+    }
+  }
+}
+
+// One wave per target row: exact distances of the shortlisted candidates, sort, emit top k.
+// Each lane owns IPL shortlist entries and walks their rows of the row-major copy Xr with
+// 32-byte loads (rows are 32-byte aligned, stride Sp); the IPL sums advance together, each in
+// the reference's strict left-to-right order.
+template <int IPL>
+__device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S, int Sp,
+                                           int64_t row, int64_t cs, int64_t own,
+                                           const uint2 *__restrict__ sl_row, int n, int k,
+                                           int32_t *__restrict__ oi, double *__restrict__ od) {
+  const int lane = wcx::lane_id();
+  double d[IPL];
+  int ix[IPL];
+  const double *xc[IPL];
+  const double *xt = Xr + row * (int64_t)Sp;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int e = q * 64 + lane;
+    ix[q] = 0x7fffffff;
+    xc[q] = xt;
+    d[q] = 0.0;
+    if (e < n) {
+      const int ci = (int)sl_row[e].y;
+      ix[q] = ci;
+      const int64_t g = ci < cs ? (int64_t)ci : (int64_t)ci + own;
+      xc[q] = Xr + g * (int64_t)Sp;
+    }
+  }
+  int j = 0;
+#pragma clang loop unroll(disable)
+  for (; j + 4 <= S; j += 4) {
+    const double2 t01 = *reinterpret_cast<const double2 *>(xt + j);
+    const double2 t23 = *reinterpret_cast<const double2 *>(xt + j + 2);
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const double2 c01 = *reinterpret_cast<const double2 *>(xc[q] + j);
+      const double2 c23 = *reinterpret_cast<const double2 *>(xc[q] + j + 2);
+      double diff = c01.x - t01.x;       // newref_tools.py:260, sequential, unfused
+      double sq = diff * diff;
+      d[q] = d[q] + sq;
+      diff = c01.y - t01.y; sq = diff * diff; d[q] = d[q] + sq;
+      diff = c23.x - t23.x; sq = diff * diff; d[q] = d[q] + sq;
+      diff = c23.y - t23.y; sq = diff * diff; d[q] = d[q] + sq;
+    }
+  }
+#pragma clang loop unroll(disable)
+  for (; j < S; ++j) {
+    const double t = xt[j];
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const double diff = xc[q][j] - t;
+      const double sq = diff * diff;
+      d[q] = d[q] + sq;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const bool ok = (ix[q] != 0x7fffffff) && (d[q] < 1e10);   // NaN / >= 1e10 never admitted
+    if (!ok) { d[q] = HUGE_VAL; ix[q] = 0x7fffffff; }
+  }
+  wave_sort_pairs<IPL>(d, ix);
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int e = q * 64 + lane;
+    if (e < k) {
+      const bool ok = d[q] < 1e10;
+      oi[e] = ok ? ix[q] : -1;
+      od[e] = ok ? d[q] : 1e10;
+    }
+  }
+}
+
+// Rows whose shortlist fits 512 entries (8 per lane): the common case.
+__global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, int S, int Sp,
+                                               ChrTab chr, int64_t row_begin, int64_t n_rows,
+                                               const unsigned char *__restrict__ searched,
+                                               const uint2 *__restrict__ sl,
+                                               const int *__restrict__ cnt_out,
+                                               const unsigned int *__restrict__ flags, int k,
+                                               int32_t *__restrict__ out_idx,
+                                               double *__restrict__ out_dist,
+                                               ScreenGlobals *__restrict__ glob) {
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  for (int64_t r = w0; r < n_rows; r += nw) {
+    if (!searched[r]) continue;
+    if (flags[r]) {
+      if (wcx::lane_id() == 0) atomicAdd(&glob->n_overflow, 1u);
+      continue;
+    }
+    const int n = cnt_out[r];
+    if (n > 512) continue;     // k_refine_big
+    const int64_t row = row_begin + r;
+    int64_t cs = 0, ce = chr.cum[0];
+    for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+    refine_row<8>(Xr, S, Sp, row, cs, ce - cs, sl + r * (int64_t)CAP, n, k,
+                  out_idx + r * (int64_t)k, out_dist + r * (int64_t)k);
+  }
+}
+
+// Rare rows with 512 < n <= CAP shortlisted entries: one workgroup per row, LDS bitonic sort.
+__global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr, int S, int Sp,
+                                                   ChrTab chr, int64_t row_begin, int64_t n_rows,
+                                                   const unsigned char *__restrict__ searched,
+                                                   const uint2 *__restrict__ sl,
+                                                   const int *__restrict__ cnt_out,
+                                                   const unsigned int *__restrict__ flags, int k,
+                                                   int32_t *__restrict__ out_idx,
+                                                   double *__restrict__ out_dist) {
+  __shared__ double sd[CAP];
+  __shared__ int si[CAP];
+  for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+    if (!searched[r] || flags[r]) continue;
+    const int n = cnt_out[r];
+    if (n <= 512) continue;
+    const int64_t row = row_begin + r;
+    int64_t cs = 0, ce = chr.cum[0];
+    for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+    const int64_t own = ce - cs;
+    const double *xt = Xr + row * (int64_t)Sp;
+    const uint2 *sl_row = sl + r * (int64_t)CAP;
+    __syncthreads();
+    for (int e = threadIdx.x; e < CAP; e += NT) {
+      double acc = HUGE_VAL;
+      int ci = 0x7fffffff;
+      if (e < n) {
+        ci = (int)sl_row[e].y;
+        const int64_t g = ci < cs ? (int64_t)ci : (int64_t)ci + own;
+        const double *xc = Xr + g * (int64_t)Sp;
+        acc = 0.0;
+        for (int j = 0; j < S; ++j) {
+          const double diff = xc[j] - xt[j];
+          const double sq = diff * diff;
+          acc = acc + sq;
+        }
+        if (!(acc < 1e10)) { acc = HUGE_VAL; ci = 0x7fffffff; }
+      }
+      sd[e] = acc;
+      si[e] = ci;
+    }
+    // workgroup bitonic sort by (distance, index)
+    for (int size = 2; size <= CAP; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < CAP / 2; t += NT) {
+          const int lo = 2 * t - (t & (stride - 1));
+          const int hi = lo + stride;
+          const bool asc = ((lo & size) == 0);
+          const double dl = sd[lo], dh = sd[hi];
+          const int il = si[lo], ih = si[hi];
+          const bool hi_less = (dh < dl) || (dh == dl && ih < il);
+          if (hi_less == asc) { sd[lo] = dh; sd[hi] = dl; si[lo] = ih; si[hi] = il; }
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < k; e += NT) {
+      const bool ok = e < CAP && sd[e] < 1e10;
+      out_idx[r * (int64_t)k + e] = ok ? si[e] : -1;
+      out_dist[r * (int64_t)k + e] = ok ? sd[e] : 1e10;
+    }
+  }
+}
+
+}  // namespace
+
+int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTab &tab,
+                      int64_t row_begin, int64_t n_rows, const unsigned char *searched,
+                      const uint2 *sl, const int *cnt_out, const unsigned int *flags, int k,
+                      int32_t *d_out_idx, double *d_out_dist, ScreenGlobals *glob) {
+  const unsigned gref = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
+  k_refine<<<gref, NT, 0, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out,
+                                         flags, k, d_out_idx, d_out_dist, glob);
+  const unsigned gbig = (unsigned)(n_rows < 2048 ? n_rows : 2048);
+  k_refine_big<<<gbig, NT, 0, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl,
+                                             cnt_out, flags, k, d_out_idx, d_out_dist);
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}

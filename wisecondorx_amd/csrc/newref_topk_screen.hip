@@ -27,32 +27,11 @@
 // Roofline: MFMA bound, 3 * 2*32*32*16 flop per instruction, dense f16 peak ~2.5 PFLOP/s.
 #include "wave_sort.h"
 #include "wcx_common.h"
+#include "screen_common.h"
 
 #pragma clang fp contract(off)
 
 namespace {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int NT = 256;      // 4 waves per workgroup
-constexpr int TGT = 128;     // target rows per workgroup (32 per wave)
-constexpr int CT = 64;       // candidate rows per main-loop iteration (2 MFMA tiles)
-constexpr int CAP = 1024;    // shortlist capacity per target
-constexpr int LIM = CAP - CT;
-
-struct RowInfo {
-  float nb;  // |a~|^2
-  float e;   // >= |a - a~|
-  float L;   // >= |a_lo|
-  float N;   // >= |a~|
-};
-
-struct ScreenGlobals {
-  unsigned long long amax_bits;  // max |x - c| over finite entries (double bits)
-  unsigned int e_max, L_max, N_max;  // float bits, finite rows only
-  unsigned int n_overflow;
-};
 
 __device__ __forceinline__ unsigned int f32_key(float t) {
   const unsigned int u = __float_as_uint(t);
@@ -101,8 +80,9 @@ __global__ __launch_bounds__(NT) void k_col_stats(const double *__restrict__ Xs,
     atomicMax(&glob->amax_bits, (unsigned long long)__double_as_longlong(mx));
 }
 
-__global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S,
+__global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S, int Sp,
                             double *__restrict__ Xr) {
+  // Xs [S][B] -> Xr [B][Sp], Sp = S rounded up to 4 doubles (32-byte aligned rows, zero pad)
   __shared__ double tile[32][33];
   const int64_t b0 = (int64_t)blockIdx.x * 32;
   const int j0 = blockIdx.y * 32;
@@ -116,7 +96,7 @@ __global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S,
   for (int r = ty; r < 32; r += 8) {
     const int64_t b = b0 + r;
     const int j = j0 + tx;
-    if (b < B && j < S) Xr[b * S + j] = tile[tx][r];
+    if (b < B && j < Sp) Xr[b * Sp + j] = tile[tx][r];
   }
 }
 
@@ -126,7 +106,7 @@ __global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S,
 // v_mfma_f32_32x32x16_f16, so one wave-wide 16-byte load per (ks, plane) is fully coalesced.
 template <int NK>
 __global__ __launch_bounds__(NT) void k_screen_prep(
-    const double *__restrict__ Xr, int64_t B, int64_t Bpad, int S,
+    const double *__restrict__ Xr, int64_t B, int64_t Bpad, int S, int Sp,
     const double *__restrict__ cmean, ScreenGlobals *__restrict__ glob,
     half8 *__restrict__ F, RowInfo *__restrict__ info) {
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
@@ -151,7 +131,7 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
       for (int e = 0; e < 8; ++e) {
         const int j = ks * 16 + h * 8 + e;
         double a = 0.0;
-        if (b < B && j < S) a = (Xr[b * S + j] - cmean[j]) * scale;
+        if (b < B && j < S) a = (Xr[b * Sp + j] - cmean[j]) * scale;
         const _Float16 hh = (_Float16)a;
         const double r1 = a - (double)hh;
         const _Float16 ll = (_Float16)r1;
@@ -348,24 +328,43 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1l, th[ks], acc1, 0, 0, 0);
     }
     // epilogue: C[row = candidate][col = target]; row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // phase 1: screen values + pass mask (no memory traffic); phase 2: ONE LDS atomic per
+    // lane reserves its slots, then the (rare) passing entries are stored.
+    float tv[32];
+    unsigned int pmask = 0;
+    {
+      // own-chromosome rows of this group are not candidates
+      const int64_t lo_ex = blk.cs - g_base, hi_ex = blk.ce - g_base;  // excluded local range
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const f32x16 &acc = sub ? acc1 : acc0;
+      for (int sub = 0; sub < 2; ++sub) {
+        const f32x16 &acc = sub ? acc1 : acc0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
-        const float nbv[4] = {nb4.x, nb4.y, nb4.z, nb4.w};
+        for (int j = 0; j < 4; ++j) {
+          const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
+          const float nbv[4] = {nb4.x, nb4.y, nb4.z, nb4.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float t = fmaf(-2.f, acc[4 * j + i], nbv[i]);
-          if (t <= G) {
-            const int64_t g = g_base + sub * 32 + 8 * j + 4 * hf + i;
-            if (g < blk.cs || g >= blk.ce) {
-              const int pos = atomicAdd(&cnt[tl], 1);
-              if (pos < CAP)
-                sl_row[pos] = make_uint2(f32_key(t), (unsigned int)(g < blk.cs ? g : g - own));
-            }
+          for (int i = 0; i < 4; ++i) {
+            const int r = sub * 16 + 4 * j + i;
+            const float t = fmaf(-2.f, acc[4 * j + i], nbv[i]);
+            tv[r] = t;
+            const int loc = sub * 32 + 8 * j + 4 * hf + i;
+            const bool ok = (t <= G) && (loc < lo_ex || loc >= hi_ex);
+            pmask |= ok ? (1u << r) : 0u;
           }
+        }
+      }
+    }
+    if (__any(pmask != 0u)) {
+      int pos = 0;
+      if (pmask) pos = atomicAdd(&cnt[tl], __popc(pmask));
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        if ((pmask >> r) & 1u) {
+          const int loc = (r >> 4) * 32 + 8 * ((r >> 2) & 3) + 4 * hf + (r & 3);
+          const int64_t g = g_base + loc;
+          if (pos < CAP)
+            sl_row[pos] = make_uint2(f32_key(tv[r]), (unsigned int)(g < blk.cs ? g : g - own));
+          ++pos;
         }
       }
     }
@@ -399,119 +398,6 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
     if (lane == 0) cnt_out[crow_s] = cnt[wave * 32 + c];
   }
   if (lane == 0 && stats) atomicAdd(&stats[2], n_compact);
-}
-
-// ------------------------------------------------------------------------------------------
-// Pair (distance, index) wave bitonic sort, lane-minor layout (see wave_sort.h).
-template <int IPL>
-__device__ __forceinline__ void wave_sort_pairs(double (&d)[IPL], int (&ix)[IPL]) {
-  constexpr int N = 64 * IPL;
-  const int lane = wcx::lane_id();
-#pragma unroll
-  for (int size = 2; size <= N; size <<= 1) {
-#pragma unroll
-    for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-      if (stride >= 64) {
-        const int rs = stride >> 6;
-#pragma unroll
-        for (int r = 0; r < IPL; ++r) {
-          if ((r & rs) == 0) {
-            const bool asc = (((r * 64) & size) == 0);
-            const double a = d[r], b = d[r | rs];
-            const int ia = ix[r], ib = ix[r | rs];
-            const bool b_less = (b < a) || (b == a && ib < ia);
-            if (b_less == asc) { d[r] = b; d[r | rs] = a; ix[r] = ib; ix[r | rs] = ia; }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < IPL; ++r) {
-          const bool asc = (((r * 64 + lane) & size) == 0);
-          const bool lower = ((lane & stride) == 0);
-          const double pd = wcx::shfl_xor_f64(d[r], stride);
-          const int pi = __shfl_xor(ix[r], stride, 64);
-          const bool p_less = (pd < d[r]) || (pd == d[r] && pi < ix[r]);
-          const bool want_min = (lower == asc);
-          const bool take = want_min ? p_less : !p_less;
-          if (take) { d[r] = pd; ix[r] = pi; }
-        }
-      }
-    }
-  }
-}
-
-struct ChrTab {
-  int n_chr;
-  int64_t cum[32];
-};
-
-// One wave per target row: exact distances of the shortlisted candidates, sort, emit top k.
-template <int IPL>
-__device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S, int64_t row,
-                                           int64_t cs, int64_t own, const uint2 *__restrict__ sl_row,
-                                           int n, int k, int32_t *__restrict__ oi,
-                                           double *__restrict__ od) {
-  const int lane = wcx::lane_id();
-  double d[IPL];
-  int ix[IPL];
-  const double *xt = Xr + row * (int64_t)S;
-#pragma unroll
-  for (int q = 0; q < IPL; ++q) {
-    const int e = q * 64 + lane;
-    d[q] = HUGE_VAL;
-    ix[q] = 0x7fffffff;
-    if (e < n) {
-      const int ci = (int)sl_row[e].y;
-      const int64_t g = ci < cs ? (int64_t)ci : (int64_t)ci + own;
-      const double *xc = Xr + g * (int64_t)S;
-      double acc = 0.0;
-      for (int j = 0; j < S; ++j) {
-        const double diff = xc[j] - xt[j];     // newref_tools.py:260, sequential, unfused
-        const double sq = diff * diff;
-        acc = acc + sq;
-      }
-      if (acc < 1e10) { d[q] = acc; ix[q] = ci; }   // NaN / >= 1e10 never admitted
-    }
-  }
-  wave_sort_pairs<IPL>(d, ix);
-#pragma unroll
-  for (int q = 0; q < IPL; ++q) {
-    const int e = q * 64 + lane;
-    if (e < k) {
-      const bool ok = d[q] < 1e10;
-      oi[e] = ok ? ix[q] : -1;
-      od[e] = ok ? d[q] : 1e10;
-    }
-  }
-}
-
-__global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, int S, ChrTab chr,
-                                               int64_t row_begin, int64_t n_rows,
-                                               const unsigned char *__restrict__ searched,
-                                               const uint2 *__restrict__ sl,
-                                               const int *__restrict__ cnt_out,
-                                               const unsigned int *__restrict__ flags, int k,
-                                               int32_t *__restrict__ out_idx,
-                                               double *__restrict__ out_dist,
-                                               ScreenGlobals *__restrict__ glob) {
-  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
-  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
-  for (int64_t r = w0; r < n_rows; r += nw) {
-    if (!searched[r]) continue;
-    if (flags[r]) {
-      if (wcx::lane_id() == 0) atomicAdd(&glob->n_overflow, 1u);
-      continue;
-    }
-    const int64_t row = row_begin + r;
-    int64_t cs = 0, ce = chr.cum[0];
-    for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
-    const int n = cnt_out[r];
-    const uint2 *sl_row = sl + r * (int64_t)CAP;
-    int32_t *oi = out_idx + r * (int64_t)k;
-    double *od = out_dist + r * (int64_t)k;
-    if (n <= 512 && k <= 512) refine_row<8>(Xr, S, row, cs, ce - cs, sl_row, n, k, oi, od);
-    else refine_row<16>(Xr, S, row, cs, ce - cs, sl_row, n, k, oi, od);
-  }
 }
 
 __global__ void k_mark(unsigned char *searched, int64_t lo, int64_t hi) {
@@ -559,7 +445,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_glob = carve(sizeof(ScreenGlobals));
   const size_t o_mean = carve((size_t)S * 8);
-  const size_t o_xr = carve((size_t)B * S * 8);
+  const int Sp = (S + 3) & ~3;
+  const size_t o_xr = carve((size_t)B * Sp * 8);
   const size_t o_F = carve((size_t)Bpad * NK * 64);  // Bpad/32 tiles * NK * 2 planes * 1 KiB
   const size_t o_info = carve((size_t)Bpad * sizeof(RowInfo));
   const size_t o_sl = carve((size_t)n_rows * CAP * 8);
@@ -599,12 +486,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   rc = wcx_timer_begin(ctx, "topk_prep");
   if (rc) return rc;
   k_col_stats<<<S, NT, 0, st>>>(dXs, B, cmean, glob);
-  k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((S + 31) / 32)), 256, 0, st>>>(dXs, B, S, Xr);
+  k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
   const unsigned gprep = (unsigned)((Bpad + NT - 1) / NT);
   const size_t lds = 2 * (size_t)(CT / 32 * NK * 2 * 64) * 16 + 2 * CT * 4 + TGT * 4;
 #define WCX_SCREEN_CASE(N)                                                                    \
   case N:                                                                                     \
-    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, B, Bpad, S, cmean, glob, F, info);              \
+    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, B, Bpad, S, Sp, cmean, glob, F, info);              \
     rc = wcx_timer_end(ctx, "topk_prep");                                                     \
     if (rc) return rc;                                                                        \
     rc = wcx_timer_begin(ctx, "topk_screen");                                                 \
@@ -631,10 +518,9 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   ChrTab tab;
   tab.n_chr = n_chr;
   for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
-  const unsigned gref = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
-  k_refine<<<gref, NT, 0, st>>>(Xr, S, tab, row_begin, n_rows, searched, sl, cnt_out, flags, k,
-                                d_out_idx, d_out_dist, glob);
-  WCX_HIP(hipGetLastError());
+  rc = wcx_refine_launch(ctx, Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out, flags, k,
+                         d_out_idx, d_out_dist, glob);
+  if (rc) return rc;
   rc = wcx_timer_end(ctx, "topk_refine");
   if (rc) return rc;
   rc = wcx_timer_end(ctx, "topk");

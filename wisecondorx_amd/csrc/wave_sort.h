@@ -87,4 +87,69 @@ __device__ __forceinline__ double wave_median_sorted(const double (&v)[IPL], int
   return (a + b) / 2.0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Wave-wide quickselect (no sort): rank-th smallest (0-based) of the elements whose bit is
+// set in `act` (bit q of lane l <-> element v[q] of lane l).  No NaNs allowed.  Control flow
+// is wave-uniform; each round costs IPL compares + 2*IPL ballots, expected ~2 ln(n) rounds.
+template <int IPL>
+__device__ __forceinline__ double wave_quickselect(const double (&v)[IPL], unsigned int act,
+                                                   int rank) {
+  for (;;) {
+    // pivot: first active element of the middle-most lane that still has one
+    double lp = 0.0;
+    bool has = false;
+#pragma unroll
+    for (int q = IPL - 1; q >= 0; --q)
+      if ((act >> q) & 1u) { lp = v[q]; has = true; }
+    const unsigned long long bal = __ballot(has);
+    const unsigned long long hi = bal >> 32;
+    const int src = hi ? 32 + (__ffsll((long long)hi) - 1) : 63 - __clzll((long long)bal);
+    const double p = __shfl(lp, src, 64);
+    int cl = 0, ce = 0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const bool a = (act >> q) & 1u;
+      cl += __popcll(__ballot(a && v[q] < p));
+      ce += __popcll(__ballot(a && v[q] == p));
+    }
+    if (rank < cl) {
+#pragma unroll
+      for (int q = 0; q < IPL; ++q)
+        if (!(v[q] < p)) act &= ~(1u << q);
+    } else if (rank < cl + ce) {
+      return p;
+    } else {
+      rank -= cl + ce;
+#pragma unroll
+      for (int q = 0; q < IPL; ++q)
+        if (!(v[q] > p)) act &= ~(1u << q);
+    }
+  }
+}
+
+// np.median of the n elements flagged in `act` (n = total popcount, wave-uniform, no NaNs).
+template <int IPL>
+__device__ __forceinline__ double wave_median_select(const double (&v)[IPL], unsigned int act,
+                                                     int n) {
+  if (n <= 0) return __builtin_nan("");
+  const double a = wave_quickselect<IPL>(v, act, (n - 1) >> 1);
+  if (n & 1) return a;
+  // next order statistic: a again if enough elements are <= a, else the smallest one above a
+  int cle = 0;
+  double mn = HUGE_VAL;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const bool on = (act >> q) & 1u;
+    cle += __popcll(__ballot(on && v[q] <= a));
+    if (on && v[q] > a && v[q] < mn) mn = v[q];
+  }
+  double b = a;
+  if (cle < (n >> 1) + 1) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const double o = shfl_xor_f64(mn, m); mn = o < mn ? o : mn; }
+    b = mn;
+  }
+  return (a + b) / 2.0;
+}
+
 }  // namespace wcx
