@@ -179,7 +179,7 @@ struct ScreenBlock {
 // Returns the new threshold G (t-space) for that target; updates cnt in LDS.
 __device__ __forceinline__ float compact_target(uint2 *__restrict__ sl_row, int *cnt_p, int k,
                                                 float na, float E, float Q, float G_old,
-                                                unsigned int *overflow_flag) {
+                                                unsigned int *overflow_flag, bool exact) {
   const int lane = wcx::lane_id();
   // the entries were stored by (other lanes of) this wave: make them visible before re-reading
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -195,15 +195,43 @@ __device__ __forceinline__ float compact_target(uint2 *__restrict__ sl_row, int 
   }
   float G = G_old;
   if (n >= k) {
-    // k-th smallest key by bitwise bisection: largest v with #(key < v) < k
     unsigned int prefix = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-      const unsigned int trial = prefix | (1u << bit);
-      int c = 0;
+    if (exact) {
+      // k-th smallest key by bitwise bisection (ballot counts): largest v with #(key < v) < k
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned int trial = prefix | (1u << bit);
+        int c = 0;
 #pragma unroll
-      for (int q = 0; q < CAP / 64; ++q) c += (key[q] < trial) ? 1 : 0;
-      c = wcx::wave_sum_i(c);
-      if (c < k) prefix = trial;
+        for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] < trial));
+        if (c < k) prefix = trial;
+      }
+    } else {
+      // Cheap upper bound of the k-th smallest key: bisect a 64-entry strided sample to 16-bit
+      // resolution at a rank a little above k/n, then VERIFY by an exact count (any value with
+      // >= k keys at or below it is a valid bound); raise the sample rank until it holds.
+      unsigned int smp = key[0];
+#pragma unroll
+      for (int q = 1; q < CAP / 64; ++q)
+        if ((lane & (CAP / 64 - 1)) == q) smp = key[q];
+      const bool smp_ok = ((lane & (CAP / 64 - 1)) * 64 + lane) < n;
+      if (!smp_ok) smp = 0xffffffffu;
+      int rs = (64 * k + n - 1) / n;
+      rs += (rs >> 2) + 3;
+      for (;;) {
+        if (rs > 64) rs = 64;
+        unsigned int p = 0;
+        for (int bit = 31; bit >= 16; --bit) {
+          const unsigned int trial = p | (1u << bit);
+          if (__popcll(__ballot(smp < trial)) < rs) p = trial;
+        }
+        p |= 0xffffu;
+        if (rs >= 64) p = 0xfffffffeu;   // everything valid
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] <= p));
+        if (c >= k) { prefix = p; break; }
+        rs += 8;
+      }
     }
     const float tk = key_f32(prefix);
     // T-space -> distance space -> filter bound F -> back to t-space, rounded outwards
@@ -212,7 +240,7 @@ __device__ __forceinline__ float compact_target(uint2 *__restrict__ sl_row, int 
     const float rt = sqrtf(up(dk + Q)) * 1.0000005f + 2.f * E;
     const float Fb = up(up(rt * rt) + Q);
     const float Gn = (Fb - na) + 4e-7f * (Fb + na);
-    G = Gn < G_old ? Gn : G_old;
+    if (tk < HUGE_VALF && Gn < G_old) G = Gn;   // (NaN / inf bound: keep the old threshold)
   }
   // keep entries with t <= G
   const unsigned int gkey = f32_key(G);
@@ -239,7 +267,12 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
     const ScreenGlobals *__restrict__ glob, int64_t B, int64_t Bpad,
     const ScreenBlock *__restrict__ blocks, int k, int64_t row_begin,
     uint2 *__restrict__ sl, int *__restrict__ cnt_out, unsigned int *__restrict__ flags,
+    float *__restrict__ g_state, int64_t gi_begin, int64_t gi_end, int first, int last,
     unsigned long long *__restrict__ stats) {
+  // The candidate sweep is cut into chunks [gi_begin,gi_end) of groups, one launch per chunk:
+  // every workgroup of a launch streams the SAME few MB of candidate fragments, which therefore
+  // come out of the XCD L2s instead of HBM/MALL.  Per-target state (threshold G, shortlist
+  // count) lives in g_state/cnt_out between launches; the shortlists are in HBM anyway.
   constexpr int TILE_H8 = CT / 32 * NK * 2 * 64;   // half8 elements per staged candidate group
   extern __shared__ __align__(16) unsigned char smem[];
   half8 *sbuf = reinterpret_cast<half8 *>(smem);                       // [2][TILE_H8]
@@ -256,7 +289,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   const int64_t trow = tvalid ? blk.row0 + tl : blk.row0;
   const int64_t srow = trow - row_begin;
 
-  if (tid < TGT) cnt[tid] = 0;
+  if (tid < TGT) cnt[tid] = (first || tid >= blk.nrows) ? 0 : cnt_out[blk.row0 + tid - row_begin];
 
   // target operand (B operand of the MFMA) stays in registers for the whole sweep
   half8 th[NK], tlo[NK];
@@ -278,11 +311,11 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   const float gamma = (float)(3 * 16 * NK + 8) * 1.1920929e-7f;   // n * 2^-23
   const float Q = up(2.f * ti.L * L_max + 2.f * gamma * ti.N * N_max +
                      4.8e-7f * (ti.N * ti.N + N_max * N_max));
-  float G = tvalid ? HUGE_VALF : -HUGE_VALF;     // NaN target: na is NaN -> every test fails
+  float G = tvalid ? (first ? HUGE_VALF : g_state[srow]) : -HUGE_VALF;  // NaN target: tests fail
   uint2 *sl_row = sl + srow * (int64_t)CAP;
   unsigned long long n_compact = 0;
 
-  const int64_t n_groups = Bpad / CT;
+  const int64_t n_groups = gi_end;
   // first group that is not entirely inside the own chromosome
   auto skip = [&](int64_t gi) {
     const int64_t g0 = gi * CT;
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
     for (int p = 0; p < NK; ++p) pre[p] = src[p * NT + tid];
     if (tid < CT) pre_nb = info[gi * CT + tid].nb;
   };
-  int64_t gi = 0;
+  int64_t gi = gi_begin;
   while (gi < n_groups && skip(gi)) ++gi;
   if (gi < n_groups) fetch(gi);
   int buf = 0;
@@ -379,7 +412,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
         const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
                     G_c = __shfl(G, c, 64);
         const float Gn = compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c,
-                                        E_c, Q_c, G_c, &flags[crow_s]);
+                                        E_c, Q_c, G_c, &flags[crow_s], false);
         if ((lane & 31) == c) G = Gn;
         ++n_compact;
       }
@@ -387,16 +420,20 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
     buf ^= 1;
     gi = gn;
   }
-  // final cut of every target's shortlist with its final threshold
-  for (int c = 0; c < 32; ++c) {
-    if (wave * 32 + c >= blk.nrows) break;
-    const int64_t crow_s = (blk.row0 + wave * 32 + c) - row_begin;
-    const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
-                G_c = __shfl(G, c, 64);
-    (void)compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c, E_c, Q_c, G_c,
-                         &flags[crow_s]);
-    if (lane == 0) cnt_out[crow_s] = cnt[wave * 32 + c];
+  if (last) {
+    // final cut of every target's shortlist with its final threshold
+    for (int c = 0; c < 32; ++c) {
+      if (wave * 32 + c >= blk.nrows) break;
+      const int64_t crow_s = (blk.row0 + wave * 32 + c) - row_begin;
+      const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
+                  G_c = __shfl(G, c, 64);
+      (void)compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c, E_c, Q_c,
+                           G_c, &flags[crow_s], true);
+    }
+  } else if (tvalid && hf == 0) {
+    g_state[srow] = G;
   }
+  if (tvalid && hf == 0) cnt_out[srow] = cnt[tl];
   if (lane == 0 && stats) atomicAdd(&stats[2], n_compact);
 }
 
@@ -451,6 +488,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_info = carve((size_t)Bpad * sizeof(RowInfo));
   const size_t o_sl = carve((size_t)n_rows * CAP * 8);
   const size_t o_cnt = carve((size_t)n_rows * 4);
+  const size_t o_gst = carve((size_t)n_rows * 4);
   const size_t o_flag = carve((size_t)n_rows * 4);
   const size_t o_srch = carve((size_t)n_rows);
   const size_t o_blk = carve(blocks.size() * sizeof(ScreenBlock));
@@ -465,6 +503,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   RowInfo *info = reinterpret_cast<RowInfo *>(base + o_info);
   uint2 *sl = reinterpret_cast<uint2 *>(base + o_sl);
   int *cnt_out = reinterpret_cast<int *>(base + o_cnt);
+  float *g_state = reinterpret_cast<float *>(base + o_gst);
   unsigned int *flags = reinterpret_cast<unsigned int *>(base + o_flag);
   unsigned char *searched = reinterpret_cast<unsigned char *>(base + o_srch);
   ScreenBlock *d_blocks = reinterpret_cast<ScreenBlock *>(base + o_blk);
@@ -489,6 +528,11 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
   const unsigned gprep = (unsigned)((Bpad + NT - 1) / NT);
   const size_t lds = 2 * (size_t)(CT / 32 * NK * 2 * 64) * 16 + 2 * CT * 4 + TGT * 4;
+  // candidate chunk per launch: ~3 MB of fragments (fits the 4 MB XCD L2)
+  const int64_t n_groups = Bpad / CT;
+  const int64_t group_bytes = (int64_t)CT * NK * 64;
+  int64_t chunk_groups = (3 << 20) / group_bytes;
+  if (chunk_groups < 16) chunk_groups = 16;
 #define WCX_SCREEN_CASE(N)                                                                    \
   case N:                                                                                     \
     k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, B, Bpad, S, Sp, cmean, glob, F, info);              \
@@ -498,9 +542,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     if (rc) return rc;                                                                        \
     WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<N>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-    k_screen<N><<<(unsigned)blocks.size(), NT, lds, st>>>(F, info, glob, B, Bpad, d_blocks, k, \
-                                                         row_begin, sl, cnt_out, flags,        \
-                                                         ctx->d_stats);                        \
+    for (int64_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {                                    \
+      const int64_t g1 = g0 + chunk_groups < n_groups ? g0 + chunk_groups : n_groups;           \
+      k_screen<N><<<(unsigned)blocks.size(), NT, lds, st>>>(                                    \
+          F, info, glob, B, Bpad, d_blocks, k, row_begin, sl, cnt_out, flags, g_state, g0, g1,  \
+          g0 == 0, g1 == n_groups, ctx->d_stats);                                               \
+    }                                                                                           \
     break;
   switch (NK) {
     WCX_SCREEN_CASE(1) WCX_SCREEN_CASE(2) WCX_SCREEN_CASE(3) WCX_SCREEN_CASE(4)
