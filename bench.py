@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--refsize", type=int, default=300)
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact fp64, 2 MFMA screen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-flags", type=int, default=0, help="profiling ablations (invalid results)")
     args = ap.parse_args()
 
     import torch
@@ -124,6 +125,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ctx = _lib.Context(local_rank, stream)
     lib = ctx.lib
+    if args.debug_flags:
+        lib.wcx_debug_flags(args.debug_flags)
     d_idx = torch.empty((max(n_rows, 1), k), dtype=torch.int32, device=dev)
     d_dist = torch.empty((max(n_rows, 1), k), dtype=torch.float64, device=dev)
     d_nr = torch.empty((max(n_rows, 1), m), dtype=torch.float64, device=dev)

@@ -40,6 +40,9 @@ typedef struct wcx_ctx wcx_ctx; /* one per (process, GPU): device id, stream, sc
 typedef struct wcx_ref wcx_ref; /* a reference (indexes/distances) resident in HBM    */
 
 int wcx_version(void);
+/* Diagnostics only: ablation switches used by the profiling scripts (0 = normal operation;
+ * any other value makes results INVALID).  Returns the previous value. */
+int wcx_debug_flags(int flags);
 const char *wcx_last_error(void); /* thread-local, never NULL */
 
 /* ---- context / memory ------------------------------------------------------------- */

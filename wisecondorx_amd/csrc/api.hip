@@ -81,6 +81,13 @@ extern "C" {
 
 int wcx_version(void) { return 100; }
 
+extern int wcx_debug_value;
+int wcx_debug_flags(int flags) {
+  const int old = wcx_debug_value;
+  wcx_debug_value = flags;
+  return old;
+}
+
 const char *wcx_last_error(void) { return g_err; }
 
 int wcx_ctx_create(int device, void *stream, wcx_ctx **out) {

@@ -150,10 +150,10 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
     }
   }
   RowInfo ri;
-  if (b >= B) {            // padding row: NaN norm -> every screen test fails
-    ri.nb = __builtin_nanf(""); ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
+  if (b >= B) {            // padding row: +inf norm -> every screen test fails
+    ri.nb = HUGE_VALF; ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
   } else if (bad) {        // NaN/inf row: as in the reference it is never admitted / finds nothing
-    ri.nb = __builtin_nanf(""); ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
+    ri.nb = HUGE_VALF; ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
   } else {
     ri.nb = (float)n2;
     // representation error also covers the fp64 rounding of (x - c) * scale
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
     const ScreenBlock *__restrict__ blocks, int k, int64_t row_begin,
     uint2 *__restrict__ sl, int *__restrict__ cnt_out, unsigned int *__restrict__ flags,
     float *__restrict__ g_state, int64_t gi_begin, int64_t gi_end, int first, int last,
-    unsigned long long *__restrict__ stats) {
+    unsigned long long *__restrict__ stats, int dbg) {
   // The candidate sweep is cut into chunks [gi_begin,gi_end) of groups, one launch per chunk:
   // every workgroup of a launch streams the SAME few MB of candidate fragments, which therefore
   // come out of the XCD L2s instead of HBM/MALL.  Per-target state (threshold G, shortlist
@@ -309,28 +309,31 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   const float na = ti.nb;
   const float E = up(ti.e + e_max);
   const float gamma = (float)(3 * 16 * NK + 8) * 1.1920929e-7f;   // n * 2^-23
+  // Q also covers the threshold folded into the accumulator (see the main loop) and the
+  // reconstruction t = G - 2 acc:  2.2 gamma (N_a + N_max)^2
+  const float nsum = ti.N + N_max;
   const float Q = up(2.f * ti.L * L_max + 2.f * gamma * ti.N * N_max +
-                     4.8e-7f * (ti.N * ti.N + N_max * N_max));
-  float G = tvalid ? (first ? HUGE_VALF : g_state[srow]) : -HUGE_VALF;  // NaN target: tests fail
+                     4.8e-7f * (ti.N * ti.N + N_max * N_max) + 2.2f * gamma * nsum * nsum);
+  constexpr float G_INIT = 3.0e38f;   // "no threshold yet" (finite on purpose)
+  float G = tvalid ? (first ? G_INIT : g_state[srow]) : -HUGE_VALF;
   uint2 *sl_row = sl + srow * (int64_t)CAP;
   unsigned long long n_compact = 0;
 
   const int64_t n_groups = gi_end;
-  // first group that is not entirely inside the own chromosome
-  auto skip = [&](int64_t gi) {
-    const int64_t g0 = gi * CT;
-    return g0 >= blk.cs && g0 + CT <= blk.ce;
+  // candidate groups entirely inside the own chromosome are skipped
+  const int64_t skip_lo = (blk.cs + CT - 1) / CT, skip_hi = blk.ce / CT;
+  auto next_group = [&](int64_t g) {
+    return (g >= skip_lo && g < skip_hi) ? skip_hi : g;
   };
   half8 pre[NK];
   float pre_nb = 0.f;
-  auto fetch = [&](int64_t gi) {
-    const half8 *src = F + gi * (int64_t)TILE_H8;
+  auto fetch = [&](int64_t gix) {
+    const half8 *src = F + gix * (int64_t)TILE_H8;
 #pragma unroll
     for (int p = 0; p < NK; ++p) pre[p] = src[p * NT + tid];
-    if (tid < CT) pre_nb = info[gi * CT + tid].nb;
+    if (tid < CT) pre_nb = info[gix * CT + tid].nb;
   };
-  int64_t gi = gi_begin;
-  while (gi < n_groups && skip(gi)) ++gi;
+  int64_t gi = next_group(gi_begin);
   if (gi < n_groups) fetch(gi);
   int buf = 0;
   __syncthreads();
@@ -342,11 +345,32 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
     if (tid < CT) nbb[tid] = pre_nb;
     __syncthreads();
     const int64_t g_base = gi * CT;
-    int64_t gn = gi + 1;
-    while (gn < n_groups && skip(gn)) ++gn;
-    if (gn < n_groups) fetch(gn);
+    const int64_t gn = next_group(gi + 1);
+    if (gn < n_groups && !(dbg & 8)) fetch(gn);
 
-    f32x16 acc0 = {0}, acc1 = {0};
+    // Once every target of the wave has a finite threshold the test is folded into the MFMA:
+    // acc starts at (G - |b~|^2)/2, so after the products acc = g~ - (|b~|^2 - G)/2 and the pair
+    // passes (t = |b~|^2 - 2 g~ <= G) iff acc >= 0 -- one sign bit per output, no extra VALU.
+    const bool fast = __all(G < 1.0e37f);
+    const float halfG = fast ? 0.5f * G : 0.f;
+    const float nbscale = fast ? -0.5f : 0.f;
+    f32x16 acc0, acc1;
+    float nbv[32];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
+        nbv[sub * 16 + 4 * j + 0] = nb4.x; nbv[sub * 16 + 4 * j + 1] = nb4.y;
+        nbv[sub * 16 + 4 * j + 2] = nb4.z; nbv[sub * 16 + 4 * j + 3] = nb4.w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = fast ? fmaf(nbscale, nbv[r], halfG) : 0.f;
+      acc1[r] = fast ? fmaf(nbscale, nbv[16 + r], halfG) : 0.f;
+    }
+    if (!(dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
       const half8 c0h = sb[((0 * NK + ks) * 2 + 0) * 64 + lane];
@@ -360,43 +384,44 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0l, th[ks], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1l, th[ks], acc1, 0, 0, 0);
     }
-    // epilogue: C[row = candidate][col = target]; row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // phase 1: screen values + pass mask (no memory traffic); phase 2: ONE LDS atomic per
-    // lane reserves its slots, then the (rare) passing entries are stored.
-    float tv[32];
+    // C[row = candidate][col = target]; output rr = sub*16 + r is candidate row
+    // loc(rr) = sub*32 + 8*(r>>2) + 4*(lane>>5) + (r&3) of this group.  Bit (31-rr) of pmask.
     unsigned int pmask = 0;
-    {
-      // own-chromosome rows of this group are not candidates
-      const int64_t lo_ex = blk.cs - g_base, hi_ex = blk.ce - g_base;  // excluded local range
+    if (fast) {
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const f32x16 &acc = sub ? acc1 : acc0;
+      for (int r = 0; r < 16; ++r) pmask = (pmask << 1) | (__float_as_uint(acc0[r]) >> 31);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
-          const float nbv[4] = {nb4.x, nb4.y, nb4.z, nb4.w};
+      for (int r = 0; r < 16; ++r) pmask = (pmask << 1) | (__float_as_uint(acc1[r]) >> 31);
+      pmask = ~pmask;
+    } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = sub * 16 + 4 * j + i;
-            const float t = fmaf(-2.f, acc[4 * j + i], nbv[i]);
-            tv[r] = t;
-            const int loc = sub * 32 + 8 * j + 4 * hf + i;
-            const bool ok = (t <= G) && (loc < lo_ex || loc >= hi_ex);
-            pmask |= ok ? (1u << r) : 0u;
-          }
-        }
+      for (int r = 0; r < 16; ++r) {
+        const bool ok0 = fmaf(-2.f, acc0[r], nbv[r]) <= G;
+        const bool ok1 = fmaf(-2.f, acc1[r], nbv[16 + r]) <= G;
+        pmask |= (ok0 ? (0x80000000u >> r) : 0u) | (ok1 ? (0x8000u >> r) : 0u);
       }
     }
+    if (g_base < blk.ce && g_base + CT > blk.cs) {   // group straddles the own chromosome
+      const int64_t lo_ex = blk.cs - g_base, hi_ex = blk.ce - g_base;
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr) {
+        const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
+        if (loc >= lo_ex && loc < hi_ex) pmask &= ~(0x80000000u >> rr);
+      }
+    }
+    if (dbg & 1) pmask = 0;
     if (__any(pmask != 0u)) {
       int pos = 0;
       if (pmask) pos = atomicAdd(&cnt[tl], __popc(pmask));
 #pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        if ((pmask >> r) & 1u) {
-          const int loc = (r >> 4) * 32 + 8 * ((r >> 2) & 3) + 4 * hf + (r & 3);
+      for (int rr = 0; rr < 32; ++rr) {
+        if (pmask & (0x80000000u >> rr)) {
+          const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
           const int64_t g = g_base + loc;
+          const float av = rr < 16 ? acc0[rr & 15] : acc1[rr & 15];
+          const float t = fast ? fmaf(-2.f, av, G) : fmaf(-2.f, av, nbv[rr]);
           if (pos < CAP)
-            sl_row[pos] = make_uint2(f32_key(tv[r]), (unsigned int)(g < blk.cs ? g : g - own));
+            sl_row[pos] = make_uint2(f32_key(t), (unsigned int)(g < blk.cs ? g : g - own));
           ++pos;
         }
       }
@@ -445,6 +470,7 @@ __global__ void k_mark(unsigned char *searched, int64_t lo, int64_t hi) {
 }  // namespace
 
 // Host side --------------------------------------------------------------------------------
+int wcx_debug_value = 0;   // diagnostics only (wcx_debug_flags): ablation switches for profiling
 bool wcx_screen_supported(int64_t B, int S, int k) {
   return S <= 128 && k <= 512 && k <= LIM && B >= 2048;
 }
@@ -546,7 +572,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       const int64_t g1 = g0 + chunk_groups < n_groups ? g0 + chunk_groups : n_groups;           \
       k_screen<N><<<(unsigned)blocks.size(), NT, lds, st>>>(                                    \
           F, info, glob, B, Bpad, d_blocks, k, row_begin, sl, cnt_out, flags, g_state, g0, g1,  \
-          g0 == 0, g1 == n_groups, ctx->d_stats);                                               \
+          g0 == 0, g1 == n_groups, ctx->d_stats, wcx_debug_value);                                               \
     }                                                                                           \
     break;
   switch (NK) {
