@@ -104,13 +104,107 @@ __global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S, int
 // Fragment array F: half8[tile = row/32][ks][plane][lane'], lane' = (row%32) + 32*(k/8 % 2),
 // the 8 halfs are k = ks*16 + 8*(lane'/32) + 0..7 -- exactly the A/B operand of
 // v_mfma_f32_32x32x16_f16, so one wave-wide 16-byte load per (ks, plane) is fully coalesced.
+// ------------------------------------------------------------------------------------------
+// Best-first candidate order.  Nearest neighbours are overwhelmingly low-noise bins (small
+// centred norm), so the candidates are swept in order of increasing norm bucket: the top-k
+// thresholds are near-final after the first few per cent of the sweep and almost nothing
+// passes the screen afterwards.  Order = counting sort by (norm bucket, chromosome); groups of
+// 64 positions are therefore chromosome-pure except at cell borders, which lets the sweep skip
+// own-chromosome groups wholesale (gmask) and mask rows only in the rare mixed groups.
+constexpr int NBUCKET = 128;            // norm buckets: float bits >> 20 (12.5 % steps)
+constexpr int NCELL = NBUCKET * 32;     // (bucket, chromosome) cells
+
+__global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xr, int64_t B, int S,
+                                                 int Sp, const double *__restrict__ cmean,
+                                                 ChrTab chr, ScreenGlobals *__restrict__ glob,
+                                                 unsigned int *__restrict__ rbits,
+                                                 int *__restrict__ rchr) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float a = (float)(Xr[b * Sp + j] - cmean[j]);
+    s += a * a;
+  }
+  int c = 0;
+  while (c < chr.n_chr - 1 && b >= chr.cum[c]) ++c;
+  rchr[b] = c;
+  unsigned int u = 0xffffffffu;                     // non-finite rows go last
+  if (s < HUGE_VALF) {
+    u = __float_as_uint(s) >> 20;
+    atomicMax(&glob->uinv, 0xffffffffu - u);
+  }
+  rbits[b] = u;
+}
+
+__global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict__ rbits,
+                                                 const int *__restrict__ rchr, int64_t B,
+                                                 const ScreenGlobals *__restrict__ glob,
+                                                 int *__restrict__ rkey, int *__restrict__ cellcnt) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (b >= B) return;
+  const unsigned int umin = 0xffffffffu - glob->uinv;
+  const unsigned int u = rbits[b];
+  unsigned int bucket = NBUCKET - 1;
+  if (u != 0xffffffffu && u >= umin && u - umin < NBUCKET - 1) bucket = u - umin;
+  const int key = (int)bucket * 32 + rchr[b];
+  rkey[b] = key;
+  atomicAdd(&cellcnt[key], 1);
+}
+
+__global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cellcnt,
+                                                     int *__restrict__ cursor) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  constexpr int PER = NCELL / 1024;
+  int loc[PER], s = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { loc[i] = s; s += cellcnt[t * PER + i]; }
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  const int base = part[t] - s;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) cursor[t * PER + i] = base + loc[i];
+}
+
+__global__ __launch_bounds__(NT) void k_scatter(const int *__restrict__ rkey, int64_t B,
+                                                int *__restrict__ cursor, int *__restrict__ perm,
+                                                int *__restrict__ rowpos) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (b >= B) return;
+  const int pos = atomicAdd(&cursor[rkey[b]], 1);
+  perm[pos] = (int)b;
+  rowpos[b] = pos;
+}
+
+__global__ __launch_bounds__(NT) void k_group_mask(const int *__restrict__ perm,
+                                                   const int *__restrict__ rchr, int64_t n_groups,
+                                                   unsigned int *__restrict__ gmask) {
+  const int64_t g = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (g >= n_groups) return;
+  unsigned int m = 0;
+  for (int i = 0; i < CT; ++i) {
+    const int row = perm[g * CT + i];
+    if (row >= 0) m |= 1u << rchr[row];
+  }
+  gmask[g] = m;
+}
+
 template <int NK>
 __global__ __launch_bounds__(NT) void k_screen_prep(
-    const double *__restrict__ Xr, int64_t B, int64_t Bpad, int S, int Sp,
-    const double *__restrict__ cmean, ScreenGlobals *__restrict__ glob,
-    half8 *__restrict__ F, RowInfo *__restrict__ info) {
+    const double *__restrict__ Xr, int64_t Bpad, int S, int Sp,
+    const double *__restrict__ cmean, const int *__restrict__ perm,
+    ScreenGlobals *__restrict__ glob, half8 *__restrict__ F, RowInfo *__restrict__ info) {
+  // one thread per sweep POSITION p; the row it holds is perm[p] (-1 = padding)
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
   if (b >= Bpad) return;
+  const int64_t row = perm[b];
   // scale 2^p so that the largest |a| lands in [8192, 16384)  (fp16 max 65504)
   const double amax = __longlong_as_double((long long)glob->amax_bits);
   int ex = 0;
@@ -131,7 +225,7 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
       for (int e = 0; e < 8; ++e) {
         const int j = ks * 16 + h * 8 + e;
         double a = 0.0;
-        if (b < B && j < S) a = (Xr[b * Sp + j] - cmean[j]) * scale;
+        if (row >= 0 && j < S) a = (Xr[row * Sp + j] - cmean[j]) * scale;
         const _Float16 hh = (_Float16)a;
         const double r1 = a - (double)hh;
         const _Float16 ll = (_Float16)r1;
@@ -150,7 +244,7 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
     }
   }
   RowInfo ri;
-  if (b >= B) {            // padding row: +inf norm -> every screen test fails
+  if (row < 0) {           // padding position: +inf norm -> every screen test fails
     ri.nb = HUGE_VALF; ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
   } else if (bad) {        // NaN/inf row: as in the reference it is never admitted / finds nothing
     ri.nb = HUGE_VALF; ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
@@ -171,7 +265,7 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
 struct ScreenBlock {
   int64_t row0;
   int32_t nrows;  // <= TGT
-  int32_t pad;
+  int32_t chr;    // chromosome index of the target rows
   int64_t cs, ce;
 };
 
@@ -265,6 +359,8 @@ template <int NK>
 __global__ __launch_bounds__(NT, 2) void k_screen(
     const half8 *__restrict__ F, const RowInfo *__restrict__ info,
     const ScreenGlobals *__restrict__ glob, int64_t B, int64_t Bpad,
+    const int *__restrict__ perm, const int *__restrict__ rowpos,
+    const unsigned int *__restrict__ gmask,
     const ScreenBlock *__restrict__ blocks, int k, int64_t row_begin,
     uint2 *__restrict__ sl, int *__restrict__ cnt_out, unsigned int *__restrict__ flags,
     float *__restrict__ g_state, int64_t gi_begin, int64_t gi_end, int first, int last,
@@ -278,6 +374,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   half8 *sbuf = reinterpret_cast<half8 *>(smem);                       // [2][TILE_H8]
   float *snb = reinterpret_cast<float *>(smem + 2 * TILE_H8 * 16);     // [2][CT]
   int *cnt = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16 + 2 * CT * 4);  // [TGT]
+  int *sperm = cnt + TGT;                                              // [2][CT] rows of the group
 
   const ScreenBlock blk = blocks[blockIdx.x];
   const int tid = threadIdx.x;
@@ -294,8 +391,9 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   // target operand (B operand of the MFMA) stays in registers for the whole sweep
   half8 th[NK], tlo[NK];
   {
-    const int64_t ttile = trow >> 5;
-    const int trl = (int)(trow & 31);
+    const int64_t tpos = rowpos[trow];        // sweep position of the target row
+    const int64_t ttile = tpos >> 5;
+    const int trl = (int)(tpos & 31);
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
       const int64_t base = ((ttile * NK + ks) * 2) * 64 + trl + 32 * hf;
@@ -303,7 +401,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
       tlo[ks] = F[base + 64];
     }
   }
-  const RowInfo ti = info[trow];
+  const RowInfo ti = info[rowpos[trow]];
   const float e_max = __uint_as_float(glob->e_max), L_max = __uint_as_float(glob->L_max),
               N_max = __uint_as_float(glob->N_max);
   const float na = ti.nb;
@@ -320,18 +418,20 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   unsigned long long n_compact = 0;
 
   const int64_t n_groups = gi_end;
-  // candidate groups entirely inside the own chromosome are skipped
-  const int64_t skip_lo = (blk.cs + CT - 1) / CT, skip_hi = blk.ce / CT;
+  // groups holding only own-chromosome rows are skipped (gmask = chromosomes present)
+  const unsigned int blkbit = 1u << blk.chr;
   auto next_group = [&](int64_t g) {
-    return (g >= skip_lo && g < skip_hi) ? skip_hi : g;
+    while (g < n_groups && gmask[g] == blkbit) ++g;
+    return g;
   };
   half8 pre[NK];
   float pre_nb = 0.f;
+  int pre_row = -1;
   auto fetch = [&](int64_t gix) {
     const half8 *src = F + gix * (int64_t)TILE_H8;
 #pragma unroll
     for (int p = 0; p < NK; ++p) pre[p] = src[p * NT + tid];
-    if (tid < CT) pre_nb = info[gix * CT + tid].nb;
+    if (tid < CT) { pre_nb = info[gix * CT + tid].nb; pre_row = perm[gix * CT + tid]; }
   };
   int64_t gi = next_group(gi_begin);
   if (gi < n_groups) fetch(gi);
@@ -340,11 +440,12 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   while (gi < n_groups) {
     half8 *sb = sbuf + buf * TILE_H8;
     float *nbb = snb + buf * CT;
+    int *prow = sperm + buf * CT;
 #pragma unroll
     for (int p = 0; p < NK; ++p) sb[p * NT + tid] = pre[p];
-    if (tid < CT) nbb[tid] = pre_nb;
+    if (tid < CT) { nbb[tid] = pre_nb; prow[tid] = pre_row; }
     __syncthreads();
-    const int64_t g_base = gi * CT;
+    const bool mixed = (gmask[gi] & blkbit) != 0;   // some own-chromosome rows in this group
     const int64_t gn = next_group(gi + 1);
     if (gn < n_groups && !(dbg & 8)) fetch(gn);
 
@@ -401,12 +502,12 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
         pmask |= (ok0 ? (0x80000000u >> r) : 0u) | (ok1 ? (0x8000u >> r) : 0u);
       }
     }
-    if (g_base < blk.ce && g_base + CT > blk.cs) {   // group straddles the own chromosome
-      const int64_t lo_ex = blk.cs - g_base, hi_ex = blk.ce - g_base;
+    if (mixed) {   // rare: mask the own-chromosome rows of a mixed group
 #pragma unroll
       for (int rr = 0; rr < 32; ++rr) {
         const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
-        if (loc >= lo_ex && loc < hi_ex) pmask &= ~(0x80000000u >> rr);
+        const int64_t g = prow[loc];
+        if (g >= blk.cs && g < blk.ce) pmask &= ~(0x80000000u >> rr);
       }
     }
     if (dbg & 1) pmask = 0;
@@ -417,7 +518,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
       for (int rr = 0; rr < 32; ++rr) {
         if (pmask & (0x80000000u >> rr)) {
           const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
-          const int64_t g = g_base + loc;
+          const int64_t g = prow[loc];
           const float av = rr < 16 ? acc0[rr & 15] : acc1[rr & 15];
           const float t = fast ? fmaf(-2.f, av, G) : fmaf(-2.f, av, nbv[rr]);
           if (pos < CAP)
@@ -490,7 +591,9 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       ScreenBlock sb;
       sb.row0 = exact_blocks[i].row0;
       sb.nrows = exact_blocks[i].nrows;
-      sb.pad = 0;
+      sb.chr = 0;
+      for (int c = 0; c < n_chr; ++c)
+        if (chr_cum[c] == exact_blocks[i].ce && (c ? chr_cum[c - 1] : 0) == exact_blocks[i].cs) sb.chr = c;
       sb.cs = exact_blocks[i].cs;
       sb.ce = exact_blocks[i].ce;
       size_t j = i + 1;
@@ -512,6 +615,15 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_xr = carve((size_t)B * Sp * 8);
   const size_t o_F = carve((size_t)Bpad * NK * 64);  // Bpad/32 tiles * NK * 2 planes * 1 KiB
   const size_t o_info = carve((size_t)Bpad * sizeof(RowInfo));
+  const int64_t n_groups = Bpad / CT;
+  const size_t o_perm = carve((size_t)Bpad * 4);
+  const size_t o_rpos = carve((size_t)B * 4);
+  const size_t o_rbit = carve((size_t)B * 4);
+  const size_t o_rchr = carve((size_t)B * 4);
+  const size_t o_rkey = carve((size_t)B * 4);
+  const size_t o_cell = carve((size_t)NCELL * 4);
+  const size_t o_curs = carve((size_t)NCELL * 4);
+  const size_t o_gmsk = carve((size_t)n_groups * 4);
   const size_t o_sl = carve((size_t)n_rows * CAP * 8);
   const size_t o_cnt = carve((size_t)n_rows * 4);
   const size_t o_gst = carve((size_t)n_rows * 4);
@@ -527,6 +639,14 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   double *Xr = reinterpret_cast<double *>(base + o_xr);
   half8 *F = reinterpret_cast<half8 *>(base + o_F);
   RowInfo *info = reinterpret_cast<RowInfo *>(base + o_info);
+  int *perm = reinterpret_cast<int *>(base + o_perm);
+  int *rowpos = reinterpret_cast<int *>(base + o_rpos);
+  unsigned int *rbits = reinterpret_cast<unsigned int *>(base + o_rbit);
+  int *rchr = reinterpret_cast<int *>(base + o_rchr);
+  int *rkey = reinterpret_cast<int *>(base + o_rkey);
+  int *cellcnt = reinterpret_cast<int *>(base + o_cell);
+  int *cursor = reinterpret_cast<int *>(base + o_curs);
+  unsigned int *gmask = reinterpret_cast<unsigned int *>(base + o_gmsk);
   uint2 *sl = reinterpret_cast<uint2 *>(base + o_sl);
   int *cnt_out = reinterpret_cast<int *>(base + o_cnt);
   float *g_state = reinterpret_cast<float *>(base + o_gst);
@@ -552,16 +672,28 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   if (rc) return rc;
   k_col_stats<<<S, NT, 0, st>>>(dXs, B, cmean, glob);
   k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
+  {
+    ChrTab tab0;
+    tab0.n_chr = n_chr;
+    for (int c = 0; c < 32; ++c) tab0.cum[c] = c < n_chr ? chr_cum[c] : B;
+    const unsigned gb = (unsigned)((B + NT - 1) / NT);
+    WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)NCELL * 4, st));
+    WCX_HIP(hipMemsetAsync(perm, 0xff, (size_t)Bpad * 4, st));
+    k_row_norm<<<gb, NT, 0, st>>>(Xr, B, S, Sp, cmean, tab0, glob, rbits, rchr);
+    k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt);
+    k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor);
+    k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
+    k_group_mask<<<(unsigned)((n_groups + NT - 1) / NT), NT, 0, st>>>(perm, rchr, n_groups, gmask);
+  }
   const unsigned gprep = (unsigned)((Bpad + NT - 1) / NT);
-  const size_t lds = 2 * (size_t)(CT / 32 * NK * 2 * 64) * 16 + 2 * CT * 4 + TGT * 4;
+  const size_t lds = 2 * (size_t)(CT / 32 * NK * 2 * 64) * 16 + 2 * CT * 4 + TGT * 4 + 2 * CT * 4;
   // candidate chunk per launch: ~3 MB of fragments (fits the 4 MB XCD L2)
-  const int64_t n_groups = Bpad / CT;
   const int64_t group_bytes = (int64_t)CT * NK * 64;
   int64_t chunk_groups = (3 << 20) / group_bytes;
   if (chunk_groups < 16) chunk_groups = 16;
 #define WCX_SCREEN_CASE(N)                                                                    \
   case N:                                                                                     \
-    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, B, Bpad, S, Sp, cmean, glob, F, info);              \
+    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);            \
     rc = wcx_timer_end(ctx, "topk_prep");                                                     \
     if (rc) return rc;                                                                        \
     rc = wcx_timer_begin(ctx, "topk_screen");                                                 \
@@ -571,7 +703,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     for (int64_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {                                    \
       const int64_t g1 = g0 + chunk_groups < n_groups ? g0 + chunk_groups : n_groups;           \
       k_screen<N><<<(unsigned)blocks.size(), NT, lds, st>>>(                                    \
-          F, info, glob, B, Bpad, d_blocks, k, row_begin, sl, cnt_out, flags, g_state, g0, g1,  \
+          F, info, glob, B, Bpad, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out,     \
+          flags, g_state, g0, g1,                                                               \
           g0 == 0, g1 == n_groups, ctx->d_stats, wcx_debug_value);                                               \
     }                                                                                           \
     break;

@@ -18,22 +18,41 @@ namespace {
 
 constexpr int NT = 256;  // 4 waves per workgroup
 
-// samples per wave-visit: the index row is loaded once and reused for MS sample vectors
-constexpr int MS = 4;
+// The null samples are first packed 8 to a 64-byte line:  Xg[sg][b][8] = X[b][sid[8 sg + 0..7]]
+// so that ONE gathered cache line serves 8 medians (the gather traffic, not the selection, is
+// what bounds this kernel).
+__global__ __launch_bounds__(NT) void k_nr_pack(const double *__restrict__ Xs, int64_t B,
+                                                const int32_t *__restrict__ sids, int n_ids,
+                                                double *__restrict__ Xg) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  const int sg = blockIdx.y;
+  if (b >= B) return;
+  double v[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int m = sg * 8 + s;
+    v[s] = m < n_ids ? Xs[(int64_t)sids[m] * B + b] : 1.0;
+  }
+  double2 *dst = reinterpret_cast<double2 *>(Xg + ((int64_t)sg * B + b) * 8);
+  dst[0] = make_double2(v[0], v[1]);
+  dst[1] = make_double2(v[2], v[3]);
+  dst[2] = make_double2(v[4], v[5]);
+  dst[3] = make_double2(v[6], v[7]);
+}
 
+// One wave per (row, group of 8 samples).  blockIdx.x (fastest in dispatch order) walks the rows,
+// blockIdx.y the sample groups: at any moment the whole chip gathers from ONE 64*B-byte slab.
 template <int IPL>
 __global__ __launch_bounds__(NT) void k_null_ratios(
-    const double *__restrict__ Xs, int64_t B, const int32_t *__restrict__ idx,
-    int64_t row_begin, int64_t n_rows, int k, const int32_t *__restrict__ sids, int n_ids,
-    double *__restrict__ out) {
+    const double *__restrict__ Xg, int64_t B, const int32_t *__restrict__ idx,
+    int64_t row_begin, int64_t n_rows, int k, int n_ids, double *__restrict__ out) {
   const int lane = wcx::lane_id();
   const int wave = threadIdx.x >> 6;
-  // blockIdx.x (fastest in dispatch order) walks the rows, blockIdx.y the sample groups: at any
-  // moment the whole chip gathers from the same few sample vectors (1.5 MB each at 15 kb),
-  // which therefore stay L2-resident.
   const int64_t r = (int64_t)blockIdx.x * (NT / 64) + wave;
   if (r >= n_rows) return;
-  int64_t g[IPL];
+  const int sg = blockIdx.y;
+  const double *slab = Xg + (int64_t)sg * B * 8;
+  double v[8][IPL];
   unsigned int act = 0;
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
@@ -41,24 +60,27 @@ __global__ __launch_bounds__(NT) void k_null_ratios(
     const bool valid = t < k;
     int64_t c = valid ? (int64_t)idx[r * (int64_t)k + t] : 0;
     if (c < 0) c += B;  // NumPy negative index
-    g[q] = c;
     act |= valid ? (1u << q) : 0u;
+    const double2 *src = reinterpret_cast<const double2 *>(slab + c * 8);
+    const double2 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+    v[0][q] = a0.x; v[1][q] = a0.y; v[2][q] = a1.x; v[3][q] = a1.y;
+    v[4][q] = a2.x; v[5][q] = a2.y; v[6][q] = a3.x; v[7][q] = a3.y;
   }
-  const int m0 = blockIdx.y * MS;
-  for (int m = m0; m < m0 + MS && m < n_ids; ++m) {
-    const double *x = Xs + (int64_t)sids[m] * B;
-    double v[IPL];
+  double my_med = 0.0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
     bool has_nan = false;
 #pragma unroll
-    for (int q = 0; q < IPL; ++q) {
-      const double val = ((act >> q) & 1u) ? x[g[q]] : 0.0;
-      has_nan |= (val != val);
-      v[q] = val;
-    }
+    for (int q = 0; q < IPL; ++q) has_nan |= ((act >> q) & 1u) && (v[s][q] != v[s][q]);
     double med;
     if (__any(has_nan)) med = __builtin_nan("");  // np.median propagates NaN
-    else med = wcx::wave_median_select<IPL>(v, act, k);
-    if (lane == 0) out[r * (int64_t)n_ids + m] = log2(x[row_begin + r] / med);
+    else med = wcx::wave_median_select<IPL>(v[s], act, k);
+    if (lane == s) my_med = med;
+  }
+  const int m = sg * 8 + lane;
+  if (lane < 8 && m < n_ids) {
+    const double xr = slab[(row_begin + r) * 8 + lane];
+    out[r * (int64_t)n_ids + m] = log2(xr / my_med);
   }
 }
 
@@ -77,22 +99,23 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipSetDevice(ctx->device));
   const int64_t n_rows = row_end - row_begin;
   if (n_rows == 0 || n_ids == 0) return WCX_OK;
-  if (k > 64 * 32) {
-    wcx_set_error("refsize %d too large for the null-ratio kernel (max 2048)", k);
-    return WCX_ERR_UNSUPPORTED;
-  }
+  const int n_sg = (n_ids + 7) / 8;
+  const size_t xg_bytes = (size_t)n_sg * B * 64;
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, (size_t)n_ids * 4, &scr);
+  int rc = wcx_scratch(ctx, xg_bytes + (size_t)n_ids * 4 + 256, &scr);
   if (rc) return rc;
-  int32_t *d_sids = reinterpret_cast<int32_t *>(scr);
+  double *Xg = reinterpret_cast<double *>(scr);
+  int32_t *d_sids = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(scr) + xg_bytes);
   rc = wcx_upload_small(ctx, d_sids, sample_ids, (size_t)n_ids * 4);
   if (rc) return rc;
-  const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)((n_ids + MS - 1) / MS));
   rc = wcx_timer_begin(ctx, "null_ratios");
   if (rc) return rc;
-#define WCX_NR_LAUNCH(IPL)                                                              \
-  k_null_ratios<IPL><<<grid, NT, 0, ctx->stream>>>(dXs, B, d_idx, row_begin, n_rows, k, \
-                                                   d_sids, n_ids, d_out)
+  k_nr_pack<<<dim3((unsigned)((B + NT - 1) / NT), (unsigned)n_sg), NT, 0, ctx->stream>>>(
+      dXs, B, d_sids, n_ids, Xg);
+  const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)n_sg);
+#define WCX_NR_LAUNCH(IPL)                                                                    \
+  k_null_ratios<IPL><<<grid, NT, 0, ctx->stream>>>(Xg, B, d_idx, row_begin, n_rows, k, n_ids, \
+                                                   d_out)
   const int ipl = (k + 63) / 64;
   if (ipl <= 1) WCX_NR_LAUNCH(1);
   else if (ipl <= 2) WCX_NR_LAUNCH(2);
@@ -101,8 +124,10 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   else if (ipl <= 5) WCX_NR_LAUNCH(5);
   else if (ipl <= 6) WCX_NR_LAUNCH(6);
   else if (ipl <= 8) WCX_NR_LAUNCH(8);
-  else if (ipl <= 16) WCX_NR_LAUNCH(16);
-  else WCX_NR_LAUNCH(32);
+  else {
+    wcx_set_error("refsize %d too large for the null-ratio kernel (max 512)", k);
+    return WCX_ERR_UNSUPPORTED;
+  }
 #undef WCX_NR_LAUNCH
   WCX_HIP(hipGetLastError());
   return wcx_timer_end(ctx, "null_ratios");

@@ -24,6 +24,7 @@ struct ScreenGlobals {
   unsigned long long amax_bits;  // max |x - c| over finite entries (double bits)
   unsigned int e_max, L_max, N_max;  // float bits, finite rows only
   unsigned int n_overflow;
+  unsigned int uinv;             // 0xffffffff - min(norm float bits >> 20) over finite rows
 };
 
 
