@@ -130,11 +130,12 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
             double alpha, int64_t binsize, uint64_t seed, double *out_seg, int cap,
             int *out_count);
 /* Replaces overall_tools.get_z_score (overall_tools.py:88-119).  nr double[n_bins][m]
- * (rows of masked bins ignored), seg as produced by wcx_cbs; out_z double[n_seg], NaN where
- * the reference returns the string "nan". */
+ * (rows of masked bins ignored; pad ragged rows with NaN), seg as produced by wcx_cbs;
+ * out_z double[n_seg] (NaN where undefined), out_nnull double[n_seg] (may be NULL) = number of
+ * finite null-segment averages: 0 is where the reference returns the string "nan". */
 int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
                   const int64_t *chr_off, int n_chr, const double *seg, int n_seg,
-                  double *out_z);
+                  double *out_z, double *out_nnull);
 
 #ifdef __cplusplus
 }

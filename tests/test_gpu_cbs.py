@@ -1,0 +1,112 @@
+"""GPU tests of a14-a17: post-processing + segment z against the reference-generated fixtures,
+and CBS.  CBS breakpoints are PARITY UNPINNED (DNAcopy is not part of the reference repo and R
+is absent): the tests pin (i) the reference-owned CBS.R logic around the DNAcopy call against
+the oracle restatement, (ii) recovery of planted change-points, (iii) determinism in the seed."""
+import argparse
+
+import numpy as np
+import pytest
+
+from conftest import ref_dict_from_golden
+from oracle import wcx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    from wisecondorx_amd import predict_tools
+    return predict_tools
+
+
+@pytest.mark.parametrize("name", ["t0", "t1", "t2"])
+def test_post_processing_and_segment_z_golden(pt, g_pipe, name, tmp_path):
+    g = g_pipe
+    ref = ref_dict_from_golden(g)
+    gender = str(g[name + "_gender"])
+    ap = "." + gender
+    resA = [g["{}_A_{}".format(name, k)] for k in ("r", "z", "w", "n", "mlr", "mz")]
+    resG = [g["{}_G_{}".format(name, k)] for k in ("r", "z", "w", "n", "mlr", "mz")]
+    r, z, w, n = pt.merge_autosomes_gonosomes(resA, resG)
+    args = argparse.Namespace(minrefbins=20)
+    rem = {"args": args, "mask": ref["mask" + ap], "bins_per_chr": ref["bins_per_chr" + ap],
+           "binsize": int(ref["binsize"])}
+    nr_aut = ref["null_ratios"]
+    nr_gon = ref["null_ratios" + ap][len(nr_aut):]
+    m = max(nr_aut.shape[1], nr_gon.shape[1])
+    nr = np.full((len(nr_aut) + len(nr_gon), m), np.nan)
+    nr[:len(nr_aut), :nr_aut.shape[1]] = nr_aut
+    nr[len(nr_aut):, :nr_gon.shape[1]] = nr_gon
+    results = {"results_r": r, "results_z": z, "results_w": w, "results_nr": nr}
+    for k in results:
+        results[k] = pt.get_post_processed_result(args, results[k], n, rem)
+    pt.log_trans(results, float(resA[4]))
+    if name == "t1":
+        bl = tmp_path / "bl.bed"
+        bl.write_text("".join("\t".join(row) + "\n" for row in g["t1_blacklist"]))
+        args.blacklist = str(bl)
+        pt.apply_blacklist(rem, results)
+    flat = lambda key: np.concatenate([np.asarray(c, dtype=float) for c in results[key]])
+    for key, gk in (("results_r", "_post_r"), ("results_z", "_post_z"), ("results_w", "_post_w")):
+        np.testing.assert_allclose(flat(key), g[name + gk], rtol=1e-12, atol=0, err_msg=key)
+    segs = [[int(s[0]), int(s[1]), int(s[2]), float(s[3])] for s in g[name + "_segs"]]
+    zs = pt.get_z_score(segs, results)
+    isstr = np.array([isinstance(v, str) for v in zs])
+    assert np.array_equal(isstr, g[name + "_segz_isstr"])
+    got = np.array([np.nan if isinstance(v, str) else float(v) for v in zs])
+    np.testing.assert_allclose(got, g[name + "_segz"], rtol=1e-9, atol=1e-9, equal_nan=True)
+
+
+def _noise_results(rng, n_per_chr, sd=0.05):
+    r = [rng.normal(0, sd, n) for n in n_per_chr]
+    w = [rng.uniform(0.5, 2.0, n) for n in n_per_chr]
+    return {"results_r": r, "results_w": w}
+
+
+def test_cbs_planted_changepoints(pt):
+    rng = np.random.default_rng(1)
+    n_per_chr = [600] * 4 + [300] * 19
+    res = _noise_results(rng, n_per_chr)
+    res["results_r"][2][200:260] += 0.4            # interior gain
+    res["results_r"][5][:80] -= 0.5                # loss at the start of a chromosome
+    res["results_r"][0][100:104] = 0               # a few blacklisted bins (0 = missing)
+    segs = pt.run_cbs(res, "F", 1e-4, 100000, 7)
+    by_chr = {}
+    for c, s, e, r in segs:
+        by_chr.setdefault(c, []).append((s, e, r))
+    assert len(by_chr) == 23
+    c2 = sorted(by_chr[2])
+    assert len(c2) == 3
+    assert abs(c2[1][0] - 200) <= 2 and abs(c2[1][1] - 260) <= 2 and abs(c2[1][2] - 0.4) < 0.05
+    c5 = sorted(by_chr[5])
+    assert len(c5) == 2 and abs(c5[0][1] - 80) <= 2 and abs(c5[0][2] + 0.5) < 0.05
+    # pure-noise chromosomes stay in one piece
+    assert sum(len(v) for c, v in by_chr.items() if c not in (2, 5)) == 21
+    # deterministic in the seed
+    assert pt.run_cbs(res, "F", 1e-4, 100000, 7) == segs
+
+
+def test_cbs_wrapper_logic_matches_oracle(pt):
+    """No change-points (noise, strict alpha): the output is decided by the reference-owned
+    CBS.R code only -- all-NA chromosome dropped, split over long NA runs (pieces start AT the
+    last NA bin), >=2-bin rule, weighted re-mean, weight 0 -> 1."""
+    rng = np.random.default_rng(3)
+    n_per_chr = [400] * 24
+    res = _noise_results(rng, n_per_chr, sd=0.02)
+    res["results_r"][1][:] = 0                     # all-NA chromosome
+    res["results_r"][3][100:160] = 0               # long NA run (60 > 20 at 100 kb) -> split
+    res["results_r"][4][50:60] = 0                 # short NA run -> no split
+    res["results_r"][6][0:30] = 0                  # leading NAs
+    res["results_r"][6][395:] = 0                  # trailing NAs
+    res["results_w"][7][10:20] = 0                 # zero weights -> 1
+    segs = pt.run_cbs(res, "M", 1e-9, 100000, 1)
+
+    def one_segment(c, y, w, alpha, state):
+        ok = np.flatnonzero(~np.isnan(y))
+        return [(int(ok[0]) + 1, int(ok[-1]) + 1)]
+
+    exp = O.cbs_r_wrapper(res["results_r"], res["results_w"], "M", 1e-9, 100000, 1, one_segment)
+    assert [s[:3] for s in segs] == [s[:3] for s in exp]
+    np.testing.assert_allclose([s[3] for s in segs], [s[3] for s in exp], rtol=1e-12)
+    assert not any(s[0] == 1 for s in segs)
+    assert [s[:3] for s in segs if s[0] == 3] == [[3, 0, 100], [3, 159, 400]]  # piece starts AT the last NA bin

@@ -126,3 +126,163 @@ def normalize(args, sample, ref_file, ref_gender, cache=None):
     results_z, results_r, ref_sizes, m_lr, m_z = normalize_repeat(
         sample, ref_file, optimal_cutoff, ct, cp, ap, cache)
     return results_r, results_z, results_w, ref_sizes, m_lr, m_z
+
+
+# --------------------------------------------------------------------------- a14-a17 (host glue)
+def merge_autosomes_gonosomes(res_a, res_g):
+    """main.py:242-257: append gonosomal to autosomal results, centre z, cross-scale and
+    renormalise the weights (all-ones fallback when not finite)."""
+    results_r, results_z, results_w, ref_sizes, m_lr, m_z = res_a
+    results_r_2, results_z_2, results_w_2, ref_sizes_2, _, _ = res_g
+    with np.errstate(all="ignore"):
+        r = np.append(results_r, results_r_2)
+        z = np.append(results_z, results_z_2) - m_z
+        w = np.append(results_w * np.nanmean(results_w_2), results_w_2 * np.nanmean(results_w))
+        w = w / np.nanmean(w)
+    if np.isnan(w).any() or np.isinf(w).any():
+        w = np.ones(len(w))
+    return r, z, w, np.append(ref_sizes, ref_sizes_2)
+
+
+def inflate_results(results, rem_input):
+    """predict_tools.py:163-170 (vectorised): masked-out bins become 0."""
+    mask = np.asarray(rem_input["mask"], dtype=bool)
+    results = np.asarray(results)
+    out = np.zeros((len(mask),) + results.shape[1:], dtype=float)
+    out[mask] = results
+    return out
+
+
+def get_post_processed_result(args, result, ref_sizes, rem_input):
+    """predict_control.py:49-63: zero bins with < minrefbins reference bins, inflate to the
+    unmasked length, split per chromosome.  Returns a list of per-chromosome arrays."""
+    result = np.array(result, dtype=float, copy=True)
+    result[np.asarray(ref_sizes) < args.minrefbins] = 0
+    inflated = inflate_results(result, rem_input)
+    off = np.concatenate(([0], np.cumsum(rem_input["bins_per_chr"]))).astype(int)
+    return [inflated[off[c]:off[c + 1]] for c in range(len(rem_input["bins_per_chr"]))]
+
+
+def log_trans(results, log_r_median):
+    """predict_tools.py:180-193 (vectorised, in place)."""
+    for c in range(len(results["results_r"])):
+        with np.errstate(all="ignore"):
+            r = np.log2(np.asarray(results["results_r"][c], dtype=float))
+        bad = ~np.isfinite(r)
+        r[bad] = 0
+        z = np.array(results["results_z"][c], dtype=float)
+        w = np.array(results["results_w"][c], dtype=float)
+        z[bad] = 0
+        w[bad] = 0
+        nz = r != 0
+        r[nz] = r[nz] - log_r_median
+        results["results_r"][c], results["results_z"][c], results["results_w"][c] = r, z, w
+
+
+def _import_bed(rem_input):
+    """predict_tools.py:217-233."""
+    bed = {}
+    for line in open(rem_input["args"].blacklist):
+        chr_name, s, e = line.strip().split("\t")
+        if chr_name[:3] == "chr":
+            chr_name = chr_name[3:]
+        if chr_name == "X":
+            chr_name = "23"
+        if chr_name == "Y":
+            chr_name = "24"
+        c = int(chr_name) - 1
+        bed.setdefault(c, []).append(
+            [int(int(s) / rem_input["binsize"]), int(int(e) / rem_input["binsize"]) + 1])
+    return bed
+
+
+def apply_blacklist(rem_input, results):
+    """predict_tools.py:202-214."""
+    for c, spans in _import_bed(rem_input).items():
+        if len(results["results_r"]) < 24 and c == 23:
+            continue
+        if c >= len(results["results_r"]):
+            continue
+        n = len(results["results_r"][c])
+        for s, e in spans:
+            s, e = max(s, 0), min(e, n)
+            if s < e:
+                for key in ("results_r", "results_z", "results_w"):
+                    results[key][c][s:e] = 0
+
+
+def _flatten(results, key):
+    return np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=float)
+                                                for c in results[key]]))
+
+
+def _chr_offsets(results):
+    n = [len(c) for c in results["results_r"]]
+    return np.concatenate(([0], np.cumsum(n))).astype(np.int64)
+
+
+def _null_matrix(results):
+    """Per-bin null ratios -> dense [n_bins][m].  Accepts per-chromosome 2-D arrays or the
+    reference's ragged lists (autosomal rows have min(S,100) columns, gonosomal rows
+    min(S_gender,100); masked bins hold the int 0): short rows are padded with NaN, which the
+    kernel ignores exactly like the reference ignores non-finite entries."""
+    chrs = results["results_nr"]
+    if all(isinstance(c, np.ndarray) and c.ndim == 2 for c in chrs):
+        m = max(c.shape[1] for c in chrs)
+        return np.vstack([c if c.shape[1] == m else
+                          np.hstack([c, np.full((c.shape[0], m - c.shape[1]), np.nan)])
+                          for c in chrs])
+    rows = [row for c in chrs for row in c]
+    m = max([len(row) for row in rows if np.ndim(row) > 0] + [1])
+    out = np.full((len(rows), m), np.nan)
+    for i, row in enumerate(rows):
+        if np.ndim(row) > 0:
+            out[i, :len(row)] = row
+    return out
+
+
+def get_z_score(results_c, results, ctx=None):
+    """overall_tools.py:88-119: per-segment z against the null ratios; "nan" string where the
+    null mean/sd is undefined, exactly like the reference."""
+    ctx = ctx or _lib.default_context()
+    if not len(results_c):
+        return []
+    r, w = _flatten(results, "results_r"), _flatten(results, "results_w")
+    nr = np.ascontiguousarray(_null_matrix(results), dtype=np.float64)
+    off, off_p = _lib.i64_array(_chr_offsets(results))
+    seg = np.ascontiguousarray([[s[0], s[1], s[2], s[3]] for s in results_c], dtype=np.float64)
+    z = np.empty(len(seg))
+    nn = np.empty(len(seg))
+    _lib.check(ctx.lib.wcx_segment_z(ctx.h, _lib.ptr(r), _lib.ptr(w), _lib.ptr(nr), nr.shape[1],
+                                     off_p, len(off) - 1, _lib.ptr(seg), len(seg), _lib.ptr(z),
+                                     _lib.ptr(nn)))
+    return ["nan" if nn[i] == 0 else float(z[i]) for i in range(len(seg))]
+
+
+def run_cbs(results, ref_gender, alpha, binsize, seed, ctx=None):
+    """The Rscript CBS.R call of exec_cbs (predict_tools.py:245-257) on the GPU.  Returns the
+    reference's JSON rows as [chr0, s, e, r]."""
+    ctx = ctx or _lib.default_context()
+    n_chr = 24 if ref_gender == "M" else 23            # CBS.R:30-34
+    n_chr = min(n_chr, len(results["results_r"]))
+    r = np.ascontiguousarray(np.concatenate(
+        [np.asarray(results["results_r"][c], dtype=float) for c in range(n_chr)]))
+    w = np.ascontiguousarray(np.concatenate(
+        [np.asarray(results["results_w"][c], dtype=float) for c in range(n_chr)]))
+    n = [len(results["results_r"][c]) for c in range(n_chr)]
+    off, off_p = _lib.i64_array(np.concatenate(([0], np.cumsum(n))))
+    cap = 4096
+    seg = np.empty((cap, 4))
+    cnt = _lib.C.c_int()
+    seed_v = 0 if seed is None else int(seed)
+    _lib.check(ctx.lib.wcx_cbs(ctx.h, _lib.ptr(r), _lib.ptr(w), off_p, n_chr, float(alpha),
+                               int(binsize), seed_v, _lib.ptr(seg), cap, _lib.C.byref(cnt)))
+    return [[int(s[0]), int(s[1]), int(s[2]), float(s[3])] for s in seg[:cnt.value]]
+
+
+def exec_cbs(rem_input, results, ctx=None):
+    """predict_tools.py:242-263: CBS + segment z, rows [chr0, start, end, z, ratio]."""
+    results_c = run_cbs(results, rem_input["ref_gender"], rem_input["args"].alpha,
+                        rem_input["binsize"], rem_input["args"].seed, ctx)
+    segment_z = get_z_score(results_c, results, ctx)
+    return [results_c[i][:3] + [segment_z[i]] + [results_c[i][3]] for i in range(len(results_c))]
