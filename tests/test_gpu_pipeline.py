@@ -1,0 +1,100 @@
+"""End-to-end on the GPU through the CLI: newref on the golden cohort -> reference .npz with the
+reference's keys/dtypes; every sub-reference bit-identical to the oracle run on the same
+PCA-corrected matrix; predict --bed -> tables in the reference's formats, planted CNV called."""
+import argparse
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import ref_dict_from_golden, sample_from_counts
+from oracle import wcx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def built(g_pipe, tmp_path_factory):
+    from wisecondorx_amd import main, npz_io
+    tmp = tmp_path_factory.mktemp("pipe")
+    bpc = g_pipe["cohort_bpc"]
+    infiles = []
+    for i, counts in enumerate(g_pipe["cohort_counts"]):
+        p = str(tmp / "s{}.npz".format(i))
+        npz_io.save_sample(p, sample_from_counts(counts, bpc), 4000000)
+        infiles.append(p)
+    out = str(tmp / "ref.npz")
+    random.seed(11)
+    main.main(["newref"] + infiles + [out, "--binsize", "4000000", "--refsize", "60",
+                                      "--yfrac", "0.004"])
+    return tmp, out, infiles
+
+
+def test_reference_file_format(built, g_pipe):
+    _, out, _ = built
+    mine = np.load(out, encoding="latin1", allow_pickle=True)
+    gold = ref_dict_from_golden(g_pipe)
+    assert set(mine.files) == set(gold.keys())
+    for k in gold:
+        assert mine[k].dtype.kind == gold[k].dtype.kind, k
+        if k.split(".")[0] in ("bins_per_chr", "has_female", "has_male", "is_nipt", "binsize"):
+            assert np.array_equal(mine[k], gold[k]), k
+        if k.split(".")[0] in ("indexes", "distances", "null_ratios", "pca_components"):
+            assert mine[k].shape[1:] == gold[k].shape[1:], k
+    assert mine["indexes"].dtype == np.int32 and mine["distances"].dtype == np.float64
+
+
+def test_sub_references_match_oracle(built, g_pipe):
+    """Same X (the build's deterministic PCA) -> same neighbours as the oracle, A/F/M passes."""
+    from wisecondorx_amd import prep
+    from wisecondorx_amd.overall_tools import gender_correct
+    _, out, _ = built
+    mine = np.load(out, encoding="latin1", allow_pickle=True)
+    bpc = g_pipe["cohort_bpc"]
+    genders = [str(x) for x in g_pipe["cohort_genders"]]
+    samples = np.array([gender_correct(sample_from_counts(c, bpc), g)
+                        for c, g in zip(g_pipe["cohort_counts"], genders)])
+    g = np.array(genders)
+    total_mask, bins_per_chr = prep.get_mask(samples)
+    total_mask = total_mask & prep.get_mask(samples[g == "F"])[0] & prep.get_mask(samples[g == "M"])[0]
+    for gender, sub, ap in (("A", samples, ""), ("F", samples[g == "F"], ".F"),
+                            ("M", samples[g == "M"], ".M")):
+        p = prep.prepare(sub, gender, total_mask, bins_per_chr)
+        assert np.array_equal(p["mask"], mine["mask" + ap])
+        cum = p["masked_bins_per_chr_cum"].tolist()
+        oi, od, _ = O.get_reference(p["X"], p["masked_bins_per_chr"].tolist(), cum, 60, 1, 1, [0])
+        assert np.array_equal(mine["indexes" + ap], oi), gender
+        assert np.array_equal(mine["distances" + ap], od), gender
+        assert mine["null_ratios" + ap].shape == (cum[-1], min(len(sub), 100))
+
+
+def test_predict_cli_tables(built, g_pipe):
+    from wisecondorx_amd import main, npz_io
+    tmp, out, _ = built
+    from wisecondorx_amd.synth import Cohort
+    co = Cohort(4000000, struct_seed=11, female_y=0.1)
+    test = co.sample(9001, "M", reads=4e6, cnv=[(3, 10, 25, 1.5)])
+    sp = str(tmp / "test.npz")
+    npz_io.save_sample(sp, test, 4000000)
+    outid = str(tmp / "ID")
+    main.main(["predict", sp, out, outid, "--bed", "--minrefbins", "20", "--seed", "3",
+               "--zscore", "4"])
+    bins = open(outid + "_bins.bed").read().splitlines()
+    assert bins[0] == "chr\tstart\tend\tid\tratio\tzscore"
+    assert bins[1].split("\t")[:4] == ["1", "1", "4000000", "1:1-4000000"]
+    assert len(bins) - 1 == int(np.sum(co.bpc))          # male: 24 chromosomes of bins
+    segs = [l.split("\t") for l in open(outid + "_segments.bed").read().splitlines()]
+    assert segs[0] == ["chr", "start", "end", "ratio", "zscore"]
+    abr = [l.split("\t") for l in open(outid + "_aberrations.bed").read().splitlines()[1:]]
+    hits = [a for a in abr if a[0] == "3" and a[5] == "gain"]
+    assert hits, abr
+    cov = np.zeros(60, dtype=bool)
+    for a in hits:
+        cov[int((int(a[1]) - 1) / 4e6):int(int(a[2]) / 4e6)] = True
+        assert abs(float(a[3]) - np.log2(1.5)) < 0.2, hits
+    assert cov[10:25].sum() >= 11 and cov[:8].sum() == 0 and cov[27:].sum() == 0, hits
+    stats = open(outid + "_statistics.txt").read()
+    assert stats.startswith("chr\tratio.mean\tratio.median\tzscore\n")
+    assert "Gender based on --yfrac (or manually overridden by --gender): M" in stats
+    assert "Copy number profile abnormality (CPA) score" in stats

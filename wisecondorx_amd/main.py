@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""`WisecondorX convert / newref / gender / predict` -- the reference's command line
+(main.py:302-498: same sub-commands, flags, defaults and validation rules) driving the MI355X
+hot path.  Additions: `--gpus` (newref: row parts are spread over that many devices; the
+reference's --cpus is accepted and ignored).  `--plot` needs R/plotter.R and is outside the
+hot path: it logs a warning and is skipped."""
+import argparse
+import logging
+import os
+import random
+import sys
+import warnings
+
+import numpy as np
+
+from . import npz_io, prep
+from .overall_tools import gender_correct, predict_gender, scale_sample
+
+
+# --------------------------------------------------------------------------- convert
+def tool_convert(args):
+    logging.info("Starting conversion")
+    try:
+        import pysam  # noqa: F401
+    except ImportError:
+        logging.critical("convert needs pysam/htslib (BAM/CRAM parsing); it is I/O-bound host "
+                         "work outside the MI355X hot path and pysam is not installed here")
+        sys.exit()
+    from .convert_tools import convert_reads
+    sample, qual_info = convert_reads(args)
+    np.savez_compressed(args.outfile, binsize=args.binsize, sample=sample, quality=qual_info)
+    logging.info("Finished conversion")
+
+
+# --------------------------------------------------------------------------- newref
+def train_gender_model(args, samples):
+    """Two-component Gaussian mixture on the Y-read fractions; cut-off = first local minimum of
+    the mixture density on [0, 0.02] unless --yfrac is given (newref_tools.py:21-68)."""
+    y_fractions = np.array([
+        float(np.sum(s["24"])) / float(np.sum([np.sum(s[x]) for x in s.keys()])) for s in samples])
+    if args.yfrac is not None:
+        cut_off = args.yfrac
+    else:
+        from scipy.signal import argrelextrema
+        from sklearn.mixture import GaussianMixture
+        gmm = GaussianMixture(n_components=2, covariance_type="full", reg_covar=1e-99,
+                              max_iter=10000, tol=1e-99)
+        gmm.fit(X=y_fractions.reshape(-1, 1))
+        gmm_x = np.linspace(0, 0.02, 5000)
+        gmm_y = np.exp(gmm.score_samples(gmm_x.reshape(-1, 1)))
+        if getattr(args, "plotyfrac", None) is not None:
+            import matplotlib.pyplot as plt
+            fig, ax = plt.subplots(figsize=(16, 6))
+            ax.hist(y_fractions, bins=100, density=True)
+            ax.plot(gmm_x, gmm_y, "r-", label="Gaussian mixture fit")
+            ax.set_xlim([0, 0.02])
+            ax.legend(loc="best")
+            plt.savefig(args.plotyfrac)
+            logging.info("Image written to {}, now quitting ...".format(args.plotyfrac))
+            sys.exit()
+        local_min = argrelextrema(gmm_y, np.less)
+        cut_off = gmm_x[local_min][0]
+        logging.info("Determined --yfrac cutoff: {}".format(str(round(cut_off, 4))))
+    genders = np.empty(len(samples), dtype="object")
+    genders[y_fractions > cut_off] = "M"
+    genders[y_fractions < cut_off] = "F"
+    return genders.tolist(), cut_off
+
+
+def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, contexts):
+    """One of the A / F / M passes: tool_newref_prep + tool_newref_main + tool_newref_post
+    (newref_control.py:24-189) without the temp-file round trips."""
+    from . import newref_tools
+    p = prep.prepare(samples, gender, total_mask, bins_per_chr)
+    X = p.pop("X")
+    cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
+    n_parts = len(contexts)
+    sample_ids = random.sample(range(X.shape[1]), min(X.shape[1], 100))   # newref_tools.py:214-217
+    parts = newref_tools.get_reference_parts(X, cum, args.refsize, n_parts, sample_ids, contexts)
+    out = dict(p)
+    out["binsize"] = args.binsize
+    out["indexes"] = np.concatenate([q[0] for q in parts])
+    out["distances"] = np.concatenate([q[1] for q in parts])
+    out["null_ratios"] = np.concatenate([q[2] for q in parts])
+    return out
+
+
+def tool_newref(args):
+    logging.info("Creating new reference")
+    if args.yfrac is not None and (args.yfrac < 0 or args.yfrac > 1):
+        logging.critical("Parameter --yfrac should be a positive number lower than or equal to 1")
+        sys.exit()
+    from . import _lib
+    n_gpus = max(1, int(getattr(args, "gpus", 1) or 1))
+    contexts = [_lib.default_context(d) for d in range(n_gpus)]
+
+    samples = []
+    logging.info("Importing data ...")
+    for infile in args.infiles:
+        logging.info("Loading: {}".format(infile))
+        sample, binsize = npz_io.load_sample(infile)
+        logging.info("Binsize: {}".format(int(binsize)))
+        samples.append(scale_sample(sample, binsize, args.binsize))
+    samples = np.array(samples)
+    genders, trained_cutoff = train_gender_model(args, samples)
+
+    if genders.count("F") < 5 and args.nipt:
+        logging.warning("A NIPT reference should have at least 5 female feti samples. "
+                        "Removing --nipt flag.")
+        args.nipt = False
+    if not args.nipt:
+        for i, sample in enumerate(samples):
+            samples[i] = gender_correct(sample, genders[i])
+
+    g = np.array(genders)
+    total_mask, bins_per_chr = prep.get_mask(samples)
+    if genders.count("F") > 4:
+        total_mask = total_mask & prep.get_mask(samples[g == "F"])[0]
+    if genders.count("M") > 4 and not args.nipt:
+        total_mask = total_mask & prep.get_mask(samples[g == "M"])[0]
+
+    final_ref = {"has_female": False, "has_male": False}
+    if len(genders) > 9:
+        logging.info("Starting autosomal reference creation ...")
+        sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts)
+        final_ref.update({k: v for k, v in sub.items() if k != "gender"})
+    else:
+        logging.critical("Provide at least 10 samples to enable the generation of a reference.")
+        sys.exit()
+    if genders.count("F") > 4:
+        logging.info("Starting female gonosomal reference creation ...")
+        sub = build_sub_reference(args, samples[g == "F"], "F", total_mask, bins_per_chr, contexts[:1])
+        final_ref["has_female"] = True
+        final_ref.update({k + ".F": v for k, v in sub.items() if k != "gender"})
+    else:
+        logging.warning("Provide at least 5 female samples to enable normalization of female gonosomes.")
+    if not args.nipt:
+        if genders.count("M") > 4:
+            logging.info("Starting male gonosomal reference creation ...")
+            sub = build_sub_reference(args, samples[g == "M"], "M", total_mask, bins_per_chr, contexts[:1])
+            final_ref["has_male"] = True
+            final_ref.update({k + ".M": v for k, v in sub.items() if k != "gender"})
+        else:
+            logging.warning("Provide at least 5 male samples to enable normalization of male gonosomes.")
+    final_ref["is_nipt"] = args.nipt
+    final_ref["trained_cutoff"] = trained_cutoff
+    npz_io.save_npz(args.outfile, final_ref)
+    logging.info("Finished creating reference")
+
+
+# --------------------------------------------------------------------------- gender / predict
+def output_gender(args):
+    ref_file = npz_io.load_reference(args.reference)
+    sample, _ = npz_io.load_sample(args.infile)
+    print("male" if predict_gender(sample, ref_file["trained_cutoff"]) == "M" else "female")
+
+
+def tool_test(args):
+    logging.info("Starting CNA prediction")
+    if not args.bed and not args.plot:
+        logging.critical("No output format selected. Select at least one of the supported output "
+                         "formats (--bed, --plot)")
+        sys.exit()
+    if args.zscore <= 0:
+        logging.critical("Parameter --zscore should be a strictly positive number")
+        sys.exit()
+    if args.beta is not None and (args.beta <= 0 or args.beta > 1):
+        logging.critical("Parameter --beta should be a strictly positive number lower than or equal to 1")
+        sys.exit()
+    if args.alpha <= 0 or args.alpha > 1:
+        logging.critical("Parameter --alpha should be a strictly positive number lower than or equal to 1")
+        sys.exit()
+    from . import predict_tools as pt
+    from .predict_output import generate_output_tables
+
+    logging.info("Importing data ...")
+    ref_file = npz_io.load_reference(args.reference)
+    sample, sample_binsize = npz_io.load_sample(args.infile)
+    n_reads = sum([sum(sample[x]) for x in sample.keys()])
+    sample = scale_sample(sample, int(sample_binsize), int(ref_file["binsize"]))
+
+    gender = predict_gender(sample, ref_file["trained_cutoff"])
+    if not ref_file["is_nipt"]:
+        if args.gender:
+            gender = args.gender
+        sample = gender_correct(sample, gender)
+        ref_gender = gender
+    else:
+        if args.gender:
+            gender = args.gender
+        ref_gender = "F"
+
+    cache = {}
+    logging.info("Normalizing autosomes ...")
+    res_a = pt.normalize(args, sample, ref_file, "A", cache)
+    if not ref_file["is_nipt"]:
+        if not ref_file["has_male"] and gender == "M":
+            logging.warning("This sample is male, whilst the reference is created with fewer than 5 "
+                            "males. The female gonosomal reference will be used for X predictions.")
+            ref_gender = "F"
+        elif not ref_file["has_female"] and gender == "F":
+            logging.warning("This sample is female, whilst the reference is created with fewer than 5 "
+                            "females. The male gonosomal reference will be used for XY predictions.")
+            ref_gender = "M"
+    logging.info("Normalizing gonosomes ...")
+    ap = ".{}".format(ref_gender)
+    nr_aut = ref_file["null_ratios"]
+    nr_gon = ref_file["null_ratios" + ap][len(nr_aut):]
+    res_g = pt.normalize(args, sample, ref_file, ref_gender, cache)
+
+    rem_input = {
+        "args": args, "binsize": int(ref_file["binsize"]), "n_reads": n_reads,
+        "ref_gender": ref_gender, "gender": gender, "mask": ref_file["mask" + ap],
+        "bins_per_chr": ref_file["bins_per_chr" + ap],
+        "masked_bins_per_chr": ref_file["masked_bins_per_chr" + ap],
+        "masked_bins_per_chr_cum": ref_file["masked_bins_per_chr_cum" + ap],
+    }
+    m_lr = res_a[4]
+    r, z, w, ref_sizes = pt.merge_autosomes_gonosomes(res_a, res_g)
+    if not np.isfinite(w).all():
+        logging.warning("Non-numeric values found in weights -- reference too small.")
+    m = max(nr_aut.shape[1], nr_gon.shape[1])
+    nr = np.full((len(nr_aut) + len(nr_gon), m), np.nan)      # ragged rows padded with NaN
+    nr[:len(nr_aut), :nr_aut.shape[1]] = nr_aut
+    nr[len(nr_aut):, :nr_gon.shape[1]] = nr_gon
+    results = {"results_r": r, "results_z": z, "results_w": w, "results_nr": nr}
+    for key in results:
+        results[key] = pt.get_post_processed_result(args, results[key], ref_sizes, rem_input)
+    pt.log_trans(results, m_lr)
+    if args.blacklist:
+        logging.info("Applying blacklist ...")
+        pt.apply_blacklist(rem_input, results)
+    logging.info("Executing circular binary segmentation ...")
+    results["results_c"] = pt.exec_cbs(rem_input, results)
+    if args.bed:
+        logging.info("Writing tables ...")
+        generate_output_tables(rem_input, results)
+    if args.plot:
+        logging.warning("--plot needs R (include/plotter.R of the reference); plotting is outside "
+                        "the MI355X hot path and is skipped")
+    logging.info("Finished prediction")
+    return results
+
+
+# --------------------------------------------------------------------------- CLI
+def build_parser():
+    parser = argparse.ArgumentParser(description="WisecondorX (MI355X hot path)")
+    parser.add_argument("--loglevel", type=str, default="INFO",
+                        choices=["info", "warning", "debug", "error", "critical"])
+    sub = parser.add_subparsers()
+    F = argparse.ArgumentDefaultsHelpFormatter
+
+    p = sub.add_parser("convert", description="Convert and filter a aligned reads to .npz",
+                       formatter_class=F)
+    p.add_argument("infile", type=str, help="aligned reads input for conversion")
+    p.add_argument("outfile", type=str, help="Output .npz file")
+    p.add_argument("-r", "--reference", type=str, help="Fasta reference to be used during cram conversion")
+    p.add_argument("--binsize", type=float, default=5e3, help="Bin size (bp)")
+    p.add_argument("--normdup", action="store_true", help="Do not remove duplicates")
+    p.set_defaults(func=tool_convert)
+
+    p = sub.add_parser("newref", description="Create a new reference using healthy reference samples",
+                       formatter_class=F)
+    p.add_argument("infiles", type=str, nargs="+", help="Path to all reference data files")
+    p.add_argument("outfile", type=str, help="Path and filename for the reference output")
+    p.add_argument("--nipt", action="store_true", help="Use flag for NIPT")
+    p.add_argument("--yfrac", type=float, default=None,
+                   help="Use to manually set the y read fraction cutoff, which defines gender")
+    p.add_argument("--plotyfrac", type=str, default=None, help="Path to yfrac .png plot")
+    p.add_argument("--refsize", type=int, default=300, help="Amount of reference locations per target")
+    p.add_argument("--binsize", type=int, default=1e5,
+                   help="Scale samples to this binsize, multiples of existing binsize only")
+    p.add_argument("--cpus", type=int, default=1, help="Accepted for compatibility (ignored)")
+    p.add_argument("--gpus", type=int, default=1, help="Number of MI355X devices to split the rows over")
+    p.set_defaults(func=tool_newref)
+
+    p = sub.add_parser("gender", description="Returns the gender of a .npz resulting from convert",
+                       formatter_class=F)
+    p.add_argument("infile", type=str, help=".npz input file")
+    p.add_argument("reference", type=str, help="Reference .npz, as previously created with newref")
+    p.set_defaults(func=output_gender)
+
+    p = sub.add_parser("predict", description="Find copy number aberrations", formatter_class=F)
+    p.add_argument("infile", type=str, help=".npz input file")
+    p.add_argument("reference", type=str, help="Reference .npz, as previously created with newref")
+    p.add_argument("outid", type=str, help="Basename (w/o extension) of output files")
+    p.add_argument("--minrefbins", type=int, default=150,
+                   help="Minimum amount of sensible reference bins per target bin.")
+    p.add_argument("--maskrepeats", type=int, default=5, help="Number of masking cycles.")
+    p.add_argument("--alpha", type=float, default=1e-4, help="p-value cut-off for calling a CBS breakpoint.")
+    p.add_argument("--zscore", type=float, default=5, help="z-score cut-off for aberration calling.")
+    p.add_argument("--beta", type=float, default=None, help="ratio cut-off parameter (0,1]")
+    p.add_argument("--blacklist", type=str, default=None, help="Blacklist .bed that masks regions in output")
+    p.add_argument("--gender", type=str, choices=["F", "M"], help="Force the gender")
+    p.add_argument("--ylim", type=str, default="def", help="y-axis limits for plotting")
+    p.add_argument("--bed", action="store_true", help="Outputs tab-delimited .bed files")
+    p.add_argument("--plot", action="store_true", help="Outputs .png plots (needs R; skipped)")
+    p.add_argument("--cairo", action="store_true", help="Uses cairo bitmap type for plotting.")
+    p.add_argument("--add-plot-title", action="store_true", help="Add the output name as plot title")
+    p.add_argument("--seed", type=int, default=None, help="Seed for segmentation algorithm")
+    p.add_argument("--regions", type=str, default=None, help="Regions .bed to summarise")
+    p.set_defaults(func=tool_test)
+    return parser
+
+
+def main(argv=None):
+    warnings.filterwarnings("ignore")
+    parser = build_parser()
+    args = parser.parse_args(sys.argv[1:] if argv is None else argv)
+    logging.basicConfig(format="[%(levelname)s - %(asctime)s]: %(message)s",
+                        datefmt="%Y-%m-%d %H:%M:%S",
+                        level=getattr(logging, args.loglevel.upper(), None))
+    logging.debug("args are: {}".format(args))
+    if not hasattr(args, "func"):
+        parser.print_help()
+        return
+    args.func(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -105,3 +105,26 @@ def get_reference(pca_corrected_data, masked_bins_per_chr, masked_bins_per_chr_c
     null_ratio_array = get_null_ratios(pca_corrected_data, index_array, start_num, end_num,
                                        sample_ids, ctx)
     return index_array, distance_array, null_ratio_array
+
+
+def get_reference_parts(pca_corrected_data, masked_bins_per_chr_cum, ref_size, n_parts,
+                        sample_ids, contexts=None, mode=0):
+    """All `n_parts` row parts (the reference's --cpus split, newref_control.py:92-98), part p on
+    device contexts[p % len(contexts)], driven from host threads (the C-ABI is re-entrant per
+    context).  Returns [(indexes, distances, null_ratios)] in part order."""
+    from concurrent.futures import ThreadPoolExecutor
+    contexts = contexts or [_lib.default_context()]
+    bincount = masked_bins_per_chr_cum[-1]
+
+    def work(p):
+        ctx = contexts[p % len(contexts)]
+        s, e = _get_part(p, n_parts, bincount)
+        idx, dist = get_ref_for_rows(pca_corrected_data, masked_bins_per_chr_cum, ref_size, s, e,
+                                     ctx, mode)
+        nr = get_null_ratios(pca_corrected_data, idx, s, e, sample_ids, ctx)
+        return idx, dist, nr
+
+    if n_parts == 1:
+        return [work(0)]
+    with ThreadPoolExecutor(max_workers=len(contexts)) as ex:
+        return list(ex.map(work, range(n_parts)))
