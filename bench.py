@@ -97,6 +97,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from wisecondorx_amd import _lib, predict_tools
+    from wisecondorx_amd import dist as wd
     from wisecondorx_amd.newref_tools import _get_part
 
     # ---------------------------------------------------------------- inputs (untimed)
@@ -130,54 +131,39 @@ def main():
     d_idx = torch.empty((max(n_rows, 1), k), dtype=torch.int32, device=dev)
     d_dist = torch.empty((max(n_rows, 1), k), dtype=torch.float64, device=dev)
     d_nr = torch.empty((max(n_rows, 1), m), dtype=torch.float64, device=dev)
-    Bp = n_rows
-    d_z = torch.empty(max(Bp, 1), dtype=torch.float64, device=dev)
+    d_z = torch.empty(B, dtype=torch.float64, device=dev)
     d_r = torch.empty_like(d_z)
     d_n = torch.empty_like(d_z)
     d_med = torch.empty(2, dtype=torch.float64, device=dev)
     cum_p = cum.ctypes.data_as(_lib.c_i64p)
     ids_p = null_ids.ctypes.data_as(_lib.c_i32p)
-    gathered = torch.empty((world * shard_rows, S), dtype=torch.float64, device=dev)
-    d_Xs = torch.empty((S, B), dtype=torch.float64, device=dev)
-
-    # predict on this rank's rows: a row-sliced view of the reference just built
-    sub_cum = np.clip(cum, row_begin, row_end) - row_begin
     topk_ms, nr_ms, norm_ms = [], [], []
 
+    backend = wd.GpuBackend(ctx)
+    out_bufs = (d_idx, d_dist, d_nr)
+
     def step(record):
-        # (1) exchange: every rank needs all candidate rows -> all-gather of the row shards
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, Xrow)
-            rows = []
-            for r in range(world):
-                a, b = _get_part(r, world, B)
-                rows.append(gathered[r * shard_rows: r * shard_rows + (b - a)])
-            full = torch.cat(rows, 0)
-        else:
-            full = Xrow[:B]
-        d_Xs.copy_(full.t())                       # sample-major [S][B]
-        # (2) newref search + null ratios for this rank's target rows
-        _lib.check(lib.wcx_newref_topk_dev(ctx.h, d_Xs.data_ptr(), B, S, cum_p, len(cum),
-                                           row_begin, row_end, k, args.mode,
-                                           d_idx.data_ptr(), d_dist.data_ptr()))
-        _lib.check(lib.wcx_null_ratios_dev(ctx.h, d_Xs.data_ptr(), B, S, d_idx.data_ptr(),
-                                           row_begin, row_end, k, ids_p, m, d_nr.data_ptr()))
-        # (3) predict: cut-off + 3 normalisation passes of one sample on these rows
-        if n_rows > 0 and world == 1:
-            h = _lib.vp()
-            _lib.check(lib.wcx_ref_wrap_dev(ctx.h, d_idx.data_ptr(), d_dist.data_ptr(), B, k,
-                                            cum_p, len(cum), C.byref(h)))
-            cut = C.c_double()
-            _lib.check(lib.wcx_cutoff(ctx.h, h, 5, C.byref(cut)))
-            _lib.check(lib.wcx_predict_normalize_dev(
-                ctx.h, h, d_x.data_ptr(), 1, cut.value, 0, 0, d_z.data_ptr(), d_r.data_ptr(),
-                d_n.data_ptr(), d_med.data_ptr(), d_med.data_ptr() + 8))
-            lib.wcx_ref_free(ctx.h, h)
+        # (1)+(2) ONE exchange (all-gather of the row shards of X over RCCL/xGMI), then the
+        # search + null ratios of this rank's target rows
+        idx_l, dist_l, _, d_Xs = wd.newref_sharded(Xrow, B, cum, k, null_ids, backend, rank, world,
+                                                   out=out_bufs)
+        # (3) predict = replicas: every rank gets the whole reference (all-gather of the finished
+        # row blocks) and normalises its own sample: cut-off + 3 masked passes
+        idx_f, dist_f = wd.gather_reference(idx_l, dist_l, B, world)
+        h = _lib.vp()
+        _lib.check(lib.wcx_ref_wrap_dev(ctx.h, idx_f.data_ptr(), dist_f.data_ptr(), B, k,
+                                        cum_p, len(cum), C.byref(h)))
+        cut = C.c_double()
+        _lib.check(lib.wcx_cutoff(ctx.h, h, 5, C.byref(cut)))
+        _lib.check(lib.wcx_predict_normalize_dev(
+            ctx.h, h, d_x.data_ptr(), 1, cut.value, 0, 0, d_z.data_ptr(), d_r.data_ptr(),
+            d_n.data_ptr(), d_med.data_ptr(), d_med.data_ptr() + 8))
+        lib.wcx_sync(ctx.h)
+        lib.wcx_ref_free(ctx.h, h)
         if record:
             topk_ms.append(ctx.kernel_ms("topk"))
             nr_ms.append(ctx.kernel_ms("null_ratios"))
-            if world == 1:
-                norm_ms.append(ctx.kernel_ms("normalize"))
+            norm_ms.append(ctx.kernel_ms("normalize"))
 
     def barrier():
         torch.cuda.synchronize()
@@ -239,11 +225,12 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "newref {} kb bins: B={} masked autosomal bins x S={} samples, "
                                "refsize={} (search + null ratios), + predict normalise of 1 "
-                               "sample{}".format(args.binsize // 1000, B, S, k,
-                                                 "" if world == 1 else " (predict leg: N=1 only)"),
+                               "sample per GPU".format(args.binsize // 1000, B, S, k),
                    "bins": int(B), "samples": int(S), "refsize": int(k),
                    "pairs": pairs_total, "bin_samples_per_s": B * S / (ms_per_step * 1e-3),
-                   "mode": args.mode, "partition": "row-block x{} + all-gather(X)".format(world)},
+                   "mode": args.mode,
+                   "partition": "target rows x{} (_get_part) + all-gather(X); predict replicas "
+                                "after all-gather(reference)".format(world)},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

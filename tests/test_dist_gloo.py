@@ -1,0 +1,85 @@
+"""CPU, world_size=2, gloo: the row-sharded reference build (partition + the one all-gather +
+result gather) gives exactly the single-process result.  The compute backend injected here is
+the oracle (tests may use it); on the GPU the same orchestration drives libwcx_hip.so."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    def search(self, Xs, B, S, chr_cum, row_begin, row_end, k, sample_ids, o_idx, o_dist, o_nr,
+               mode=0):
+        import torch
+        from oracle import c_oracle as CO
+        from oracle import wcx_oracle as O
+        xs = np.ascontiguousarray(Xs.numpy())
+        i, d = CO.get_reference_rows(xs, list(chr_cum), row_begin, row_end, k)
+        nr = O.null_ratios(xs.T, i, row_begin, row_end, list(sample_ids))
+        n = row_end - row_begin
+        o_idx[:n] = torch.from_numpy(i)
+        o_dist[:n] = torch.from_numpy(d)
+        o_nr[:n] = torch.from_numpy(nr)
+
+
+def _worker(rank, world, port, X, cum, k, ids, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from wisecondorx_amd import dist as wd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = X.shape[0]
+    b, e = wd.row_shard(rank, world, B)
+    pad = wd.max_shard_rows(world, B)
+    local = torch.zeros((pad, X.shape[1]), dtype=torch.float64)
+    local[:e - b] = torch.from_numpy(np.ascontiguousarray(X[b:e]))
+    idx, dd, nr, Xs = wd.newref_sharded(local, B, cum, k, ids, OracleBackend(), rank, world)
+    assert Xs.shape == (X.shape[1], B)
+    fi, fd = wd.gather_reference(idx, dd, B, world)
+    q.put((rank, idx.numpy().copy(), dd.numpy().copy(), nr.numpy().copy(),
+           fi.numpy().copy(), fd.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_newref_two_ranks():
+    import torch.multiprocessing as mp
+    from oracle import wcx_oracle as O
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([40, 33, 27, 25, 20, 18], 12, seed=3)
+    X = np.asfortranarray(X)
+    k, ids = 15, [3, 1, 7, 0]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, X, cum, k, ids, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ei, ed, enr = O.get_reference(X, mbpc, cum, k, 1, 1, ids)
+    assert np.array_equal(np.concatenate([r[1] for r in res]), ei)
+    assert np.array_equal(np.concatenate([r[2] for r in res]), ed)
+    assert np.array_equal(np.concatenate([r[3] for r in res]), enr)
+    for r in res:      # every replica holds the whole reference after the gather
+        assert np.array_equal(r[4], ei) and np.array_equal(r[5], ed)
+
+
+def test_stripe_and_shards():
+    from wisecondorx_amd import dist as wd
+    assert wd.stripe(list(range(7)), 1, 3) == [1, 4]
+    cover = []
+    for r in range(8):
+        b, e = wd.row_shard(r, 8, 182179)
+        cover += [b, e]
+    assert cover[0] == 0 and cover[-1] == 182179 and cover[1:-1:2] == cover[2::2]
