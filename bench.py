@@ -193,14 +193,20 @@ def main():
         # MFMA screen: algorithmic work = the -2 X^T X Gram GEMM, 2*S flop per candidate pair
         # (SURVEY.md §8d).  The kernel executes 3 fp16 MFMA products (hi.hi+hi.lo+lo.hi) over
         # K padded to a multiple of 16, reported as executed_tflops.
-        kpad = (S + 15) // 16 * 16
+        nk = (S + 15) // 16                       # same padding rule as wcx_topk_screen_launch
+        if args.debug_flags & 32 and S <= 128:
+            kpad, nprod, form = nk * 16, 3, "fp16 hi/lo x3"
+        else:
+            nk = (nk + 1) // 2 * 2 if nk <= 8 else (16 if nk <= 16 else 24 if nk <= 24 else 32)
+            kpad, nprod, form = nk * 16, 1, "fp16 hi plane"
         flops = 2.0 * S * stats["pairs"]
         achieved = flops / (screen_ms * 1e-3) / 1e12
-        roofline = {"kernel": "k_screen (v_mfma_f32_32x32x16_f16 x3, fp32 acc) + fused top-k filter",
+        roofline = {"kernel": "k_screen (v_mfma_f32_32x32x16_f16, {}, fp32 acc) + fused top-k "
+                              "filter".format(form),
                     "bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                     "kernel_ms": screen_ms,
-                    "executed_tflops": 3.0 * 2.0 * kpad * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
+                    "executed_tflops": nprod * 2.0 * kpad * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
                     "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
                     "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
                     "fallback_rows": stats["fallback_rows"], "compactions": stats["compactions"]}

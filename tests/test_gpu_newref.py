@@ -123,7 +123,8 @@ def _check_vs_c(nt, X, cum, k, s, e, mode):
     assert np.array_equal(dist, od)
 
 
-@pytest.mark.parametrize("S,k,seed", [(100, 300, 0), (33, 64, 2), (128, 512, 4), (16, 7, 5)])
+@pytest.mark.parametrize("S,k,seed", [(100, 300, 0), (33, 64, 2), (128, 512, 4), (16, 7, 5),
+                                      (500, 300, 6), (200, 100, 7), (300, 40, 8)])
 @pytest.mark.parametrize("mode", [1, 2])
 def test_screen_and_exact_modes_vs_c_oracle(nt, S, k, seed, mode):
     from wisecondorx_amd.synth import corrected_matrix

@@ -7,8 +7,8 @@
 //   k_transpose    Xs [S][B] -> Xr [B][S]                           (rows contiguous for refine)
 //   k_screen_prep  a = 2^p (x - c) split into fp16 hi + lo, written in MFMA-fragment order;
 //                  per row: |a~|^2, representation error norms      (rigorous error budget)
-//   k_screen       -2 a~.b~ Gram tiles on the matrix cores: v_mfma_f32_32x32x16_f16 x3
-//                  (hi.hi + hi.lo + lo.hi), fp32 accumulate; targets stay in registers as the
+//   k_screen       -2 a~.b~ Gram tiles on the matrix cores: v_mfma_f32_32x32x16_f16 (hi plane;
+//                  optionally hi.hi + hi.lo + lo.hi), fp32 accumulate; targets stay in registers as the
 //                  B operand, candidates stream through LDS as the A operand; the epilogue
 //                  adds the squared norms and appends (screen distance, index) to the target's
 //                  shortlist whenever the pair could still be among the k nearest given the
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(NT) void k_group_mask(const int *__restrict__ perm,
   gmask[g] = m;
 }
 
-template <int NK>
+template <int NK, int PL>
 __global__ __launch_bounds__(NT) void k_screen_prep(
     const double *__restrict__ Xr, int64_t Bpad, int S, int Sp,
     const double *__restrict__ cmean, const int *__restrict__ perm,
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
         if (row >= 0 && j < S) a = (Xr[row * Sp + j] - cmean[j]) * scale;
         const _Float16 hh = (_Float16)a;
         const double r1 = a - (double)hh;
-        const _Float16 ll = (_Float16)r1;
+        const _Float16 ll = PL == 2 ? (_Float16)r1 : (_Float16)0;
         const double res = r1 - (double)ll;
         const double at = (double)hh + (double)ll;
         n2 += at * at;
@@ -238,9 +238,9 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
         hi[e] = hh;
         lo[e] = ll;
       }
-      const int64_t base = ((tile * NK + ks) * 2) * 64 + rl + 32 * h;
+      const int64_t base = ((tile * NK + ks) * PL) * 64 + rl + 32 * h;
       F[base] = hi;
-      F[base + 64] = lo;
+      if (PL == 2) F[base + 64] = lo;
     }
   }
   RowInfo ri;
@@ -355,7 +355,10 @@ __device__ __forceinline__ float compact_target(uint2 *__restrict__ sl_row, int 
   return G;
 }
 
-template <int NK>
+// NK = k-steps of 16 (K padded), PL = fp16 planes (2: hi+lo, three products; 1: hi only, one
+// product -- larger shortlists, used when the targets' hi+lo fragments would not fit the
+// register file), CTG = candidate sub-tiles of 32 rows per main-loop iteration.
+template <int NK, int PL, int CTG>
 __global__ __launch_bounds__(NT, 2) void k_screen(
     const half8 *__restrict__ F, const RowInfo *__restrict__ info,
     const ScreenGlobals *__restrict__ glob, int64_t B, int64_t Bpad,
@@ -369,12 +372,16 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   // every workgroup of a launch streams the SAME few MB of candidate fragments, which therefore
   // come out of the XCD L2s instead of HBM/MALL.  Per-target state (threshold G, shortlist
   // count) lives in g_state/cnt_out between launches; the shortlists are in HBM anyway.
-  constexpr int TILE_H8 = CT / 32 * NK * 2 * 64;   // half8 elements per staged candidate group
+  constexpr int GR = CTG * 32;                      // candidate rows per iteration
+  constexpr int TILE_H8 = CTG * NK * PL * 64;       // half8 elements per staged candidate group
+  constexpr int NPT = TILE_H8 / NT;                 // 16-byte pieces per thread
+  static_assert(TILE_H8 % NT == 0, "staging must divide evenly over the workgroup");
+  constexpr int NOUT = CTG * 16;                    // screen outputs per lane per iteration
   extern __shared__ __align__(16) unsigned char smem[];
   half8 *sbuf = reinterpret_cast<half8 *>(smem);                       // [2][TILE_H8]
-  float *snb = reinterpret_cast<float *>(smem + 2 * TILE_H8 * 16);     // [2][CT]
-  int *cnt = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16 + 2 * CT * 4);  // [TGT]
-  int *sperm = cnt + TGT;                                              // [2][CT] rows of the group
+  float *snb = reinterpret_cast<float *>(smem + 2 * TILE_H8 * 16);     // [2][GR]
+  int *cnt = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16 + 2 * GR * 4);  // [TGT]
+  int *sperm = cnt + TGT;                                              // [2][GR] rows of the group
 
   const ScreenBlock blk = blocks[blockIdx.x];
   const int tid = threadIdx.x;
@@ -389,16 +396,16 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   if (tid < TGT) cnt[tid] = (first || tid >= blk.nrows) ? 0 : cnt_out[blk.row0 + tid - row_begin];
 
   // target operand (B operand of the MFMA) stays in registers for the whole sweep
-  half8 th[NK], tlo[NK];
+  half8 th[NK], tlo[PL == 2 ? NK : 1];
   {
     const int64_t tpos = rowpos[trow];        // sweep position of the target row
     const int64_t ttile = tpos >> 5;
     const int trl = (int)(tpos & 31);
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-      const int64_t base = ((ttile * NK + ks) * 2) * 64 + trl + 32 * hf;
+      const int64_t base = ((ttile * NK + ks) * PL) * 64 + trl + 32 * hf;
       th[ks] = F[base];
-      tlo[ks] = F[base + 64];
+      if (PL == 2) tlo[ks] = F[base + 64];
     }
   }
   const RowInfo ti = info[rowpos[trow]];
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
               N_max = __uint_as_float(glob->N_max);
   const float na = ti.nb;
   const float E = up(ti.e + e_max);
-  const float gamma = (float)(3 * 16 * NK + 8) * 1.1920929e-7f;   // n * 2^-23
+  const float gamma = (float)((PL == 2 ? 3 : 1) * 16 * NK + 8) * 1.1920929e-7f;   // n * 2^-23
   // Q also covers the threshold folded into the accumulator (see the main loop) and the
   // reconstruction t = G - 2 acc:  2.2 gamma (N_a + N_max)^2
   const float nsum = ti.N + N_max;
@@ -418,20 +425,21 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   unsigned long long n_compact = 0;
 
   const int64_t n_groups = gi_end;
-  // groups holding only own-chromosome rows are skipped (gmask = chromosomes present)
+  // groups holding only own-chromosome rows are skipped (gmask: chromosomes present per 64 rows)
   const unsigned int blkbit = 1u << blk.chr;
+  auto gm = [&](int64_t g) { return gmask[(g * GR) >> 6]; };
   auto next_group = [&](int64_t g) {
-    while (g < n_groups && gmask[g] == blkbit) ++g;
+    while (g < n_groups && gm(g) == blkbit) ++g;
     return g;
   };
-  half8 pre[NK];
+  half8 pre[NPT];
   float pre_nb = 0.f;
   int pre_row = -1;
   auto fetch = [&](int64_t gix) {
     const half8 *src = F + gix * (int64_t)TILE_H8;
 #pragma unroll
-    for (int p = 0; p < NK; ++p) pre[p] = src[p * NT + tid];
-    if (tid < CT) { pre_nb = info[gix * CT + tid].nb; pre_row = perm[gix * CT + tid]; }
+    for (int p = 0; p < NPT; ++p) pre[p] = src[p * NT + tid];
+    if (tid < GR) { pre_nb = info[gix * GR + tid].nb; pre_row = perm[gix * GR + tid]; }
   };
   int64_t gi = next_group(gi_begin);
   if (gi < n_groups) fetch(gi);
@@ -439,13 +447,13 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   __syncthreads();
   while (gi < n_groups) {
     half8 *sb = sbuf + buf * TILE_H8;
-    float *nbb = snb + buf * CT;
-    int *prow = sperm + buf * CT;
+    float *nbb = snb + buf * GR;
+    int *prow = sperm + buf * GR;
 #pragma unroll
-    for (int p = 0; p < NK; ++p) sb[p * NT + tid] = pre[p];
-    if (tid < CT) { nbb[tid] = pre_nb; prow[tid] = pre_row; }
+    for (int p = 0; p < NPT; ++p) sb[p * NT + tid] = pre[p];
+    if (tid < GR) { nbb[tid] = pre_nb; prow[tid] = pre_row; }
     __syncthreads();
-    const bool mixed = (gmask[gi] & blkbit) != 0;   // some own-chromosome rows in this group
+    const bool mixed = (gm(gi) & blkbit) != 0;   // some own-chromosome rows in this group
     const int64_t gn = next_group(gi + 1);
     if (gn < n_groups && !(dbg & 8)) fetch(gn);
 
@@ -455,56 +463,62 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
     const bool fast = __all(G < 1.0e37f);
     const float halfG = fast ? 0.5f * G : 0.f;
     const float nbscale = fast ? -0.5f : 0.f;
-    f32x16 acc0, acc1;
-    float nbv[32];
+    f32x16 acc[CTG];
+    float nbv[NOUT];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < CTG; ++sub) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
         nbv[sub * 16 + 4 * j + 0] = nb4.x; nbv[sub * 16 + 4 * j + 1] = nb4.y;
         nbv[sub * 16 + 4 * j + 2] = nb4.z; nbv[sub * 16 + 4 * j + 3] = nb4.w;
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc0[r] = fast ? fmaf(nbscale, nbv[r], halfG) : 0.f;
-      acc1[r] = fast ? fmaf(nbscale, nbv[16 + r], halfG) : 0.f;
+      for (int r = 0; r < 16; ++r) acc[sub][r] = fast ? fmaf(nbscale, nbv[sub * 16 + r], halfG) : 0.f;
     }
     if (!(dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-      const half8 c0h = sb[((0 * NK + ks) * 2 + 0) * 64 + lane];
-      const half8 c0l = sb[((0 * NK + ks) * 2 + 1) * 64 + lane];
-      const half8 c1h = sb[((1 * NK + ks) * 2 + 0) * 64 + lane];
-      const half8 c1l = sb[((1 * NK + ks) * 2 + 1) * 64 + lane];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0h, th[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1h, th[ks], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0h, tlo[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1h, tlo[ks], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0l, th[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1l, th[ks], acc1, 0, 0, 0);
+      half8 ch[CTG], cl[PL == 2 ? CTG : 1];
+#pragma unroll
+      for (int sub = 0; sub < CTG; ++sub) {
+        ch[sub] = sb[((sub * NK + ks) * PL + 0) * 64 + lane];
+        if (PL == 2) cl[sub] = sb[((sub * NK + ks) * PL + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int sub = 0; sub < CTG; ++sub)
+        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[sub], th[ks], acc[sub], 0, 0, 0);
+      if (PL == 2) {
+#pragma unroll
+        for (int sub = 0; sub < CTG; ++sub)
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[sub], tlo[ks], acc[sub], 0, 0, 0);
+#pragma unroll
+        for (int sub = 0; sub < CTG; ++sub)
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[sub], th[ks], acc[sub], 0, 0, 0);
+      }
     }
     // C[row = candidate][col = target]; output rr = sub*16 + r is candidate row
     // loc(rr) = sub*32 + 8*(r>>2) + 4*(lane>>5) + (r&3) of this group.  Bit (31-rr) of pmask.
     unsigned int pmask = 0;
     if (fast) {
+      unsigned int neg = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pmask = (pmask << 1) | (__float_as_uint(acc0[r]) >> 31);
+      for (int sub = 0; sub < CTG; ++sub)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pmask = (pmask << 1) | (__float_as_uint(acc1[r]) >> 31);
-      pmask = ~pmask;
+        for (int r = 0; r < 16; ++r) neg = (neg << 1) | (__float_as_uint(acc[sub][r]) >> 31);
+      pmask = (~neg) << (32 - NOUT);
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok0 = fmaf(-2.f, acc0[r], nbv[r]) <= G;
-        const bool ok1 = fmaf(-2.f, acc1[r], nbv[16 + r]) <= G;
-        pmask |= (ok0 ? (0x80000000u >> r) : 0u) | (ok1 ? (0x8000u >> r) : 0u);
-      }
+      for (int sub = 0; sub < CTG; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = fmaf(-2.f, acc[sub][r], nbv[sub * 16 + r]) <= G;
+          pmask |= ok ? (0x80000000u >> (sub * 16 + r)) : 0u;
+        }
     }
     if (mixed) {   // rare: mask the own-chromosome rows of a mixed group
 #pragma unroll
-      for (int rr = 0; rr < 32; ++rr) {
+      for (int rr = 0; rr < NOUT; ++rr) {
         const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
         const int64_t g = prow[loc];
         if (g >= blk.cs && g < blk.ce) pmask &= ~(0x80000000u >> rr);
@@ -515,11 +529,11 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
       int pos = 0;
       if (pmask) pos = atomicAdd(&cnt[tl], __popc(pmask));
 #pragma unroll
-      for (int rr = 0; rr < 32; ++rr) {
+      for (int rr = 0; rr < NOUT; ++rr) {
         if (pmask & (0x80000000u >> rr)) {
           const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
           const int64_t g = prow[loc];
-          const float av = rr < 16 ? acc0[rr & 15] : acc1[rr & 15];
+          const float av = acc[rr >> 4][rr & 15];
           const float t = fast ? fmaf(-2.f, av, G) : fmaf(-2.f, av, nbv[rr]);
           if (pos < CAP)
             sl_row[pos] = make_uint2(f32_key(t), (unsigned int)(g < blk.cs ? g : g - own));
@@ -573,7 +587,7 @@ __global__ void k_mark(unsigned char *searched, int64_t lo, int64_t hi) {
 // Host side --------------------------------------------------------------------------------
 int wcx_debug_value = 0;   // diagnostics only (wcx_debug_flags): ablation switches for profiling
 bool wcx_screen_supported(int64_t B, int S, int k) {
-  return S <= 128 && k <= 512 && k <= LIM && B >= 2048;
+  return S <= 512 && k <= 512 && k <= LIM && B >= 2048;
 }
 
 int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
@@ -581,7 +595,19 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                            const std::vector<TopkBlock> &exact_blocks, int64_t row_begin,
                            int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist) {
   if (exact_blocks.empty()) return WCX_OK;
-  const int NK = (S + 15) / 16;
+  // Default: hi plane only (one fp16 product).  Its representation error (2^-11 relative) only
+  // widens the shortlists by a few dozen entries, while a third of the MFMA work and half the
+  // LDS traffic of the hi+lo form (three products; kept behind debug flag 32, S <= 128 only) is
+  // enough -- measured 24.5 ms vs 33.0 ms at 15 kb / S=100, refine +1.2 ms.
+  // K is padded so that the staging divides evenly over the workgroup.
+  const bool two_planes = (wcx_debug_value & 32) && S <= 128;
+  const int PL = two_planes ? 2 : 1;
+  int NK = (S + 15) / 16;
+  if (!two_planes) {
+    if (NK <= 8) NK = (NK + 1) & ~1;
+    else NK = NK <= 16 ? 16 : (NK <= 24 ? 24 : 32);
+  }
+  const int CTG = NK <= 16 ? 2 : 1;
   const int64_t Bpad = (B + CT - 1) / CT * CT;
   // regroup the searched row ranges into workgroups of <= 128 rows (same chromosome)
   std::vector<ScreenBlock> blocks;
@@ -613,7 +639,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_mean = carve((size_t)S * 8);
   const int Sp = (S + 3) & ~3;
   const size_t o_xr = carve((size_t)B * Sp * 8);
-  const size_t o_F = carve((size_t)Bpad * NK * 64);  // Bpad/32 tiles * NK * 2 planes * 1 KiB
+  const size_t o_F = carve((size_t)Bpad * NK * PL * 32);  // Bpad/32 tiles * NK * PL planes * 1 KiB
   const size_t o_info = carve((size_t)Bpad * sizeof(RowInfo));
   const int64_t n_groups = Bpad / CT;
   const size_t o_perm = carve((size_t)Bpad * 4);
@@ -686,34 +712,51 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     k_group_mask<<<(unsigned)((n_groups + NT - 1) / NT), NT, 0, st>>>(perm, rchr, n_groups, gmask);
   }
   const unsigned gprep = (unsigned)((Bpad + NT - 1) / NT);
-  const size_t lds = 2 * (size_t)(CT / 32 * NK * 2 * 64) * 16 + 2 * CT * 4 + TGT * 4 + 2 * CT * 4;
+  const int GRr = CTG * 32;
+  const size_t lds = 2 * (size_t)(CTG * NK * PL * 64) * 16 + 2 * GRr * 4 + TGT * 4 + 2 * GRr * 4;
   // candidate chunk per launch: ~3 MB of fragments (fits the 4 MB XCD L2)
-  const int64_t group_bytes = (int64_t)CT * NK * 64;
+  const int64_t n_iter_groups = Bpad / GRr;
+  const int64_t group_bytes = (int64_t)GRr * NK * PL * 32;
   int64_t chunk_groups = (3 << 20) / group_bytes;
   if (chunk_groups < 16) chunk_groups = 16;
-#define WCX_SCREEN_CASE(N)                                                                    \
-  case N:                                                                                     \
-    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);            \
-    rc = wcx_timer_end(ctx, "topk_prep");                                                     \
-    if (rc) return rc;                                                                        \
-    rc = wcx_timer_begin(ctx, "topk_screen");                                                 \
-    if (rc) return rc;                                                                        \
-    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<N>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-    for (int64_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {                                    \
-      const int64_t g1 = g0 + chunk_groups < n_groups ? g0 + chunk_groups : n_groups;           \
-      k_screen<N><<<(unsigned)blocks.size(), NT, lds, st>>>(                                    \
-          F, info, glob, B, Bpad, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out,     \
-          flags, g_state, g0, g1,                                                               \
-          g0 == 0, g1 == n_groups, ctx->d_stats, wcx_debug_value);                                               \
-    }                                                                                           \
-    break;
-  switch (NK) {
-    WCX_SCREEN_CASE(1) WCX_SCREEN_CASE(2) WCX_SCREEN_CASE(3) WCX_SCREEN_CASE(4)
-    WCX_SCREEN_CASE(5) WCX_SCREEN_CASE(6) WCX_SCREEN_CASE(7) WCX_SCREEN_CASE(8)
-    default:
-      wcx_set_error("screen path supports S <= 128 (got %d)", S);
-      return WCX_ERR_UNSUPPORTED;
+#define WCX_SCREEN_CASE(N, P, G)                                                               \
+  {                                                                                            \
+    k_screen_prep<N, P><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);     \
+    rc = wcx_timer_end(ctx, "topk_prep");                                                      \
+    if (rc) return rc;                                                                         \
+    rc = wcx_timer_begin(ctx, "topk_screen");                                                  \
+    if (rc) return rc;                                                                         \
+    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<N, P, G>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    for (int64_t g0 = 0; g0 < n_iter_groups; g0 += chunk_groups) {                             \
+      const int64_t g1 = g0 + chunk_groups < n_iter_groups ? g0 + chunk_groups : n_iter_groups; \
+      k_screen<N, P, G><<<(unsigned)blocks.size(), NT, lds, st>>>(                             \
+          F, info, glob, B, Bpad, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out,    \
+          flags, g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats,                  \
+          wcx_debug_value);                                                                    \
+    }                                                                                          \
+  }
+  if (two_planes) {
+    switch (NK) {
+      case 1: WCX_SCREEN_CASE(1, 2, 2) break;
+      case 2: WCX_SCREEN_CASE(2, 2, 2) break;
+      case 3: WCX_SCREEN_CASE(3, 2, 2) break;
+      case 4: WCX_SCREEN_CASE(4, 2, 2) break;
+      case 5: WCX_SCREEN_CASE(5, 2, 2) break;
+      case 6: WCX_SCREEN_CASE(6, 2, 2) break;
+      case 7: WCX_SCREEN_CASE(7, 2, 2) break;
+      default: WCX_SCREEN_CASE(8, 2, 2) break;
+    }
+  } else {
+    switch (NK) {
+      case 2: WCX_SCREEN_CASE(2, 1, 2) break;
+      case 4: WCX_SCREEN_CASE(4, 1, 2) break;
+      case 6: WCX_SCREEN_CASE(6, 1, 2) break;
+      case 8: WCX_SCREEN_CASE(8, 1, 2) break;
+      case 16: WCX_SCREEN_CASE(16, 1, 2) break;
+      case 24: WCX_SCREEN_CASE(24, 1, 1) break;
+      default: WCX_SCREEN_CASE(32, 1, 1) break;
+    }
   }
 #undef WCX_SCREEN_CASE
   WCX_HIP(hipGetLastError());
