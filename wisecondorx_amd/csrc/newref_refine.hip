@@ -47,58 +47,80 @@ __device__ __forceinline__ void wave_sort_pairs(double (&d)[IPL], int (&ix)[IPL]
 }
 
 // One wave per target row: exact distances of the shortlisted candidates, sort, emit top k.
-// Each lane owns IPL shortlist entries and walks their rows of the row-major copy Xr with
-// 32-byte loads (rows are 32-byte aligned, stride Sp); the IPL sums advance together, each in
-// the reference's strict left-to-right order.
+//
+// Lane l owns shortlist entries e = q*64 + l.  Candidate rows live in the row-major copy Xr
+// (stride Sp doubles).  A lane walking its own row would touch a different cache line than every
+// other lane on every load (64 tag look-ups per instruction, ~3 visits per line); instead the wave
+// loads 16-double chunks COALESCED -- 8 lanes per candidate, 128 contiguous bytes -- into a
+// padded per-wave LDS tile and each lane then reads its own candidate's 16 values back
+// (conflict-free: 144-byte row pitch).  The sums still advance strictly left to right
+// (newref_tools.py:260 arithmetic, unfused).
+constexpr int RCH = 16;                 // doubles per chunk
+constexpr int RPITCH = RCH + 2;         // LDS row pitch in doubles (144 B)
+
 template <int IPL>
 __device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S, int Sp,
                                            int64_t row, int64_t cs, int64_t own,
                                            const uint2 *__restrict__ sl_row, int n, int k,
-                                           int32_t *__restrict__ oi, double *__restrict__ od) {
+                                           int32_t *__restrict__ oi, double *__restrict__ od,
+                                           double *__restrict__ tile, double *__restrict__ xt_s,
+                                           int *__restrict__ g_s) {
   const int lane = wcx::lane_id();
   double d[IPL];
   int ix[IPL];
-  const double *xc[IPL];
   const double *xt = Xr + row * (int64_t)Sp;
+  for (int j = lane; j < Sp; j += 64) xt_s[j] = xt[j];     // target row -> LDS (broadcast reads)
+  const int sub = lane >> 3, part = lane & 7;               // load role: candidate sub, 16-B piece
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
-    const int e = q * 64 + lane;
-    ix[q] = 0x7fffffff;
-    xc[q] = xt;
     d[q] = 0.0;
+    ix[q] = 0x7fffffff;
+    if (q * 64 >= n) continue;                               // wave-uniform
+    const int e = q * 64 + lane;
+    int g = (int)row;                                        // padding lanes read the target row
     if (e < n) {
       const int ci = (int)sl_row[e].y;
       ix[q] = ci;
-      const int64_t g = ci < cs ? (int64_t)ci : (int64_t)ci + own;
-      xc[q] = Xr + g * (int64_t)Sp;
+      g = ci < cs ? ci : ci + (int)own;
     }
-  }
-  int j = 0;
-#pragma clang loop unroll(disable)
-  for (; j + 4 <= S; j += 4) {
-    const double2 t01 = *reinterpret_cast<const double2 *>(xt + j);
-    const double2 t23 = *reinterpret_cast<const double2 *>(xt + j + 2);
+    g_s[lane] = g;
+    __builtin_amdgcn_wave_barrier();
+    int64_t base[8];
 #pragma unroll
-    for (int q = 0; q < IPL; ++q) {
-      const double2 c01 = *reinterpret_cast<const double2 *>(xc[q] + j);
-      const double2 c23 = *reinterpret_cast<const double2 *>(xc[q] + j + 2);
-      double diff = c01.x - t01.x;       // newref_tools.py:260, sequential, unfused
-      double sq = diff * diff;
-      d[q] = d[q] + sq;
-      diff = c01.y - t01.y; sq = diff * diff; d[q] = d[q] + sq;
-      diff = c23.x - t23.x; sq = diff * diff; d[q] = d[q] + sq;
-      diff = c23.y - t23.y; sq = diff * diff; d[q] = d[q] + sq;
-    }
-  }
-#pragma clang loop unroll(disable)
-  for (; j < S; ++j) {
-    const double t = xt[j];
+    for (int i = 0; i < 8; ++i) base[i] = (int64_t)g_s[i * 8 + sub] * Sp + part * 2;
+    double acc = 0.0;
+    for (int c0 = 0; c0 < S; c0 += RCH) {
+      // coalesced load of chunk [c0, c0+16) of 64 candidate rows: 8 instructions x 8 rows x 128 B
+      double2 v[8];
 #pragma unroll
-    for (int q = 0; q < IPL; ++q) {
-      const double diff = xc[q][j] - t;
-      const double sq = diff * diff;
-      d[q] = d[q] + sq;
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(Xr + base[i] + c0);
+      __builtin_amdgcn_wave_barrier();                       // previous chunk fully consumed
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<double2 *>(&tile[(i * 8 + sub) * RPITCH + part * 2]) = v[i];
+      __builtin_amdgcn_wave_barrier();
+      const int jn = (S - c0) < RCH ? (S - c0) : RCH;
+      const double *mine = &tile[lane * RPITCH];
+      if (jn == RCH) {
+#pragma unroll
+        for (int jj = 0; jj < RCH; jj += 2) {
+          const double2 cv = *reinterpret_cast<const double2 *>(mine + jj);
+          const double2 tv = *reinterpret_cast<const double2 *>(xt_s + c0 + jj);
+          double diff = cv.x - tv.x;
+          double sq = diff * diff;
+          acc = acc + sq;
+          diff = cv.y - tv.y; sq = diff * diff; acc = acc + sq;
+        }
+      } else {
+        for (int jj = 0; jj < jn; ++jj) {
+          const double diff = mine[jj] - xt_s[c0 + jj];
+          const double sq = diff * diff;
+          acc = acc + sq;
+        }
+      }
     }
+    d[q] = acc;
+    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
@@ -127,6 +149,12 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
                                                int32_t *__restrict__ out_idx,
                                                double *__restrict__ out_dist,
                                                ScreenGlobals *__restrict__ glob) {
+  extern __shared__ __align__(16) unsigned char rsm[];
+  const int wave = threadIdx.x >> 6;
+  const size_t per_wave = (size_t)(64 * RPITCH + Sp) * 8 + 64 * 4;
+  double *tile = reinterpret_cast<double *>(rsm + wave * per_wave);
+  double *xt_s = tile + 64 * RPITCH;
+  int *g_s = reinterpret_cast<int *>(xt_s + Sp);
   const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
   for (int64_t r = w0; r < n_rows; r += nw) {
@@ -141,7 +169,7 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
     int64_t cs = 0, ce = chr.cum[0];
     for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
     refine_row<8>(Xr, S, Sp, row, cs, ce - cs, sl + r * (int64_t)CAP, n, k,
-                  out_idx + r * (int64_t)k, out_dist + r * (int64_t)k);
+                  out_idx + r * (int64_t)k, out_dist + r * (int64_t)k, tile, xt_s, g_s);
   }
 }
 
@@ -216,7 +244,10 @@ int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTa
                       const uint2 *sl, const int *cnt_out, const unsigned int *flags, int k,
                       int32_t *d_out_idx, double *d_out_dist, ScreenGlobals *glob) {
   const unsigned gref = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
-  k_refine<<<gref, NT, 0, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out,
+  const size_t rlds = (NT / 64) * ((size_t)(64 * RPITCH + Sp) * 8 + 64 * 4);
+  WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_refine),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+  k_refine<<<gref, NT, rlds, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out,
                                          flags, k, d_out_idx, d_out_dist, glob);
   const unsigned gbig = (unsigned)(n_rows < 2048 ? n_rows : 2048);
   k_refine_big<<<gbig, NT, 0, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl,

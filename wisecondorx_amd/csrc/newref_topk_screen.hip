@@ -638,7 +638,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_glob = carve(sizeof(ScreenGlobals));
   const size_t o_mean = carve((size_t)S * 8);
   const int Sp = (S + 3) & ~3;
-  const size_t o_xr = carve((size_t)B * Sp * 8);
+  const size_t o_xr = carve((size_t)B * Sp * 8 + 256);   // + slack: refine loads whole 128-B chunks
   const size_t o_F = carve((size_t)Bpad * NK * PL * 32);  // Bpad/32 tiles * NK * PL planes * 1 KiB
   const size_t o_info = carve((size_t)Bpad * sizeof(RowInfo));
   const int64_t n_groups = Bpad / CT;
