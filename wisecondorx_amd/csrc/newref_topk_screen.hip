@@ -577,9 +577,10 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
   if (lane == 0 && stats) atomicAdd(&stats[2], n_compact);
 }
 
-__global__ void k_mark(unsigned char *searched, int64_t lo, int64_t hi) {
-  int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < hi) searched[i] = 1;
+__global__ void k_mark(unsigned char *searched, const ScreenBlock *__restrict__ blocks,
+                       int64_t row_begin) {
+  const ScreenBlock b = blocks[blockIdx.x];
+  if ((int)threadIdx.x < b.nrows) searched[b.row0 - row_begin + threadIdx.x] = 1;
 }
 
 }  // namespace
@@ -688,9 +689,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 32, st));
   rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
   if (rc) return rc;
-  for (const ScreenBlock &sb : blocks)
-    k_mark<<<(unsigned)((sb.nrows + 255) / 256), 256, 0, st>>>(searched, sb.row0 - row_begin,
-                                                              sb.row0 - row_begin + sb.nrows);
+  k_mark<<<(unsigned)blocks.size(), TGT, 0, st>>>(searched, d_blocks, row_begin);
 
   rc = wcx_timer_begin(ctx, "topk");
   if (rc) return rc;

@@ -48,6 +48,8 @@ __global__ __launch_bounds__(NT) void k_null_ratios(
     int64_t row_begin, int64_t n_rows, int k, int n_ids, double *__restrict__ out) {
   const int lane = wcx::lane_id();
   const int wave = threadIdx.x >> 6;
+  __shared__ int s_hist[NT / 64][64];
+  __shared__ double s_slots[NT / 64][64];
   const int64_t r = (int64_t)blockIdx.x * (NT / 64) + wave;
   if (r >= n_rows) return;
   const int sg = blockIdx.y;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(NT) void k_null_ratios(
     for (int q = 0; q < IPL; ++q) has_nan |= ((act >> q) & 1u) && (v[s][q] != v[s][q]);
     double med;
     if (__any(has_nan)) med = __builtin_nan("");  // np.median propagates NaN
-    else med = wcx::wave_median_select<IPL>(v[s], act, k);
+    else med = wcx::wave_median_bucket<IPL>(v[s], act, k, s_hist[wave], s_slots[wave]);
     if (lane == s) my_med = med;
   }
   const int m = sg * 8 + lane;
