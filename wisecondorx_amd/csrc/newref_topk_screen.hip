@@ -461,46 +461,46 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
     // acc starts at (G - |b~|^2)/2, so after the products acc = g~ - (|b~|^2 - G)/2 and the pair
     // passes (t = |b~|^2 - 2 g~ <= G) iff acc >= 0 -- one sign bit per output, no extra VALU.
     const bool fast = __all(G < 1.0e37f);
-    const float halfG = fast ? 0.5f * G : 0.f;
-    const float nbscale = fast ? -0.5f : 0.f;
     f32x16 acc[CTG];
-    float nbv[NOUT];
+    unsigned int pmask = 0;
+    auto products = [&]() {
+      if (!(dbg & 2))
 #pragma unroll
-    for (int sub = 0; sub < CTG; ++sub) {
+      for (int ks = 0; ks < NK; ++ks) {
+        half8 ch[CTG], cl[PL == 2 ? CTG : 1];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
-        nbv[sub * 16 + 4 * j + 0] = nb4.x; nbv[sub * 16 + 4 * j + 1] = nb4.y;
-        nbv[sub * 16 + 4 * j + 2] = nb4.z; nbv[sub * 16 + 4 * j + 3] = nb4.w;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[sub][r] = fast ? fmaf(nbscale, nbv[sub * 16 + r], halfG) : 0.f;
-    }
-    if (!(dbg & 2))
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      half8 ch[CTG], cl[PL == 2 ? CTG : 1];
-#pragma unroll
-      for (int sub = 0; sub < CTG; ++sub) {
-        ch[sub] = sb[((sub * NK + ks) * PL + 0) * 64 + lane];
-        if (PL == 2) cl[sub] = sb[((sub * NK + ks) * PL + 1) * 64 + lane];
-      }
-#pragma unroll
-      for (int sub = 0; sub < CTG; ++sub)
-        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[sub], th[ks], acc[sub], 0, 0, 0);
-      if (PL == 2) {
+        for (int sub = 0; sub < CTG; ++sub) {
+          ch[sub] = sb[((sub * NK + ks) * PL + 0) * 64 + lane];
+          if (PL == 2) cl[sub] = sb[((sub * NK + ks) * PL + 1) * 64 + lane];
+        }
 #pragma unroll
         for (int sub = 0; sub < CTG; ++sub)
-          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[sub], tlo[ks], acc[sub], 0, 0, 0);
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[sub], th[ks], acc[sub], 0, 0, 0);
+        if (PL == 2) {
 #pragma unroll
-        for (int sub = 0; sub < CTG; ++sub)
-          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[sub], th[ks], acc[sub], 0, 0, 0);
+          for (int sub = 0; sub < CTG; ++sub)
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[sub], tlo[ks], acc[sub], 0, 0, 0);
+#pragma unroll
+          for (int sub = 0; sub < CTG; ++sub)
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[sub], th[ks], acc[sub], 0, 0, 0);
+        }
       }
-    }
+    };
     // C[row = candidate][col = target]; output rr = sub*16 + r is candidate row
     // loc(rr) = sub*32 + 8*(r>>2) + 4*(lane>>5) + (r&3) of this group.  Bit (31-rr) of pmask.
-    unsigned int pmask = 0;
     if (fast) {
+      const float halfG = 0.5f * G;
+#pragma unroll
+      for (int sub = 0; sub < CTG; ++sub)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
+          acc[sub][4 * j + 0] = fmaf(-0.5f, nb4.x, halfG);
+          acc[sub][4 * j + 1] = fmaf(-0.5f, nb4.y, halfG);
+          acc[sub][4 * j + 2] = fmaf(-0.5f, nb4.z, halfG);
+          acc[sub][4 * j + 3] = fmaf(-0.5f, nb4.w, halfG);
+        }
+      products();
       unsigned int neg = 0;
 #pragma unroll
       for (int sub = 0; sub < CTG; ++sub)
@@ -508,20 +508,29 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
         for (int r = 0; r < 16; ++r) neg = (neg << 1) | (__float_as_uint(acc[sub][r]) >> 31);
       pmask = (~neg) << (32 - NOUT);
     } else {
+      asm volatile("; slow path" ::: "memory");
+#pragma unroll
+      for (int sub = 0; sub < CTG; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[sub][r] = 0.f;
+      products();
 #pragma unroll
       for (int sub = 0; sub < CTG; ++sub)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const bool ok = fmaf(-2.f, acc[sub][r], nbv[sub * 16 + r]) <= G;
+          const float nbr = nbb[sub * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
+          const bool ok = fmaf(-2.f, acc[sub][r], nbr) <= G;
           pmask |= ok ? (0x80000000u >> (sub * 16 + r)) : 0u;
         }
     }
     if (mixed) {   // rare: mask the own-chromosome rows of a mixed group
+      asm volatile("; mixed group" ::: "memory");   // keep this a branch (no if-conversion)
+      const int cs32 = (int)blk.cs, ce32 = (int)blk.ce;
 #pragma unroll
       for (int rr = 0; rr < NOUT; ++rr) {
         const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
-        const int64_t g = prow[loc];
-        if (g >= blk.cs && g < blk.ce) pmask &= ~(0x80000000u >> rr);
+        const int g = prow[loc];
+        if (g >= cs32 && g < ce32) pmask &= ~(0x80000000u >> rr);
       }
     }
     if (dbg & 1) pmask = 0;
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(NT, 2) void k_screen(
           const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
           const int64_t g = prow[loc];
           const float av = acc[rr >> 4][rr & 15];
-          const float t = fast ? fmaf(-2.f, av, G) : fmaf(-2.f, av, nbv[rr]);
+          const float t = fast ? fmaf(-2.f, av, G) : fmaf(-2.f, av, nbb[loc]);
           if (pos < CAP)
             sl_row[pos] = make_uint2(f32_key(t), (unsigned int)(g < blk.cs ? g : g - own));
           ++pos;
