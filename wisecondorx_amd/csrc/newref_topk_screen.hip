@@ -271,7 +271,7 @@ struct ScreenBlock {
 
 // Wave-level shortlist compaction of target `c` (0..31) of this wave.
 // Returns the new threshold G (t-space) for that target; updates cnt in LDS.
-__device__ __forceinline__ float compact_target(uint2 *__restrict__ sl_row, int *cnt_p, int k,
+__device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl_row, int *cnt_p, int k,
                                                 float na, float E, float Q, float G_old,
                                                 unsigned int *overflow_flag, bool exact) {
   const int lane = wcx::lane_id();
@@ -359,7 +359,7 @@ __device__ __forceinline__ float compact_target(uint2 *__restrict__ sl_row, int 
 // product -- larger shortlists, used when the targets' hi+lo fragments would not fit the
 // register file), CTG = candidate sub-tiles of 32 rows per main-loop iteration.
 template <int NK, int PL, int CTG>
-__global__ __launch_bounds__(NT, 2) void k_screen(
+__global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
     const half8 *__restrict__ F, const RowInfo *__restrict__ info,
     const ScreenGlobals *__restrict__ glob, int64_t B, int64_t Bpad,
     const int *__restrict__ perm, const int *__restrict__ rowpos,
