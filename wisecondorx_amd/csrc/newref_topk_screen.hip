@@ -46,31 +46,35 @@ __device__ __forceinline__ float up(float v) {  // a float strictly above v (v >
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_col_stats(const double *__restrict__ Xs, int64_t B,
-                                                  double *__restrict__ cmean,
-                                                  ScreenGlobals *__restrict__ glob) {
+constexpr int CSPLIT = 16;   // workgroups per sample column
+
+// per-sample mean over finite entries: partial sums, fp64 atomics
+__global__ __launch_bounds__(NT) void k_col_sum(const double *__restrict__ Xs, int64_t B,
+                                                double *__restrict__ csum,
+                                                double *__restrict__ ccnt) {
   const double *x = Xs + (int64_t)blockIdx.x * B;
-  __shared__ double sh[NT / 64], shc[NT / 64];
-  __shared__ double mean_s;
   double s = 0.0, c = 0.0;
-  for (int64_t i = threadIdx.x; i < B; i += NT) {
+  for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < B; i += (int64_t)NT * CSPLIT) {
     const double v = x[i];
     if (fabs(v) < HUGE_VAL) { s += v; c += 1.0; }  // finite only
   }
   s = wcx::wave_sum(s);
   c = wcx::wave_sum(c);
-  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; shc[threadIdx.x >> 6] = c; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double ts = 0, tc = 0;
-    for (int w = 0; w < NT / 64; ++w) { ts += sh[w]; tc += shc[w]; }
-    mean_s = tc > 0 ? ts / tc : 0.0;
-    cmean[blockIdx.x] = mean_s;
-  }
-  __syncthreads();
-  const double m = mean_s;
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&csum[blockIdx.x], s); atomicAdd(&ccnt[blockIdx.x], c); }
+}
+
+// cmean[j] = csum/ccnt; global max |x - mean| over finite entries
+__global__ __launch_bounds__(NT) void k_col_stats(const double *__restrict__ Xs, int64_t B,
+                                                  const double *__restrict__ csum,
+                                                  const double *__restrict__ ccnt,
+                                                  double *__restrict__ cmean,
+                                                  ScreenGlobals *__restrict__ glob) {
+  const double *x = Xs + (int64_t)blockIdx.x * B;
+  const double cc = ccnt[blockIdx.x];
+  const double m = cc > 0 ? csum[blockIdx.x] / cc : 0.0;
+  if (blockIdx.y == 0 && threadIdx.x == 0) cmean[blockIdx.x] = m;
   double mx = 0.0;
-  for (int64_t i = threadIdx.x; i < B; i += NT) {
+  for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < B; i += (int64_t)NT * CSPLIT) {
     const double a = fabs(x[i] - m);
     if (a < HUGE_VAL && a > mx) mx = a;
   }
@@ -646,7 +650,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_glob = carve(sizeof(ScreenGlobals));
-  const size_t o_mean = carve((size_t)S * 8);
+  const size_t o_mean = carve((size_t)S * 8 * 3);   // mean | sum | count
   const int Sp = (S + 3) & ~3;
   const size_t o_xr = carve((size_t)B * Sp * 8 + 256);   // + slack: refine loads whole 128-B chunks
   const size_t o_F = carve((size_t)Bpad * NK * PL * 32);  // Bpad/32 tiles * NK * PL planes * 1 KiB
@@ -704,7 +708,9 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   if (rc) return rc;
   rc = wcx_timer_begin(ctx, "topk_prep");
   if (rc) return rc;
-  k_col_stats<<<S, NT, 0, st>>>(dXs, B, cmean, glob);
+  WCX_HIP(hipMemsetAsync(cmean + S, 0, (size_t)S * 16, st));
+  k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, cmean + S, cmean + 2 * S);
+  k_col_stats<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, cmean + S, cmean + 2 * S, cmean, glob);
   k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
   {
     ChrTab tab0;

@@ -112,6 +112,8 @@ __global__ __launch_bounds__(NT) void k_normalize_pass(
     double *__restrict__ out_z, double *__restrict__ out_r, double *__restrict__ out_n,
     double *__restrict__ out_lr, int last_pass) {
   const int lane = wcx::lane_id();
+  __shared__ int s_hist[NT / 64][64];
+  __shared__ double s_slots[NT / 64][64];
   const int s = blockIdx.y;
   const double *xs = x + (int64_t)s * B;
   const double *cin = copy_in + (int64_t)s * B;
@@ -154,8 +156,8 @@ __global__ __launch_bounds__(NT) void k_normalize_pass(
       if ((keepmask >> q) & 1u) { const double e = v[q] - mean; ssl += e * e; }
     }
     const double sd = sqrt(wcx::wave_sum(ssl) / (double)n);
-    wcx::wave_bitonic_sort<IPL>(v);
-    const double med = wcx::wave_median_sorted<IPL>(v, n);
+    const double med = wcx::wave_median_bucket<IPL>(v, keepmask, n, s_hist[threadIdx.x >> 6],
+                                                    s_slots[threadIdx.x >> 6]);
     if (lane == 0) {
       const double xi = xs[i];
       const double z = (xi - mean) / sd;              // predict_tools.py:136
@@ -183,9 +185,12 @@ __device__ __forceinline__ double key_f64(unsigned long long kx) {
 
 constexpr int NTM = 1024;
 
-__global__ __launch_bounds__(NTM) void k_nanmedian(const double *__restrict__ a0, int64_t n,
-                                                   int64_t array_stride, double *__restrict__ out) {
-  const double *a = a0 + (int64_t)blockIdx.x * array_stride;
+__global__ __launch_bounds__(NTM) void k_nanmedian(const double *__restrict__ a0,
+                                                   const double *__restrict__ a1, int64_t n,
+                                                   int64_t array_stride, double *__restrict__ out0,
+                                                   double *__restrict__ out1) {
+  const double *a = (blockIdx.y ? a1 : a0) + (int64_t)blockIdx.x * array_stride;
+  double *out = blockIdx.y ? out1 : out0;
   __shared__ unsigned int hist[2][256];
   __shared__ unsigned long long prefix[2];
   __shared__ long long rank[2];
@@ -359,8 +364,8 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_
     wcx_set_error("refsize %d too large for the normalise kernel (max 2048)", k);
     return WCX_ERR_UNSUPPORTED;
   }
-  int ipl = 1;
-  while (64 * ipl < k) ipl <<= 1;
+  int ipl = (k + 63) / 64;                 // values per lane
+  if (ipl > 8) ipl = ipl <= 16 ? 16 : 32;
   const int64_t Bp = B - ct;
   if (Bp <= 0) return WCX_OK;
 
@@ -397,7 +402,11 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_
     switch (ipl) {
       case 1: WCX_NORM_LAUNCH(1); break;
       case 2: WCX_NORM_LAUNCH(2); break;
+      case 3: WCX_NORM_LAUNCH(3); break;
       case 4: WCX_NORM_LAUNCH(4); break;
+      case 5: WCX_NORM_LAUNCH(5); break;
+      case 6: WCX_NORM_LAUNCH(6); break;
+      case 7: WCX_NORM_LAUNCH(7); break;
       case 8: WCX_NORM_LAUNCH(8); break;
       case 16: WCX_NORM_LAUNCH(16); break;
       default: WCX_NORM_LAUNCH(32); break;
@@ -405,8 +414,8 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_
 #undef WCX_NORM_LAUNCH
   }
   // m_lr = nanmedian(log2 r), m_z = nanmedian(z)   (predict_tools.py:105-106)
-  k_nanmedian<<<(unsigned)n_samples, NTM, 0, ctx->stream>>>(lr, Bp, Bp, d_out_mlr);
-  k_nanmedian<<<(unsigned)n_samples, NTM, 0, ctx->stream>>>(d_out_z, Bp, Bp, d_out_mz);
+  k_nanmedian<<<dim3((unsigned)n_samples, 2), NTM, 0, ctx->stream>>>(lr, d_out_z, Bp, Bp, d_out_mlr,
+                                                                      d_out_mz);
   WCX_HIP(hipGetLastError());
   return wcx_timer_end(ctx, "normalize");
 }
