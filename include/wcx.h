@@ -133,6 +133,10 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
  * (rows of masked bins ignored; pad ragged rows with NaN), seg as produced by wcx_cbs;
  * out_z double[n_seg] (NaN where undefined), out_nnull double[n_seg] (may be NULL) = number of
  * finite null-segment averages: 0 is where the reference returns the string "nan". */
+/* Attach (upload once) the dense null-ratio matrix of a reference to the context; later
+ * wcx_segment_z calls may pass nr = NULL to use it (batches: 165 MB at 15 kb stays in HBM).
+ * nr = NULL detaches. */
+int wcx_set_null_matrix(wcx_ctx *ctx, const double *nr, int64_t n_bins, int m);
 int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
                   const int64_t *chr_off, int n_chr, const double *seg, int n_seg,
                   double *out_z, double *out_nnull);

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Config 5 evidence: predict a batch of samples at 15 kb on ONE MI355X (samples would be striped
+over the 8 GPUs of a node; there is no collective on this path).  Times: reference upload,
+cut-off, weights, batched 3-pass normalisation, host post-processing, GPU CBS, segment z."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--binsize", type=int, default=15000)
+    ap.add_argument("--samples", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=96)
+    ap.add_argument("--cbs-samples", type=int, default=3)
+    a = ap.parse_args()
+    import bench
+    from wisecondorx_amd import _lib, newref_tools, predict_tools as pt
+    co, p, _ = bench.make_workload(a.binsize, a.samples)
+    X = p["X"]
+    cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
+    ctx = _lib.default_context(0)
+    t = time.perf_counter()
+    idx, dist = newref_tools.get_ref_for_rows(X, cum, 300, 0, cum[-1], ctx)
+    nr = newref_tools.get_null_ratios(X, idx, 0, cum[-1], list(range(min(a.samples, 100))), ctx)
+    t_newref = time.perf_counter() - t
+    ref = dict(p)
+    ref.update({"indexes": idx, "distances": dist, "null_ratios": nr})
+    tests = [co.sample(5000 + i, "F", cnv=[(1 + i % 22, 200, 200 + 2000, 1.5)]) for i in range(a.batch)]
+    t = time.perf_counter()
+    xs = np.stack([pt.project_pc(pt.coverage_normalize_and_mask(s, ref, ""), ref, "") for s in tests])
+    t_host_prep = time.perf_counter() - t
+    cache = {}
+    t = time.perf_counter(); pt._dev(ref, "", cache); ctx.sync(); t_upload = time.perf_counter() - t
+    t = time.perf_counter(); cutoff = pt.get_optimal_cutoff(ref, 5, cache); t_cut = time.perf_counter() - t
+    t = time.perf_counter(); w = pt.get_weights(ref, "", cache); t_w = time.perf_counter() - t
+    t = time.perf_counter()
+    z, r, n, mlr, mz = pt.normalize_repeat_batch(xs, ref, cutoff, 0, 0, "", cache)
+    t_norm = time.perf_counter() - t
+    norm_kernel_ms = ctx.kernel_ms("normalize")
+    args = argparse.Namespace(minrefbins=150, alpha=1e-4, seed=1)
+    rem = {"args": args, "mask": ref["mask"], "bins_per_chr": ref["bins_per_chr"],
+           "binsize": a.binsize, "ref_gender": "F"}
+    t_post = t_cbs = t_segz = 0.0
+    n_seg = []
+    t = time.perf_counter()
+    off = np.concatenate(([0], np.cumsum(ref["bins_per_chr"]))).astype(int)
+    nr_full = pt.inflate_results(nr, rem)
+    pt.attach_null_matrix([nr_full[off[c]:off[c + 1]] for c in range(len(off) - 1)], ctx)
+    t_attach = time.perf_counter() - t
+    for i in range(min(a.cbs_samples, a.batch)):
+        t = time.perf_counter()
+        res = {"results_r": r[i], "results_z": z[i] - mz[i], "results_w": w / np.nanmean(w)}
+        for k in res:
+            res[k] = pt.get_post_processed_result(args, res[k], n[i], rem)
+        res["results_nr"] = pt.ATTACHED
+        pt.log_trans(res, mlr[i])
+        t_post += time.perf_counter() - t
+        t = time.perf_counter()
+        segs = pt.run_cbs(res, "A", args.alpha, a.binsize, args.seed, ctx)
+        t_cbs += time.perf_counter() - t
+        t = time.perf_counter()
+        pt.get_z_score(segs, res, ctx)
+        t_segz += time.perf_counter() - t
+        n_seg.append(len(segs))
+    m = max(1, min(a.cbs_samples, a.batch))
+    print(json.dumps({
+        "workload": "predict batch: {} samples, {} kb bins, B={}, k=300".format(a.batch, a.binsize // 1000, cum[-1]),
+        "newref_host_api_s": t_newref, "host_prep_per_sample_ms": 1e3 * t_host_prep / a.batch,
+        "ref_upload_s": t_upload, "null_matrix_attach_s": t_attach, "cutoff_ms": 1e3 * t_cut, "weights_ms": 1e3 * t_w,
+        "normalize_batch_s": t_norm, "normalize_kernels_ms": norm_kernel_ms,
+        "normalize_per_sample_ms": 1e3 * t_norm / a.batch,
+        "postprocess_per_sample_ms": 1e3 * t_post / m, "cbs_per_sample_s": t_cbs / m,
+        "segment_z_per_sample_ms": 1e3 * t_segz / m, "segments": n_seg}))
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,7 @@ SIGNATURES = {
                                             vp, vp, vp, vp]),
     "wcx_cbs": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64, vp,
                           C.c_int, C.POINTER(C.c_int)]),
+    "wcx_set_null_matrix": (C.c_int, [vp, vp, c_i64, C.c_int]),
     "wcx_segment_z": (C.c_int, [vp, vp, vp, vp, C.c_int, c_i64p, C.c_int, vp, C.c_int, vp, vp]),
 }
 

@@ -127,6 +127,7 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->scratch2) hipFree(ctx->scratch2);
   if (ctx->d_stats) hipFree(ctx->d_stats);
+  if (ctx->d_nullm) hipFree(ctx->d_nullm);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return WCX_OK;

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y,
     const int a_hi = kmax < amax_all ? kmax : amax_all;
     const int na = a_hi - minw + 1;
     if (na > 0)
-      for (long long q = tid; q < (long long)na * (n + 1); q += NTP) {
-        const int a = minw + (int)(q % na), i = (int)(q / na);
+      for (int q = tid; q < na * (n + 1); q += NTP) {
+        const int a = minw + q % na, i = q / na;
         if (i + a > n) continue;
         const float d = Sx(i + a) - Sx(i), wa = Wp[i + a] - Wp[i];
         const float b = d * d / (wa * (W - wa) / W);
@@ -193,6 +193,30 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y,
   (void)bc;
 }
 
+// nu(x) series for a grid of x values: one workgroup per x, threads over the terms
+//   ln nu = ln 2 - 2 ln x - 2 sum_{k>=1} Phi(-x sqrt(k)/2) / k      (terms vanish once x sqrt(k)/2 > 8.5)
+__global__ __launch_bounds__(256) void k_nu_series(const double *__restrict__ xs,
+                                                   double *__restrict__ out) {
+  const double x = xs[blockIdx.x];
+  __shared__ double red[4];
+  double acc = 0.0;
+  if (x > 0.01) {
+    const double kmax_d = (17.0 / x) * (17.0 / x);
+    const long long kmax = kmax_d < 4.0e7 ? (long long)kmax_d + 1 : 40000000ll;
+    for (long long k = 1 + threadIdx.x; k <= kmax; k += 256) {
+      const double dk = (double)k;
+      acc += 0.5 * erfc(x * sqrt(dk) * 0.5 * 0.70710678118654752440) / dk;   // Phi(-x sqrt(k)/2)/k
+    }
+  }
+  acc = wcx::wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double s = red[0] + red[1] + red[2] + red[3];
+    out[blockIdx.x] = x > 0.01 ? exp(log(2.0) - 2.0 * log(x) - 2.0 * s) : exp(-0.583 * x);
+  }
+}
+
 // ------------------------------------------------------------------ host-side statistics
 double fpnorm(double x) { return 0.5 * erfc(-x / M_SQRT2); }
 
@@ -222,19 +246,29 @@ double it1tsq(double x, double a) {   // integral of 1/(t(1-t))^2 over [x, x+a]
   return r;
 }
 
-// P(max over arcs with delta <= length/m <= 1-delta of the CBS statistic >= b), Gaussian null
-double tailp(double b, double delta, int m, int ngrid, double tol) {
+// P(max over arcs with delta <= length/m <= 1-delta of the CBS statistic >= b), Gaussian null.
+// The ngrid nu() evaluations (10^4..10^6 series terms each for long chromosomes) run on the GPU.
+int tailp_gpu(wcx_ctx *ctx, double *d_x, double *d_nu, double b, double delta, int m, int ngrid,
+              double *result) {
+  std::vector<double> xs(ngrid), tls(ngrid), nus(ngrid);
   const double dincr = (0.5 - delta) / ngrid;
   const double bsqrtm = b / sqrt((double)m);
-  double tl = 0.5 - dincr, t = 0.5 - 0.5 * dincr, acc = 0.0;
+  double tl = 0.5 - dincr, t = 0.5 - 0.5 * dincr;
   for (int i = 0; i < ngrid; ++i) {
-    const double x = bsqrtm / sqrt(t * (1.0 - t));
-    const double nux = nu_fn(x, tol);
-    acc += nux * nux * it1tsq(tl, dincr);
+    xs[i] = bsqrtm / sqrt(t * (1.0 - t));
+    tls[i] = tl;
     tl -= dincr;
     t -= dincr;
   }
-  return 9.973557e-2 * b * b * b * exp(-b * b / 2.0) * acc;
+  WCX_HIP(hipMemcpyAsync(d_x, xs.data(), ngrid * 8, hipMemcpyHostToDevice, ctx->stream));
+  k_nu_series<<<ngrid, 256, 0, ctx->stream>>>(d_x, d_nu);
+  WCX_HIP(hipGetLastError());
+  WCX_HIP(hipMemcpyAsync(nus.data(), d_nu, ngrid * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  double acc = 0.0;
+  for (int i = 0; i < ngrid; ++i) acc += nus[i] * nus[i] * it1tsq(tls[i], dincr);
+  *result = 9.973557e-2 * b * b * b * exp(-b * b / 2.0) * acc;
+  return WCX_OK;
 }
 
 // regularised incomplete beta (continued fraction) -> two-sided Student t p-value
@@ -296,6 +330,7 @@ struct CbsWork {  // device buffers reused across tests
   double *dS = nullptr, *dWp = nullptr;
   float *dy = nullptr, *drw = nullptr, *dWpf = nullptr, *dout = nullptr;
   ArcBest *dbest = nullptr;
+  double *dtx = nullptr, *dtnu = nullptr;   // tail-probability grid
   int cap = 0;
 };
 
@@ -344,7 +379,9 @@ int cbs_test(wcx_ctx *ctx, CbsWork &wk, const double *x, const double *w, int n,
   double pval2 = P.alpha;
   if (hybrid) {
     const double delta = (P.kmax + 1.0) / n;
-    const double pval1 = tailp(sqrt(ostat), delta, n, P.ngrid, P.tol);
+    double pval1 = 0.0;
+    int rct = tailp_gpu(ctx, wk.dtx, wk.dtnu, sqrt(ostat), delta, n, P.ngrid, &pval1);
+    if (rct) return rct;
     if (pval1 > P.alpha) return WCX_OK;
     pval2 = P.alpha - pval1;
   }
@@ -445,7 +482,7 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
   CbsWork wk;
   const size_t nb = (size_t)maxn + 1;
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, nb * (8 + 8 + 4 + 4 + 4) + 4096 + 256 * 4, &scr);
+  int rc = wcx_scratch(ctx, nb * (8 + 8 + 4 + 4 + 4) + 4096 + 256 * 4 + 4096, &scr);
   if (rc) return rc;
   char *p = reinterpret_cast<char *>(scr);
   wk.dS = reinterpret_cast<double *>(p); p += nb * 8;
@@ -455,7 +492,9 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
   wk.dWpf = reinterpret_cast<float *>(p); p += nb * 4;
   p = reinterpret_cast<char *>(((uintptr_t)p + 255) & ~(uintptr_t)255);
   wk.dbest = reinterpret_cast<ArcBest *>(p); p += 256;
-  wk.dout = reinterpret_cast<float *>(p);
+  wk.dout = reinterpret_cast<float *>(p); p += 256 * 4;
+  wk.dtx = reinterpret_cast<double *>(p); p += 1024;
+  wk.dtnu = reinterpret_cast<double *>(p);
   CbsParams P;
   P.alpha = alpha;
   P.seed = seed;
@@ -542,14 +581,41 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
   return WCX_OK;
 }
 
+int wcx_set_null_matrix(wcx_ctx *ctx, const double *nr, int64_t n_bins, int m) {
+  WCX_ARG(ctx, "ctx is NULL");
+  WCX_HIP(hipSetDevice(ctx->device));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->d_nullm) { WCX_HIP(hipFree(ctx->d_nullm)); ctx->d_nullm = nullptr; }
+  ctx->nullm_bins = 0;
+  ctx->nullm_m = 0;
+  if (!nr) return WCX_OK;
+  WCX_ARG(n_bins > 0 && m > 0 && m <= 128, "bad sizes (m <= 128)");
+  const size_t bytes = (size_t)n_bins * m * 8;
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->d_nullm), bytes) != hipSuccess) {
+    wcx_set_error("hipMalloc(%zu) for the null-ratio matrix failed", bytes);
+    return WCX_ERR_NOMEM;
+  }
+  WCX_HIP(hipMemcpyAsync(ctx->d_nullm, nr, bytes, hipMemcpyHostToDevice, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->nullm_bins = n_bins;
+  ctx->nullm_m = m;
+  return WCX_OK;
+}
+
 int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
                   const int64_t *chr_off, int n_chr, const double *seg, int n_seg, double *out_z,
                   double *out_nnull) {
-  WCX_ARG(ctx && r && w && nr && chr_off && seg && out_z, "NULL argument");
-  WCX_ARG(m > 0 && m <= 128 && n_chr > 0 && n_seg >= 0, "bad sizes (m <= 128)");
+  WCX_ARG(ctx && r && w && chr_off && seg && out_z, "NULL argument");
+  WCX_ARG(n_chr > 0 && n_seg >= 0, "bad sizes");
   if (n_seg == 0) return WCX_OK;
   WCX_HIP(hipSetDevice(ctx->device));
   const int64_t nb = chr_off[n_chr];
+  const bool attached = (nr == nullptr);
+  if (attached) {
+    WCX_ARG(ctx->d_nullm && ctx->nullm_bins == nb, "no attached null matrix of matching size");
+    m = ctx->nullm_m;
+  }
+  WCX_ARG(m > 0 && m <= 128, "bad sizes (m <= 128)");
   std::vector<int64_t> b0(n_seg), b1(n_seg);
   std::vector<double> sr(n_seg);
   for (int s = 0; s < n_seg; ++s) {
@@ -560,7 +626,7 @@ int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *
     WCX_ARG(b0[s] >= chr_off[c] && b1[s] <= chr_off[c + 1] && b0[s] <= b1[s], "segment out of range");
     sr[s] = seg[s * 4 + 3];
   }
-  const size_t vb = (size_t)nb * 8, nrb = (size_t)nb * m * 8, sb = (size_t)n_seg * 8;
+  const size_t vb = (size_t)nb * 8, nrb = attached ? 0 : (size_t)nb * m * 8, sb = (size_t)n_seg * 8;
   void *scr = nullptr;
   int rc = wcx_scratch(ctx, 2 * vb + nrb + 5 * sb + 1024, &scr);
   if (rc) return rc;
@@ -576,13 +642,14 @@ int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *
   hipStream_t st = ctx->stream;
   WCX_HIP(hipMemcpyAsync(dr, r, vb, hipMemcpyHostToDevice, st));
   WCX_HIP(hipMemcpyAsync(dw, w, vb, hipMemcpyHostToDevice, st));
-  WCX_HIP(hipMemcpyAsync(dnr, nr, nrb, hipMemcpyHostToDevice, st));
+  if (!attached) WCX_HIP(hipMemcpyAsync(dnr, nr, nrb, hipMemcpyHostToDevice, st));
   WCX_HIP(hipMemcpyAsync(db0, b0.data(), sb, hipMemcpyHostToDevice, st));
   WCX_HIP(hipMemcpyAsync(db1, b1.data(), sb, hipMemcpyHostToDevice, st));
   WCX_HIP(hipMemcpyAsync(dsr, sr.data(), sb, hipMemcpyHostToDevice, st));
   rc = wcx_timer_begin(ctx, "segment_z");
   if (rc) return rc;
-  k_segment_z<<<n_seg, 128, 0, st>>>(dr, dw, dnr, m, db0, db1, dsr, n_seg, dz, dn);
+  k_segment_z<<<n_seg, 128, 0, st>>>(dr, dw, attached ? ctx->d_nullm : dnr, m, db0, db1, dsr, n_seg,
+                                     dz, dn);
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "segment_z");
   if (rc) return rc;

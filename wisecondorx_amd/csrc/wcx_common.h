@@ -48,6 +48,10 @@ struct wcx_ctx {
   size_t scratch_bytes = 0;
   void *scratch2 = nullptr;
   size_t scratch2_bytes = 0;
+  // null-ratio matrix attached for wcx_segment_z (wcx_set_null_matrix)
+  double *d_nullm = nullptr;
+  int64_t nullm_bins = 0;
+  int nullm_m = 0;
   // host staging for small async uploads (kept alive until the next stream sync)
   std::vector<std::vector<unsigned char>> stage;
 };

@@ -223,9 +223,15 @@ def tool_test(args):
     nr = np.full((len(nr_aut) + len(nr_gon), m), np.nan)      # ragged rows padded with NaN
     nr[:len(nr_aut), :nr_aut.shape[1]] = nr_aut
     nr[len(nr_aut):, :nr_gon.shape[1]] = nr_gon
-    results = {"results_r": r, "results_z": z, "results_w": w, "results_nr": nr}
+    results = {"results_r": r, "results_z": z, "results_w": w}
     for key in results:
         results[key] = pt.get_post_processed_result(args, results[key], ref_sizes, rem_input)
+    # null ratios: inflated once and kept on the device (rows of bins with ratio 0 are skipped by
+    # the segment-z kernel, so the per-sample zeroing of predict_control.py:50-52 is a no-op)
+    off = np.concatenate(([0], np.cumsum(rem_input["bins_per_chr"]))).astype(int)
+    nr_full = pt.inflate_results(nr, rem_input)
+    pt.attach_null_matrix([nr_full[off[c]:off[c + 1]] for c in range(len(off) - 1)])
+    results["results_nr"] = pt.ATTACHED
     pt.log_trans(results, m_lr)
     if args.blacklist:
         logging.info("Applying blacklist ...")

@@ -241,6 +241,20 @@ def _null_matrix(results):
     return out
 
 
+def attach_null_matrix(results_nr, ctx=None):
+    """Upload the (inflated, per-chromosome) null ratios once; subsequent get_z_score calls with
+    results["results_nr"] = ATTACHED use the device copy.  Bins whose ratio is 0 are skipped by
+    the kernel exactly like overall_tools.py:98-100 skips them, so the per-sample zeroing of
+    null rows (predict_control.py:50-52) has no effect on the result and is not needed."""
+    ctx = ctx or _lib.default_context()
+    nr = np.ascontiguousarray(_null_matrix({"results_nr": results_nr}), dtype=np.float64)
+    _lib.check(ctx.lib.wcx_set_null_matrix(ctx.h, _lib.ptr(nr), nr.shape[0], nr.shape[1]))
+    return nr.shape
+
+
+ATTACHED = "attached"
+
+
 def get_z_score(results_c, results, ctx=None):
     """overall_tools.py:88-119: per-segment z against the null ratios; "nan" string where the
     null mean/sd is undefined, exactly like the reference."""
@@ -248,14 +262,17 @@ def get_z_score(results_c, results, ctx=None):
     if not len(results_c):
         return []
     r, w = _flatten(results, "results_r"), _flatten(results, "results_w")
-    nr = np.ascontiguousarray(_null_matrix(results), dtype=np.float64)
     off, off_p = _lib.i64_array(_chr_offsets(results))
     seg = np.ascontiguousarray([[s[0], s[1], s[2], s[3]] for s in results_c], dtype=np.float64)
     z = np.empty(len(seg))
     nn = np.empty(len(seg))
-    _lib.check(ctx.lib.wcx_segment_z(ctx.h, _lib.ptr(r), _lib.ptr(w), _lib.ptr(nr), nr.shape[1],
-                                     off_p, len(off) - 1, _lib.ptr(seg), len(seg), _lib.ptr(z),
-                                     _lib.ptr(nn)))
+    if isinstance(results["results_nr"], str) and results["results_nr"] == ATTACHED:
+        nr_p, m = None, 0
+    else:
+        nr = np.ascontiguousarray(_null_matrix(results), dtype=np.float64)
+        nr_p, m = _lib.ptr(nr), nr.shape[1]
+    _lib.check(ctx.lib.wcx_segment_z(ctx.h, _lib.ptr(r), _lib.ptr(w), nr_p, m, off_p, len(off) - 1,
+                                     _lib.ptr(seg), len(seg), _lib.ptr(z), _lib.ptr(nn)))
     return ["nan" if nn[i] == 0 else float(z[i]) for i in range(len(seg))]
 
 
