@@ -15,17 +15,64 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   return __shfl_xor(v, mask, 64);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+// ---- DPP cross-lane primitives (VALU speed; ds_bpermute-based shuffles cost ~100 cycles each).
+// Wave64 inclusive scan schedule on gfx9-family DPP: row_shr 1,2,4,8 inside each row of 16 lanes,
+// then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3.  Lanes without a source keep
+// `old` (bound_ctrl off), so `old` must be the operation's identity.
+template <int CTRL, int RM>
+__device__ __forceinline__ int dpp_i32(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, RM, 0xf, false);
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_f64(double old, double src) {
+  const long long o = __double_as_longlong(old), x = __double_as_longlong(src);
+  const int lo = dpp_i32<CTRL, RM>((int)(o & 0xffffffffll), (int)(x & 0xffffffffll));
+  const int hi = dpp_i32<CTRL, RM>((int)(o >> 32), (int)(x >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+  v += dpp_i32<0x111, 0xf>(0, v);
+  v += dpp_i32<0x112, 0xf>(0, v);
+  v += dpp_i32<0x114, 0xf>(0, v);
+  v += dpp_i32<0x118, 0xf>(0, v);
+  v += dpp_i32<0x142, 0xa>(0, v);
+  v += dpp_i32<0x143, 0xc>(0, v);
   return v;
 }
 
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  return __builtin_amdgcn_readlane(wave_incl_scan_i(v), 63);
 }
+
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<0x111, 0xf>(0.0, v);
+  v += dpp_f64<0x112, 0xf>(0.0, v);
+  v += dpp_f64<0x114, 0xf>(0.0, v);
+  v += dpp_f64<0x118, 0xf>(0.0, v);
+  v += dpp_f64<0x142, 0xa>(0.0, v);
+  v += dpp_f64<0x143, 0xc>(0.0, v);
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {   // no NaNs
+  double o;
+  o = dpp_f64<0x111, 0xf>(HUGE_VAL, v); v = o < v ? o : v;
+  o = dpp_f64<0x112, 0xf>(HUGE_VAL, v); v = o < v ? o : v;
+  o = dpp_f64<0x114, 0xf>(HUGE_VAL, v); v = o < v ? o : v;
+  o = dpp_f64<0x118, 0xf>(HUGE_VAL, v); v = o < v ? o : v;
+  o = dpp_f64<0x142, 0xa>(HUGE_VAL, v); v = o < v ? o : v;
+  o = dpp_f64<0x143, 0xc>(HUGE_VAL, v); v = o < v ? o : v;
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double wave_max_f64(double v) { return -wave_min_f64(-v); }
 
 template <int IPL>
 __device__ __forceinline__ void wave_bitonic_sort(double (&v)[IPL]) {
@@ -147,12 +194,8 @@ __device__ __forceinline__ double wave_select_bucket(const double (&v)[IPL], uns
 #pragma unroll
   for (int q = 0; q < IPL; ++q)
     if ((act >> q) & 1u) { lo = v[q] < lo ? v[q] : lo; hi = v[q] > hi ? v[q] : hi; }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const double ol = shfl_xor_f64(lo, m), oh = shfl_xor_f64(hi, m);
-    lo = ol < lo ? ol : lo;
-    hi = oh > hi ? oh : hi;
-  }
+  lo = wave_min_f64(lo);
+  hi = wave_max_f64(hi);
   const double range = hi - lo;
   if (range == 0.0) return lo;
   if (!(range > 0.0) || !(range < HUGE_VAL)) return wave_quickselect<IPL>(v, act, rank);
@@ -172,12 +215,7 @@ __device__ __forceinline__ double wave_select_bucket(const double (&v)[IPL], uns
   }
   __builtin_amdgcn_wave_barrier();
   const int h = hist[lane];
-  int cum = h;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(cum, off, 64);
-    if (lane >= off) cum += t;
-  }
+  const int cum = wave_incl_scan_i(h);
   const unsigned long long gt = __ballot(cum > rank);
   if (gt == 0ull) return wave_quickselect<IPL>(v, act, rank);   // cannot happen for rank < n
   const int B = __ffsll((long long)gt) - 1;
@@ -225,11 +263,7 @@ __device__ __forceinline__ double wave_median_bucket(const double (&v)[IPL], uns
     if (on && v[q] > a && v[q] < mn) mn = v[q];
   }
   double bb = a;
-  if (cle < (n >> 1) + 1) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const double o = shfl_xor_f64(mn, m); mn = o < mn ? o : mn; }
-    bb = mn;
-  }
+  if (cle < (n >> 1) + 1) bb = wave_min_f64(mn);
   return (a + bb) / 2.0;
 }
 
