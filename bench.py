@@ -218,6 +218,15 @@ def main():
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
                     "kernel_ms": k_ms, "pairs_per_launch": stats["pairs"],
                     "compactions": stats["compactions"]}
+    # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (bench.py cannot read
+    # counters itself): profiles/r01/screen_traffic.json, recorded on this exact default workload
+    tpath = os.path.join(ROOT, "profiles", "r01", "screen_traffic.json")
+    if screen_ms >= 0 and (args.binsize, args.samples, args.refsize) == (15000, 100, 300) \
+            and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        roofline["traffic"] = tj["fetch_bytes_per_step_corrected_x2"] + tj["write_bytes_per_step"]
+        roofline["traffic_source"] = "profiles/r01/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
+                                     "WRITE_SIZE; bytes per screen sweep = 15 chunk launches)"
     roofline["null_ratios_ms"] = float(np.mean(nr_ms))
     roofline["normalize_ms"] = float(np.mean(norm_ms)) if norm_ms else None
 
