@@ -9,8 +9,8 @@ predict runs as replicas: the finished reference is all-gathered once and sample
 over the ranks -- no collective on the per-sample path.
 
 torch is plumbing here (device memory, streams, collectives); the compute is injected as a
-`backend` object so the same orchestration runs on the GPU library and, in the CPU tests, on the
-oracle.
+`backend` object so the same orchestration runs on the GPU library and, in the CPU tests, on a
+CPU stand-in supplied by the test.
 """
 import numpy as np
 
