@@ -428,14 +428,27 @@ __global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
   uint2 *sl_row = sl + srow * (int64_t)CAP;
   unsigned long long n_compact = 0;
 
-  const int64_t n_groups = gi_end;
-  // groups holding only own-chromosome rows are skipped (gmask: chromosomes present per 64 rows)
+  // Visit list of this launch's chunk, built once per workgroup in LDS: groups holding only
+  // own-chromosome rows are skipped (gmask = chromosomes present per 64 rows); bit 31 marks groups
+  // that also contain own-chromosome rows.  (Reading gmask from global memory inside the loop put
+  // two dependent scalar-load latencies on every iteration: 7 ms of a 20 ms sweep.)
   const unsigned int blkbit = 1u << blk.chr;
-  auto gm = [&](int64_t g) { return gmask[(g * GR) >> 6]; };
-  auto next_group = [&](int64_t g) {
-    while (g < n_groups && gm(g) == blkbit) ++g;
-    return g;
-  };
+  int *glist = sperm + 2 * GR;                 // [gi_end - gi_begin + 1]
+  __shared__ int s_nlist;
+  if (wave == 0) {
+    int count = 0;
+    for (int64_t g0 = gi_begin; g0 < gi_end; g0 += 64) {
+      const int64_t g = g0 + lane;
+      unsigned int m = blkbit;
+      if (g < gi_end) m = gmask[(g * GR) >> 6];
+      const bool keep = (g < gi_end) && m != blkbit;
+      const unsigned long long bal = __ballot(keep);
+      if (keep) glist[count + __popcll(bal & ((1ull << lane) - 1ull))] =
+          (int)g | ((m & blkbit) ? (int)0x80000000 : 0);
+      count += __popcll(bal);
+    }
+    if (lane == 0) s_nlist = count;
+  }
   half8 pre[NPT];
   float pre_nb = 0.f;
   int pre_row = -1;
@@ -445,11 +458,14 @@ __global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
     for (int p = 0; p < NPT; ++p) pre[p] = src[p * NT + tid];
     if (tid < GR) { pre_nb = info[gix * GR + tid].nb; pre_row = perm[gix * GR + tid]; }
   };
-  int64_t gi = next_group(gi_begin);
-  if (gi < n_groups) fetch(gi);
   int buf = 0;
   __syncthreads();
-  while (gi < n_groups) {
+  const int n_list = s_nlist;
+  int cur = n_list > 0 ? glist[0] : 0;
+  if (n_list > 0) fetch(cur & 0x7fffffff);
+  bool fast = false;
+  for (int j = 0; j < n_list; ++j) {
+    const int nxt = (j + 1 < n_list) ? glist[j + 1] : 0;   // LDS read, used after the barrier
     half8 *sb = sbuf + buf * TILE_H8;
     float *nbb = snb + buf * GR;
     int *prow = sperm + buf * GR;
@@ -457,14 +473,13 @@ __global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
     for (int p = 0; p < NPT; ++p) sb[p * NT + tid] = pre[p];
     if (tid < GR) { nbb[tid] = pre_nb; prow[tid] = pre_row; }
     __syncthreads();
-    const bool mixed = (gm(gi) & blkbit) != 0;   // some own-chromosome rows in this group
-    const int64_t gn = next_group(gi + 1);
-    if (gn < n_groups && !(dbg & 8)) fetch(gn);
+    const bool mixed = cur < 0;                  // some own-chromosome rows in this group
+    if (j + 1 < n_list && !(dbg & 8)) fetch(nxt & 0x7fffffff);
 
     // Once every target of the wave has a finite threshold the test is folded into the MFMA:
     // acc starts at (G - |b~|^2)/2, so after the products acc = g~ - (|b~|^2 - G)/2 and the pair
     // passes (t = |b~|^2 - 2 g~ <= G) iff acc >= 0 -- one sign bit per output, no extra VALU.
-    const bool fast = __all(G < 1.0e37f);
+    if (!fast) fast = __all(G < 1.0e37f);        // G only ever decreases
     f32x16 acc[CTG];
     unsigned int pmask = 0;
     auto products = [&]() {
@@ -553,25 +568,25 @@ __global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
           ++pos;
         }
       }
-    }
-    // shortlist maintenance: wave-private (this wave's 32 targets)
-    {
-      const int my_cnt = cnt[tl];
-      unsigned long long need = __ballot(tvalid && my_cnt > LIM) & 0xffffffffull;
-      while (need) {
-        const int c = __ffsll((long long)need) - 1;
-        need &= need - 1;
-        const int64_t crow_s = (blk.row0 + wave * 32 + c) - row_begin;
-        const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
-                    G_c = __shfl(G, c, 64);
-        const float Gn = compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c,
-                                        E_c, Q_c, G_c, &flags[crow_s], false);
-        if ((lane & 31) == c) G = Gn;
-        ++n_compact;
+      // shortlist maintenance: wave-private (this wave's 32 targets); counts only change here
+        {
+        const int my_cnt = cnt[tl];
+        unsigned long long need = __ballot(tvalid && my_cnt > LIM) & 0xffffffffull;
+        while (need) {
+          const int c = __ffsll((long long)need) - 1;
+          need &= need - 1;
+          const int64_t crow_s = (blk.row0 + wave * 32 + c) - row_begin;
+          const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
+                      G_c = __shfl(G, c, 64);
+          const float Gn = compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c,
+                                          E_c, Q_c, G_c, &flags[crow_s], false);
+          if ((lane & 31) == c) G = Gn;
+          ++n_compact;
+        }
       }
     }
     buf ^= 1;
-    gi = gn;
+    cur = nxt;
   }
   if (last) {
     // final cut of every target's shortlist with its final threshold
@@ -727,12 +742,14 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   }
   const unsigned gprep = (unsigned)((Bpad + NT - 1) / NT);
   const int GRr = CTG * 32;
-  const size_t lds = 2 * (size_t)(CTG * NK * PL * 64) * 16 + 2 * GRr * 4 + TGT * 4 + 2 * GRr * 4;
   // candidate chunk per launch: ~3 MB of fragments (fits the 4 MB XCD L2)
   const int64_t n_iter_groups = Bpad / GRr;
   const int64_t group_bytes = (int64_t)GRr * NK * PL * 32;
   int64_t chunk_groups = (3 << 20) / group_bytes;
   if (chunk_groups < 16) chunk_groups = 16;
+  if (chunk_groups > 4096) chunk_groups = 4096;
+  const size_t lds = 2 * (size_t)(CTG * NK * PL * 64) * 16 + 2 * GRr * 4 + TGT * 4 + 2 * GRr * 4 +
+                     (size_t)(chunk_groups + 64) * 4;   // + the chunk's visit list
 #define WCX_SCREEN_CASE(N, P, G)                                                               \
   {                                                                                            \
     k_screen_prep<N, P><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);     \
