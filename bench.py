@@ -147,19 +147,15 @@ def main():
         # search + null ratios of this rank's target rows
         idx_l, dist_l, _, d_Xs = wd.newref_sharded(Xrow, B, cum, k, null_ids, backend, rank, world,
                                                    out=out_bufs)
-        # (3) predict = replicas: every rank gets the whole reference (all-gather of the finished
-        # row blocks) and normalises its own sample: cut-off + 3 masked passes
-        idx_f, dist_f = wd.gather_reference(idx_l, dist_l, B, world)
-        h = _lib.vp()
-        _lib.check(lib.wcx_ref_wrap_dev(ctx.h, idx_f.data_ptr(), dist_f.data_ptr(), B, k,
-                                        cum_p, len(cum), C.byref(h)))
-        cut = C.c_double()
-        _lib.check(lib.wcx_cutoff(ctx.h, h, 5, C.byref(cut)))
-        _lib.check(lib.wcx_predict_normalize_dev(
-            ctx.h, h, d_x.data_ptr(), 1, cut.value, 0, 0, d_z.data_ptr(), d_r.data_ptr(),
-            d_n.data_ptr(), d_med.data_ptr(), d_med.data_ptr() + 8))
+        # (3) predict one sample, ROW-SHARDED like the reference build: every rank keeps only the
+        # rows it just built; cut-off = 5 x 2 local moment sweeps + tiny all-reduces, then three
+        # masked passes over the local rows with an all-gather of the updated copy vector
+        # (B doubles) between passes, and of z / r / n / log2 r at the end.
+        h = backend.wrap_rows(idx_l, dist_l, B, k, cum, row_begin, n_rows)
+        cut = wd.cutoff_sharded(backend, h, 5, world)
+        wd.normalize_sharded(backend, h, d_x, B, 0, cut, rank, world)
         lib.wcx_sync(ctx.h)
-        lib.wcx_ref_free(ctx.h, h)
+        backend.free_ref(h)
         if record:
             topk_ms.append(ctx.kernel_ms("topk"))
             nr_ms.append(ctx.kernel_ms("null_ratios"))
@@ -240,12 +236,13 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "newref {} kb bins: B={} masked autosomal bins x S={} samples, "
                                "refsize={} (search + null ratios), + predict normalise of 1 "
-                               "sample per GPU".format(args.binsize // 1000, B, S, k),
+                               "sample".format(args.binsize // 1000, B, S, k),
                    "bins": int(B), "samples": int(S), "refsize": int(k),
                    "pairs": pairs_total, "bin_samples_per_s": B * S / (ms_per_step * 1e-3),
                    "mode": args.mode,
-                   "partition": "target rows x{} (_get_part) + all-gather(X); predict replicas "
-                                "after all-gather(reference)".format(world)},
+                   "partition": "target rows x{} (_get_part): one all-gather(X) for the search; "
+                                "predict row-sharded (all-reduce of cut-off moments, all-gather "
+                                "of B-vectors between passes)".format(world)},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -121,6 +121,28 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_
                               double *d_out_z, double *d_out_r, double *d_out_n,
                               double *d_out_mlr, double *d_out_mz);
 
+/* ---- row-sharded predict (multi-GPU) --------------------------------------
+ * A handle made by wcx_ref_wrap_rows_dev holds only rows [row0,row0+nrows) of indexes/distances
+ * (the block this rank built).  The host drives normalize_repeat (predict_tools.py:94-108)
+ * pass by pass and exchanges the masked copy between passes:
+ *   wcx_cutoff_moments_dev  phase 0: out2 = {sum, count} of local dist < cutoff;
+ *                           phase 1: out2 = {sum (dist-mean)^2, .}   -> all-reduce on the host
+ *   wcx_predict_pass_dev    one _normalize_once pass (predict_tools.py:111-142) over the local
+ *                           rows >= ct: reads the full x / copy_in vectors [B], writes z, r, n, log2 r
+ *                           at position (row - ct) and copy_out[row]; build_mask != 0 on the
+ *                           first pass (turns dist < cutoff into the per-row selection mask)
+ *   wcx_nanmedian2_dev      np.nanmedian of two arrays (m_lr, m_z; predict_tools.py:105-106) */
+int wcx_ref_wrap_rows_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, int64_t B,
+                          int k, const int64_t *chr_cum /*host*/, int n_chr, int64_t row0,
+                          int64_t nrows, wcx_ref **out);
+int wcx_cutoff_moments_dev(wcx_ctx *ctx, const wcx_ref *ref, double cutoff, double mean, int phase,
+                           double *out2 /*host*/);
+int wcx_predict_pass_dev(wcx_ctx *ctx, wcx_ref *ref, const double *d_x, const double *d_copy_in,
+                         double *d_copy_out, double cutoff, int64_t ct, int build_mask, int last,
+                         double *d_z, double *d_r, double *d_n, double *d_lr);
+int wcx_nanmedian2_dev(wcx_ctx *ctx, const double *d_a0, const double *d_a1, int64_t n,
+                       double *d_out0, double *d_out1);
+
 /* Replaces predict_tools.exec_cbs -> overall_tools.exec_R -> include/CBS.R (main.py:279,
  * predict_tools.py:242-257, CBS.R:21-132): weighted circular binary segmentation of the
  * per-chromosome log2 ratios.  r,w double[n_bins] (0 = missing), chr_off int64[n_chr+1].

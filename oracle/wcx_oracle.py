@@ -179,8 +179,9 @@ def get_weights(distances):
 
 
 def normalize_once(test_data, test_copy, masked_bins_per_chr, masked_bins_per_chr_cum,
-                   indexes, distances, optimal_cutoff, ct, cp):
-    """predict_tools.py:111-142."""
+                   indexes, distances, optimal_cutoff, ct, cp, row_range=None):
+    """predict_tools.py:111-142.  row_range=(lo,hi) restricts the work to those bins (used by
+    the row-sharded multi-GPU tests; results of other bins stay 0)."""
     n = masked_bins_per_chr_cum[-1]
     results_z = np.zeros(n)[ct:]
     results_r = np.zeros(n)[ct:]
@@ -191,6 +192,10 @@ def normalize_once(test_data, test_copy, masked_bins_per_chr, masked_bins_per_ch
         end = masked_bins_per_chr_cum[c]
         chr_data = np.concatenate((test_copy[:start], test_copy[end:]))
         for index in indexes[start:end]:
+            if row_range is not None and not (row_range[0] <= i < row_range[1]):
+                i += 1
+                i2 += 1
+                continue
             ref_data = chr_data[index[distances[i] < optimal_cutoff]]
             ref_data = ref_data[ref_data >= 0]
             with np.errstate(all="ignore"):

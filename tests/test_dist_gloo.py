@@ -26,6 +26,49 @@ class OracleBackend:
         o_nr[:n] = torch.from_numpy(nr)
 
 
+class OraclePredictBackend:
+    """CPU stand-in for the row-sharded predict primitives (numpy oracle)."""
+
+    def __init__(self, mbpc, cum):
+        self.mbpc, self.cum = mbpc, cum
+
+    def wrap_rows(self, idx, dist, B, k, chr_cum, row0, nrows):
+        return {"idx": idx.numpy(), "dist": dist.numpy(), "row0": row0, "nrows": nrows, "B": B, "k": k}
+
+    def moments(self, ref, cutoff, mean, phase):
+        d = ref["dist"]
+        sel = d[d < cutoff]
+        if phase == 0:
+            return float(sel.sum()), float(sel.size)
+        return float(((sel - mean) ** 2).sum()), 0.0
+
+    def predict_pass(self, ref, x, cin, cout, cutoff, ct, build_mask, last, zB, rB, nB, lB):
+        import torch
+        from oracle import wcx_oracle as O
+        B, k, row0, nrows = ref["B"], ref["k"], ref["row0"], ref["nrows"]
+        idx = np.zeros((B, k), dtype=np.int32)
+        dist = np.full((B, k), 1e10)
+        idx[row0:row0 + nrows] = ref["idx"]
+        dist[row0:row0 + nrows] = ref["dist"]
+        z, r, n = O.normalize_once(x.numpy(), cin.numpy().copy(), self.mbpc, self.cum, idx, dist,
+                                   cutoff, ct, int(np.searchsorted(self.cum, ct, side="right")),
+                                   row_range=(row0, row0 + nrows))
+        lo, hi = max(ct, row0), row0 + nrows
+        with np.errstate(all="ignore"):
+            zB[lo:hi] = torch.from_numpy(z[lo - ct:hi - ct])
+            rB[lo:hi] = torch.from_numpy(r[lo - ct:hi - ct])
+            nB[lo:hi] = torch.from_numpy(n[lo - ct:hi - ct])
+            lB[lo:hi] = torch.from_numpy(np.log2(r[lo - ct:hi - ct]))
+            c = cin.numpy().copy()
+            zz = z[lo - ct:hi - ct]
+            c[lo:hi][np.abs(zz) >= O.Z_MASK] = -1
+        cout[lo:hi] = torch.from_numpy(c[lo:hi])
+
+    def nanmedian2(self, a0, a1):
+        with np.errstate(all="ignore"):
+            return float(np.nanmedian(a0.numpy())), float(np.nanmedian(a1.numpy()))
+
+
 def _worker(rank, world, port, X, cum, k, ids, q):
     sys.path.insert(0, ROOT)
     import torch
@@ -42,8 +85,16 @@ def _worker(rank, world, port, X, cum, k, ids, q):
     idx, dd, nr, Xs = wd.newref_sharded(local, B, cum, k, ids, OracleBackend(), rank, world)
     assert Xs.shape == (X.shape[1], B)
     fi, fd = wd.gather_reference(idx, dd, B, world)
+    # row-sharded predict of one sample against the rows this rank just built
+    mb = np.diff(np.concatenate(([0], cum))).tolist()
+    pb = OraclePredictBackend(mb, list(cum))
+    ref = pb.wrap_rows(idx, dd, B, k, cum, b, e - b)
+    cutoff = wd.cutoff_sharded(pb, ref, 5, world)
+    xt = torch.from_numpy(np.ascontiguousarray(X[:, 0]) * (1 + 0.2 * np.sin(np.arange(B))))
+    z, r, n, mlr, mz = wd.normalize_sharded(pb, ref, xt, B, 0, cutoff, rank, world)
     q.put((rank, idx.numpy().copy(), dd.numpy().copy(), nr.numpy().copy(),
-           fi.numpy().copy(), fd.numpy().copy()))
+           fi.numpy().copy(), fd.numpy().copy(),
+           (cutoff, z.numpy().copy(), r.numpy().copy(), n.numpy().copy(), mlr, mz)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,8 +122,17 @@ def test_row_sharded_newref_two_ranks():
     assert np.array_equal(np.concatenate([r[1] for r in res]), ei)
     assert np.array_equal(np.concatenate([r[2] for r in res]), ed)
     assert np.array_equal(np.concatenate([r[3] for r in res]), enr)
+    x = np.ascontiguousarray(X[:, 0]) * (1 + 0.2 * np.sin(np.arange(X.shape[0])))
+    ecut = O.get_optimal_cutoff(ed, 5)
+    ez, er, en, emlr, emz = O.normalize_repeat(x, mbpc, cum, ei, ed, ecut, 0, 0)
     for r in res:      # every replica holds the whole reference after the gather
         assert np.array_equal(r[4], ei) and np.array_equal(r[5], ed)
+        cutoff, z, rr, n, mlr, mz = r[6]
+        np.testing.assert_allclose(cutoff, ecut, rtol=1e-12)
+        np.testing.assert_allclose(z, ez, rtol=1e-9, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(rr, er, rtol=1e-12, equal_nan=True)
+        assert np.array_equal(n, en)
+        np.testing.assert_allclose([mlr, mz], [emlr, emz], rtol=1e-9, atol=1e-12)
 
 
 def test_stripe_and_shards():

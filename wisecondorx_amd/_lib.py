@@ -49,6 +49,12 @@ SIGNATURES = {
                                         vp, vp, vp]),
     "wcx_predict_normalize_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_double, c_i64, C.c_int, vp,
                                             vp, vp, vp, vp]),
+    "wcx_ref_wrap_rows_dev": (C.c_int, [vp, vp, vp, c_i64, C.c_int, c_i64p, C.c_int, c_i64, c_i64,
+                                        C.POINTER(vp)]),
+    "wcx_cutoff_moments_dev": (C.c_int, [vp, vp, C.c_double, C.c_double, C.c_int, c_f64p]),
+    "wcx_predict_pass_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_double, c_i64, C.c_int, C.c_int, vp,
+                                       vp, vp, vp]),
+    "wcx_nanmedian2_dev": (C.c_int, [vp, vp, vp, c_i64, vp, vp]),
     "wcx_cbs": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64, vp,
                           C.c_int, C.POINTER(C.c_int)]),
     "wcx_set_null_matrix": (C.c_int, [vp, vp, c_i64, C.c_int]),
@@ -72,6 +78,15 @@ def load():
         raise WcxError(
             "{} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C wisecondorx_amd/csrc`. There is no CPU fallback.".format(LIB_PATH))
+    # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Whichever
+    # copy is loaded first serves the whole process; if ours came first, torch.cuda would later
+    # fail with "No HIP GPUs are available".  So when torch is installed, let it load its runtime
+    # first (the C-ABI itself does not depend on torch).
+    if os.environ.get("WCX_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing

@@ -64,6 +64,25 @@ __global__ __launch_bounds__(NT) void k_cut_final(double *__restrict__ state, in
   }
 }
 
+// out[0] = sum of part_sum, out[1] = sum of part_cnt  (row-sharded cut-off: the host all-reduces)
+__global__ __launch_bounds__(NT) void k_sum_parts(const double *__restrict__ part_sum,
+                                                  const double *__restrict__ part_cnt, int nparts,
+                                                  double *__restrict__ out) {
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += NT) { s += part_sum[i]; c += part_cnt[i]; }
+  __shared__ double sh_s[NT / 64], sh_c[NT / 64];
+  s = wcx::wave_sum(s);
+  c = wcx::wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { sh_s[threadIdx.x >> 6] = s; sh_c[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (int w = 0; w < NT / 64; ++w) { ts += sh_s[w]; tc += sh_c[w]; }
+    out[0] = ts;
+    out[1] = tc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // a12 get_weights (predict_tools.py:152-155): w_i = 1 / mean_k sqrt(dist[i][k]); wave per row.
 __global__ __launch_bounds__(NT) void k_weights(const double *__restrict__ dist, int64_t B, int k,
@@ -81,18 +100,22 @@ __global__ __launch_bounds__(NT) void k_weights(const double *__restrict__ dist,
 
 // ------------------------------------------------------------------------------------------
 // a13: selection mask  sel[i][q] = ballot( dist[i][q*64+lane] < cutoff )   (predict_tools.py:133)
-__global__ __launch_bounds__(NT) void k_select_mask(const double *__restrict__ dist, int64_t B,
-                                                    int k, int ipl, double cutoff, int64_t ct,
+// dist / sel hold the rows [row0, ...) of the reference (row0 = 0 unless row-sharded);
+// rows [lo, hi) are processed.
+__global__ __launch_bounds__(NT) void k_select_mask(const double *__restrict__ dist, int k, int ipl,
+                                                    double cutoff, int64_t lo, int64_t hi,
+                                                    int64_t row0,
                                                     unsigned long long *__restrict__ sel) {
   const int lane = wcx::lane_id();
   const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
-  for (int64_t i = ct + w0; i < B; i += nw) {
+  for (int64_t i = lo + w0; i < hi; i += nw) {
+    const int64_t li = i - row0;
     for (int q = 0; q < ipl; ++q) {
       const int t = q * 64 + lane;
-      const bool s = (t < k) && (dist[i * (int64_t)k + t] < cutoff);
+      const bool s = (t < k) && (dist[li * (int64_t)k + t] < cutoff);
       const unsigned long long m = __ballot(s);
-      if (lane == 0) sel[i * ipl + q] = m;
+      if (lane == 0) sel[li * ipl + q] = m;
     }
   }
 }
@@ -108,9 +131,10 @@ template <int IPL>
 __global__ __launch_bounds__(NT) void k_normalize_pass(
     const double *__restrict__ x, const double *__restrict__ copy_in,
     double *__restrict__ copy_out, const int32_t *__restrict__ idx,
-    const unsigned long long *__restrict__ sel, int64_t B, int k, int64_t ct, ChrTable chr,
-    double *__restrict__ out_z, double *__restrict__ out_r, double *__restrict__ out_n,
-    double *__restrict__ out_lr, int last_pass) {
+    const unsigned long long *__restrict__ sel, int64_t B, int k, int64_t ct, int64_t lo,
+    int64_t hi, int64_t row0, ChrTable chr, double *__restrict__ out_z,
+    double *__restrict__ out_r, double *__restrict__ out_n, double *__restrict__ out_lr,
+    int last_pass) {
   const int lane = wcx::lane_id();
   __shared__ int s_hist[NT / 64][64];
   __shared__ double s_slots[NT / 64][64];
@@ -121,7 +145,8 @@ __global__ __launch_bounds__(NT) void k_normalize_pass(
   const int64_t Bp = B - ct;
   const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
-  for (int64_t i = ct + w0; i < B; i += nw) {
+  for (int64_t i = lo + w0; i < hi; i += nw) {
+    const int64_t li = i - row0;   // row of idx / sel (the reference may hold a row shard)
     // own chromosome [cs,ce) of row i
     int64_t cs = 0, ce = chr.cum[0];
     for (int c = 1; c < chr.n_chr && i >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
@@ -134,11 +159,11 @@ __global__ __launch_bounds__(NT) void k_normalize_pass(
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
       const int t = q * 64 + lane;
-      const bool selq = (t < k) && ((sel[i * IPL + q] >> lane) & 1ull);
+      const bool selq = (t < k) && ((sel[li * IPL + q] >> lane) & 1ull);
       double val = HUGE_VAL;
       bool keep = false;
       if (selq) {
-        int64_t c = idx[i * (int64_t)k + t];
+        int64_t c = idx[li * (int64_t)k + t];
         if (c < 0) c += len_cd;                       // NumPy negative index
         const int64_t g = c < cs ? c : c + own;       // chr_data index -> row
         const double cv = cin[g];
@@ -262,6 +287,8 @@ int wcx_ref_wrap_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, i
   r->owned = false;
   r->B = B;
   r->k = k;
+  r->row0 = 0;
+  r->nrows = B;
   r->chr_cum.assign(chr_cum, chr_cum + n_chr);
   *out = r;
   return WCX_OK;
@@ -291,6 +318,7 @@ int wcx_ref_upload(wcx_ctx *ctx, const int32_t *idx, const double *dist, int64_t
 int wcx_ref_free(wcx_ctx *ctx, wcx_ref *ref) {
   if (!ref) return WCX_OK;
   if (ctx) hipStreamSynchronize(ctx->stream);
+  if (ref->d_sel) hipFree(ref->d_sel);
   if (ref->owned) {
     hipFree(const_cast<int32_t *>(ref->d_idx));
     hipFree(const_cast<double *>(ref->d_dist));
@@ -303,7 +331,7 @@ int wcx_cutoff(wcx_ctx *ctx, const wcx_ref *ref, int repeats, double *cutoff) {
   WCX_ARG(ctx && ref && cutoff, "NULL argument");
   WCX_ARG(repeats >= 0, "repeats must be >= 0");
   WCX_HIP(hipSetDevice(ctx->device));
-  const int64_t n = ref->B * (int64_t)ref->k;
+  const int64_t n = ref->nrows * (int64_t)ref->k;
   const int nparts = 2048;
   void *scr = nullptr;
   int rc = wcx_scratch(ctx, (size_t)(2 * nparts + 8) * 8, &scr);
@@ -333,91 +361,209 @@ int wcx_weights(wcx_ctx *ctx, const wcx_ref *ref, double *out) {
   WCX_ARG(ctx && ref && out, "NULL argument");
   WCX_HIP(hipSetDevice(ctx->device));
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, (size_t)ref->B * 8, &scr);
+  int rc = wcx_scratch(ctx, (size_t)ref->nrows * 8 + 8, &scr);
   if (rc) return rc;
   rc = wcx_timer_begin(ctx, "weights");
   if (rc) return rc;
-  const unsigned grid = (unsigned)((ref->B + 3) / 4 < 8192 ? (ref->B + 3) / 4 : 8192);
-  k_weights<<<grid, NT, 0, ctx->stream>>>(ref->d_dist, ref->B, ref->k, (double *)scr);
+  const unsigned grid = (unsigned)((ref->nrows + 3) / 4 < 8192 ? (ref->nrows + 3) / 4 + 1 : 8192);
+  k_weights<<<grid, NT, 0, ctx->stream>>>(ref->d_dist, ref->nrows, ref->k, (double *)scr);
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "weights");
   if (rc) return rc;
-  WCX_HIP(hipMemcpyAsync(out, scr, (size_t)ref->B * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (ref->nrows)
+    WCX_HIP(hipMemcpyAsync(out, scr, (size_t)ref->nrows * 8, hipMemcpyDeviceToHost, ctx->stream));
   WCX_HIP(hipStreamSynchronize(ctx->stream));
   return WCX_OK;
 }
 
-int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_x, int n_samples,
+}  // extern "C"
+
+namespace {
+
+int ipl_for(int k) {
+  int ipl = (k + 63) / 64;                 // values per lane
+  if (ipl > 8) ipl = ipl <= 16 ? 16 : 32;
+  return ipl;
+}
+
+// selection mask of the reference's rows (kept in the handle: it outlives the scratch buffers)
+int ensure_sel(wcx_ctx *ctx, wcx_ref *ref, int ipl) {
+  const size_t need = (size_t)ref->nrows * ipl * 8;
+  if (ref->d_sel && ref->sel_bytes >= need) return WCX_OK;
+  if (ref->d_sel) { WCX_HIP(hipStreamSynchronize(ctx->stream)); WCX_HIP(hipFree(ref->d_sel)); ref->d_sel = nullptr; }
+  if (hipMalloc(reinterpret_cast<void **>(&ref->d_sel), need ? need : 8) != hipSuccess) {
+    wcx_set_error("hipMalloc(%zu) for the selection mask failed", need);
+    return WCX_ERR_NOMEM;
+  }
+  ref->sel_bytes = need;
+  return WCX_OK;
+}
+
+// One pass over the reference's rows intersected with [ct, B).
+int launch_pass(wcx_ctx *ctx, const wcx_ref *ref, const double *d_x, const double *cin, double *cout,
+                int n_samples, int64_t ct, bool last, double *d_z, double *d_r, double *d_n,
+                double *d_lr) {
+  const int64_t B = ref->B;
+  const int k = ref->k;
+  const int ipl = ipl_for(k);
+  const int64_t lo = ct > ref->row0 ? ct : ref->row0, hi = ref->row0 + ref->nrows;
+  if (lo >= hi) return WCX_OK;
+  ChrTable tab;
+  tab.n_chr = (int)ref->chr_cum.size();
+  for (int c = 0; c < 32; ++c) tab.cum[c] = c < tab.n_chr ? ref->chr_cum[c] : B;
+  const int64_t nl = hi - lo;
+  dim3 grid((unsigned)((nl + 3) / 4 < 16384 ? (nl + 3) / 4 : 16384), (unsigned)n_samples);
+#define WCX_NORM_LAUNCH(IPL)                                                                  \
+  k_normalize_pass<IPL><<<grid, NT, 0, ctx->stream>>>(d_x, cin, cout, ref->d_idx, ref->d_sel, B, k, \
+                                                      ct, lo, hi, ref->row0, tab, d_z, d_r, d_n,    \
+                                                      d_lr, last ? 1 : 0)
+  switch (ipl) {
+    case 1: WCX_NORM_LAUNCH(1); break;
+    case 2: WCX_NORM_LAUNCH(2); break;
+    case 3: WCX_NORM_LAUNCH(3); break;
+    case 4: WCX_NORM_LAUNCH(4); break;
+    case 5: WCX_NORM_LAUNCH(5); break;
+    case 6: WCX_NORM_LAUNCH(6); break;
+    case 7: WCX_NORM_LAUNCH(7); break;
+    case 8: WCX_NORM_LAUNCH(8); break;
+    case 16: WCX_NORM_LAUNCH(16); break;
+    default: WCX_NORM_LAUNCH(32); break;
+  }
+#undef WCX_NORM_LAUNCH
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
+int launch_select_mask(wcx_ctx *ctx, wcx_ref *ref, double cutoff, int64_t ct) {
+  const int ipl = ipl_for(ref->k);
+  int rc = ensure_sel(ctx, ref, ipl);
+  if (rc) return rc;
+  const int64_t lo = ct > ref->row0 ? ct : ref->row0, hi = ref->row0 + ref->nrows;
+  if (lo >= hi) return WCX_OK;
+  const int64_t nl = hi - lo;
+  const unsigned gsel = (unsigned)((nl + 3) / 4 < 16384 ? (nl + 3) / 4 : 16384);
+  k_select_mask<<<gsel, NT, 0, ctx->stream>>>(ref->d_dist, ref->k, ipl, cutoff, lo, hi, ref->row0,
+                                              ref->d_sel);
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *d_x, int n_samples,
                               double cutoff, int64_t ct, int cp, double *d_out_z,
                               double *d_out_r, double *d_out_n, double *d_out_mlr,
                               double *d_out_mz) {
+  wcx_ref *ref = const_cast<wcx_ref *>(ref_c);
   WCX_ARG(ctx && ref && d_x && d_out_z && d_out_r && d_out_n && d_out_mlr && d_out_mz,
           "NULL argument");
   WCX_ARG(n_samples > 0, "n_samples must be positive");
+  WCX_ARG(ref->row0 == 0 && ref->nrows == ref->B, "needs a handle holding all rows");
   const int64_t B = ref->B;
-  const int k = ref->k;
   const int n_chr = (int)ref->chr_cum.size();
   WCX_ARG(cp >= 0 && cp < n_chr, "cp out of range");
   WCX_ARG(ct == (cp ? ref->chr_cum[cp - 1] : 0), "ct must be the first row of chromosome cp");
   WCX_HIP(hipSetDevice(ctx->device));
-  if (k > 64 * 32) {
-    wcx_set_error("refsize %d too large for the normalise kernel (max 2048)", k);
+  if (ref->k > 64 * 32) {
+    wcx_set_error("refsize %d too large for the normalise kernel (max 2048)", ref->k);
     return WCX_ERR_UNSUPPORTED;
   }
-  int ipl = (k + 63) / 64;                 // values per lane
-  if (ipl > 8) ipl = ipl <= 16 ? 16 : 32;
   const int64_t Bp = B - ct;
   if (Bp <= 0) return WCX_OK;
-
-  // scratch: sel[B][ipl] u64 | copyA[n][B] | copyB[n][B] | lr[n][Bp]
-  const size_t sel_b = (size_t)B * ipl * 8;
+  // scratch: copyA[n][B] | copyB[n][B] | lr[n][Bp]
   const size_t cp_b = (size_t)n_samples * B * 8;
   const size_t lr_b = (size_t)n_samples * Bp * 8;
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, sel_b + 2 * cp_b + lr_b, &scr);
+  int rc = wcx_scratch(ctx, 2 * cp_b + lr_b, &scr);
   if (rc) return rc;
-  unsigned long long *sel = reinterpret_cast<unsigned long long *>(scr);
-  double *cA = reinterpret_cast<double *>(reinterpret_cast<char *>(scr) + sel_b);
+  double *cA = reinterpret_cast<double *>(scr);
   double *cB = cA + (size_t)n_samples * B;
   double *lr = cB + (size_t)n_samples * B;
-
-  ChrTable tab;
-  tab.n_chr = n_chr;
-  for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? ref->chr_cum[c] : B;
-
   rc = wcx_timer_begin(ctx, "normalize");
   if (rc) return rc;
   const int64_t ntot = (int64_t)n_samples * B;
   k_copy2<<<(unsigned)((ntot + 255) / 256), 256, 0, ctx->stream>>>(d_x, cA, cB, ntot);
-  const unsigned gsel = (unsigned)((Bp + 3) / 4 < 16384 ? (Bp + 3) / 4 : 16384);
-  k_select_mask<<<gsel, NT, 0, ctx->stream>>>(ref->d_dist, B, k, ipl, cutoff, ct, sel);
-  dim3 grid((unsigned)((Bp + 3) / 4 < 16384 ? (Bp + 3) / 4 : 16384), (unsigned)n_samples);
+  rc = launch_select_mask(ctx, ref, cutoff, ct);
+  if (rc) return rc;
   for (int pass = 0; pass < 3; ++pass) {  // predict_tools.py:99
-    const double *cin = (pass & 1) ? cB : cA;
-    double *cout = (pass & 1) ? cA : cB;
-    const int last = pass == 2;
-#define WCX_NORM_LAUNCH(IPL)                                                                   \
-  k_normalize_pass<IPL><<<grid, NT, 0, ctx->stream>>>(d_x, cin, cout, ref->d_idx, sel, B, k, ct, \
-                                                      tab, d_out_z, d_out_r, d_out_n, lr, last)
-    switch (ipl) {
-      case 1: WCX_NORM_LAUNCH(1); break;
-      case 2: WCX_NORM_LAUNCH(2); break;
-      case 3: WCX_NORM_LAUNCH(3); break;
-      case 4: WCX_NORM_LAUNCH(4); break;
-      case 5: WCX_NORM_LAUNCH(5); break;
-      case 6: WCX_NORM_LAUNCH(6); break;
-      case 7: WCX_NORM_LAUNCH(7); break;
-      case 8: WCX_NORM_LAUNCH(8); break;
-      case 16: WCX_NORM_LAUNCH(16); break;
-      default: WCX_NORM_LAUNCH(32); break;
-    }
-#undef WCX_NORM_LAUNCH
+    rc = launch_pass(ctx, ref, d_x, (pass & 1) ? cB : cA, (pass & 1) ? cA : cB, n_samples, ct,
+                     pass == 2, d_out_z, d_out_r, d_out_n, lr);
+    if (rc) return rc;
   }
   // m_lr = nanmedian(log2 r), m_z = nanmedian(z)   (predict_tools.py:105-106)
   k_nanmedian<<<dim3((unsigned)n_samples, 2), NTM, 0, ctx->stream>>>(lr, d_out_z, Bp, Bp, d_out_mlr,
                                                                       d_out_mz);
   WCX_HIP(hipGetLastError());
   return wcx_timer_end(ctx, "normalize");
+}
+
+// ---- row-sharded predict (multi-GPU): the handle holds rows [row0, row0+nrows) of the reference
+int wcx_ref_wrap_rows_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, int64_t B, int k,
+                          const int64_t *chr_cum, int n_chr, int64_t row0, int64_t nrows,
+                          wcx_ref **out) {
+  WCX_ARG(row0 >= 0 && nrows >= 0 && row0 + nrows <= B, "bad row range");
+  int rc = wcx_ref_wrap_dev(ctx, d_idx, d_dist, B, k, chr_cum, n_chr, out);
+  if (rc) return rc;
+  (*out)->row0 = row0;
+  (*out)->nrows = nrows;
+  return WCX_OK;
+}
+
+int wcx_cutoff_moments_dev(wcx_ctx *ctx, const wcx_ref *ref, double cutoff, double mean, int phase,
+                           double *out2) {
+  WCX_ARG(ctx && ref && out2 && (phase == 0 || phase == 1), "bad argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  const int64_t n = ref->nrows * (int64_t)ref->k;
+  const int nparts = 2048;
+  void *scr = nullptr;
+  int rc = wcx_scratch(ctx, (size_t)(2 * nparts + 16) * 8, &scr);
+  if (rc) return rc;
+  double *state = reinterpret_cast<double *>(scr);
+  double *ps = state + 16, *pc = ps + nparts;
+  const double init[3] = {cutoff, mean, 0.0};
+  rc = wcx_upload_small(ctx, state, init, sizeof(init));
+  if (rc) return rc;
+  if (n > 0) k_cut_partial<<<nparts, NT, 0, ctx->stream>>>(ref->d_dist, n, state, phase, ps, pc);
+  else WCX_HIP(hipMemsetAsync(ps, 0, (size_t)2 * nparts * 8, ctx->stream));
+  k_sum_parts<<<1, NT, 0, ctx->stream>>>(ps, pc, nparts, state + 8);
+  WCX_HIP(hipGetLastError());
+  WCX_HIP(hipMemcpyAsync(out2, state + 8, 16, hipMemcpyDeviceToHost, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+int wcx_predict_pass_dev(wcx_ctx *ctx, wcx_ref *ref, const double *d_x, const double *d_copy_in,
+                         double *d_copy_out, double cutoff, int64_t ct, int build_mask, int last,
+                         double *d_z, double *d_r, double *d_n, double *d_lr) {
+  WCX_ARG(ctx && ref && d_x && d_copy_in && d_copy_out && d_z && d_r && d_n && d_lr, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  if (ref->k > 64 * 32) {
+    wcx_set_error("refsize %d too large for the normalise kernel (max 2048)", ref->k);
+    return WCX_ERR_UNSUPPORTED;
+  }
+  int rc = WCX_OK;
+  if (build_mask) {
+    rc = wcx_timer_begin(ctx, "normalize");
+    if (rc) return rc;
+    rc = launch_select_mask(ctx, ref, cutoff, ct);
+    if (rc) return rc;
+  }
+  WCX_ARG(ref->d_sel != nullptr || ref->nrows == 0, "first pass must build the selection mask");
+  rc = launch_pass(ctx, ref, d_x, d_copy_in, d_copy_out, 1, ct, last != 0, d_z, d_r, d_n, d_lr);
+  if (rc) return rc;
+  if (last) rc = wcx_timer_end(ctx, "normalize");
+  return rc;
+}
+
+int wcx_nanmedian2_dev(wcx_ctx *ctx, const double *d_a0, const double *d_a1, int64_t n,
+                       double *d_out0, double *d_out1) {
+  WCX_ARG(ctx && d_a0 && d_a1 && d_out0 && d_out1 && n >= 0, "bad argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  k_nanmedian<<<dim3(1, 2), NTM, 0, ctx->stream>>>(d_a0, d_a1, n, n, d_out0, d_out1);
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
 }
 
 int wcx_predict_normalize(wcx_ctx *ctx, const wcx_ref *ref, const double *x, int n_samples,

@@ -62,6 +62,9 @@ struct wcx_ref {
   bool owned = false;
   int64_t B = 0;
   int k = 0;
+  int64_t row0 = 0, nrows = 0;          // rows held by d_idx / d_dist (all B unless row-sharded)
+  unsigned long long *d_sel = nullptr;   // selection mask of those rows (dist < cutoff)
+  size_t sel_bytes = 0;
   std::vector<int64_t> chr_cum;
   int64_t *d_chr_cum = nullptr;
 };

@@ -44,8 +44,52 @@ def allgather_rows(local_rows, n_rows, world, group=None):
     return torch.cat(parts, 0)
 
 
-class GpuBackend:
-    """Compute on this rank's MI355X through the C-ABI (device pointers, caller's stream)."""
+class _GpuPredictMixin:
+    """Row-sharded predict primitives on the GPU (device pointers)."""
+
+    def wrap_rows(self, d_idx, d_dist, B, k, chr_cum, row0, nrows):
+        from . import _lib
+        cum, cum_p = _lib.i64_array(chr_cum)
+        h = _lib.vp()
+        _lib.check(self.ctx.lib.wcx_ref_wrap_rows_dev(self.ctx.h, d_idx.data_ptr(), d_dist.data_ptr(),
+                                                      B, k, cum_p, len(cum), row0, nrows,
+                                                      _lib.C.byref(h)))
+        return h
+
+    def free_ref(self, h):
+        self.ctx.lib.wcx_ref_free(self.ctx.h, h)
+
+    def moments(self, ref, cutoff, mean, phase):
+        from . import _lib
+        out = (_lib.C.c_double * 2)()
+        _lib.check(self.ctx.lib.wcx_cutoff_moments_dev(self.ctx.h, ref, float(cutoff), float(mean),
+                                                       int(phase), out))
+        return out[0], out[1]
+
+    def predict_pass(self, ref, x, cin, cout, cutoff, ct, build_mask, last, zB, rB, nB, lB):
+        from . import _lib
+        off = 8 * int(ct)      # outputs are written at (row - ct): shift so that they land at [row]
+        _lib.check(self.ctx.lib.wcx_predict_pass_dev(
+            self.ctx.h, ref, x.data_ptr(), cin.data_ptr(), cout.data_ptr(), float(cutoff), int(ct),
+            int(build_mask), int(last), zB.data_ptr() + off, rB.data_ptr() + off,
+            nB.data_ptr() + off, lB.data_ptr() + off))
+
+    def nanmedian2(self, a0, a1):
+        import torch
+        from . import _lib
+        out = torch.empty(2, dtype=torch.float64, device=a0.device)
+        _lib.check(self.ctx.lib.wcx_nanmedian2_dev(self.ctx.h, a0.data_ptr(), a1.data_ptr(),
+                                                   a0.numel(), out.data_ptr(), out.data_ptr() + 8))
+        self.ctx.sync()
+        o = out.cpu()
+        return float(o[0]), float(o[1])
+
+
+class GpuBackend(_GpuPredictMixin):
+    """Compute on this rank's MI355X through the C-ABI (device pointers).  The orchestration in this
+    module interleaves torch ops (clones, all-gathers) with library calls on the same buffers, so
+    the context MUST have been created on torch's current stream:
+        _lib.Context(device, torch.cuda.current_stream().cuda_stream)"""
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -99,6 +143,62 @@ def gather_reference(idx_local, dist_local, n_rows, world):
         return p
     return (allgather_rows(padded(idx_local), n_rows, world),
             allgather_rows(padded(dist_local), n_rows, world))
+
+
+def _allreduce2(a, b, world):
+    if world == 1:
+        return a, b
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([a, b], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t)
+    return float(t[0]), float(t[1])
+
+
+def cutoff_sharded(backend, ref, repeats, world):
+    """get_optimal_cutoff (predict_tools.py:74-82) over row-sharded distances: per repeat two
+    local moment sweeps + two tiny all-reduces."""
+    cutoff = float("inf")
+    for _ in range(repeats):
+        s, c = _allreduce2(*backend.moments(ref, cutoff, 0.0, 0), world)
+        mean = s / c
+        ss, _ = _allreduce2(*backend.moments(ref, cutoff, mean, 1), world)
+        cutoff = mean + 3.0 * (ss / c) ** 0.5
+    return cutoff
+
+
+def normalize_sharded(backend, ref, x, n_rows, ct, cutoff, rank, world):
+    """normalize_repeat (predict_tools.py:94-108) of ONE sample with the reference rows sharded:
+    each rank runs the three masked passes on its own rows; between passes the updated slices
+    of test_copy are exchanged (all-gather of B doubles), at the end z / r / n / log2 r likewise.
+    x: torch [B] float64 on the compute device.  Returns (z, r, n, m_lr, m_z) with z, r, n of
+    length B - ct (full, identical on every rank)."""
+    import torch
+    B = n_rows
+    b, e = row_shard(rank, world, B)
+    pad = max_shard_rows(world, B)
+    cin = x.clone()
+    cout = x.clone()
+    zB = torch.zeros(B, dtype=torch.float64, device=x.device)
+    rB, nB, lB = torch.zeros_like(zB), torch.zeros_like(zB), torch.zeros_like(zB)
+
+    def exchange(v):
+        if world == 1:
+            return v
+        loc = torch.zeros(pad, dtype=v.dtype, device=v.device)
+        loc[:e - b] = v[b:e]
+        return allgather_rows(loc, B, world)
+
+    for p in range(3):
+        backend.predict_pass(ref, x, cin, cout, cutoff, ct, p == 0, p == 2, zB, rB, nB, lB)
+        if p < 2:
+            full = exchange(cout)
+            cin, cout = full, full.clone()
+    zB, rB, nB, lB = exchange(zB), exchange(rB), exchange(nB), exchange(lB)
+    m_lr, m_z = backend.nanmedian2(lB[ct:].contiguous(), zB[ct:].contiguous())
+    return zB[ct:], rB[ct:], nB[ct:], m_lr, m_z
 
 
 def stripe(items, rank, world):
