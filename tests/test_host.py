@@ -71,3 +71,77 @@ def test_npz_roundtrip(tmp_path):
     assert set(back.files) == set(ref)
     assert back["indexes"].dtype == np.int32 and int(back["binsize"]) == 100000
     assert not back["is_nipt"] and float(back["trained_cutoff"]) == 0.004
+
+
+def test_convert_filters_match_reference_loop(monkeypatch):
+    """convert (pysam absent here): the vectorised duplicate / MAPQ / proper-pair filters against
+    a straight per-read loop with the reference's branching (convert_tools.py:75-104), on fake
+    read columns including the carry-over of the previous read across contigs."""
+    import types
+    from wisecondorx_amd import convert_tools as ct
+    rng = np.random.default_rng(0)
+
+    class Read:
+        def __init__(self, pos, mate, mq, paired, proper):
+            self.pos, self.next_reference_start, self.mapping_quality = pos, mate, mq
+            self.is_paired, self.is_proper_pair = paired, proper
+
+    class FakeBam:
+        references = ["chr1", "chrM", "2", "chrX"]
+        lengths = [5000, 100, 3000, 2000]
+        mapped, unmapped, nocoordinate = 1, 2, 3
+
+        def __init__(self):
+            self.reads = {}
+            for c, L in zip(self.references, self.lengths):
+                pos = np.sort(rng.integers(0, L, 400))
+                pos[rng.random(400) < 0.3] = 0
+                pos = np.sort(pos)
+                self.reads[c] = [Read(int(p), int(rng.integers(0, 4)), int(rng.integers(0, 3)),
+                                      bool(rng.random() < 0.6), bool(rng.random() < 0.8)) for p in pos]
+
+        def fetch(self, c):
+            return iter(self.reads[c])
+
+    def loop(f, binsize, normdup):
+        out, larp, larp2, dup, mq, pf, seen = {}, -1, -1, 0, 0, 0, 0
+        for i, c in enumerate(f.references):
+            name = c[3:] if c[:3].lower() == "chr" else c
+            if name not in [str(x) for x in range(1, 25)] + ["X", "Y"]:
+                continue
+            counts = np.zeros(int(f.lengths[i] / float(binsize) + 1), dtype=np.int32)
+            for r in f.fetch(c):
+                if r.is_paired:
+                    if not r.is_proper_pair:
+                        pf += 1
+                        continue
+                    if not normdup and larp == r.pos and larp2 == r.next_reference_start:
+                        dup += 1
+                    elif r.mapping_quality >= 1:
+                        counts[int(r.pos / binsize)] += 1
+                    else:
+                        mq += 1
+                    larp2 = r.next_reference_start
+                else:
+                    if not normdup and larp == r.pos:
+                        dup += 1
+                    elif r.mapping_quality >= 1:
+                        counts[int(r.pos / binsize)] += 1
+                    else:
+                        mq += 1
+                seen += 1
+                larp = r.pos
+            out[{"X": "23", "Y": "24"}.get(name, name)] = counts
+        return out, (dup, mq, pf, seen)
+
+    f = FakeBam()
+    monkeypatch.setattr(ct, "_open", lambda a: f)
+    for normdup in (False, True):
+        args = types.SimpleNamespace(infile="x.bam", reference=None, binsize=100.0, normdup=normdup)
+        bins, q = ct.convert_reads(args)
+        exp, (dup, mq, pf, seen) = loop(f, 100.0, normdup)
+        assert bins["3"] is None and set(k for k, v in bins.items() if v is not None) == set(exp)
+        for k in exp:
+            assert bins[k].dtype == np.int32 and np.array_equal(bins[k], exp[k])
+        assert (q["filter_rmdup"], q["filter_mapq"], q["pair_fail"], q["pre_retro"]) == (dup, mq, pf, seen)
+        assert q["post_retro"] == sum(int(v.sum()) for v in exp.values())

@@ -79,7 +79,6 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y,
                                                   float *__restrict__ out) {
   extern __shared__ unsigned int sk[];  // npad words: keys, then the permuted weighted series
   __shared__ float red[NTP / 64];
-  __shared__ float bc[2];
   const int tid = threadIdx.x;
   const int p = perm0 + blockIdx.x;
   const unsigned long long s0 = mix64(seed ^ ((unsigned long long)p * 0xd1342543de82ef95ull));
@@ -190,7 +189,6 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y,
     for (int w = 0; w < NTP / 64; ++w) b = red[w] > b ? red[w] : b;
     out[blockIdx.x] = b / ((tss - b) / (float)(n - 2));
   }
-  (void)bc;
 }
 
 // nu(x) series for a grid of x values: one workgroup per x, threads over the terms
@@ -219,24 +217,6 @@ __global__ __launch_bounds__(256) void k_nu_series(const double *__restrict__ xs
 
 // ------------------------------------------------------------------ host-side statistics
 double fpnorm(double x) { return 0.5 * erfc(-x / M_SQRT2); }
-
-double nu_fn(double x, double tol) {   // Siegmund's nu(x) = (2/x^2) exp(-2 sum Phi(-x sqrt(k)/2)/k)
-  double lnu1;
-  if (x > 0.01) {
-    lnu1 = log(2.0) - 2.0 * log(x);
-    double lnu0 = lnu1, dk = 0.0;
-    int k = 2;
-    for (int i = 0; i < k; ++i) { dk += 1.0; lnu1 -= 2.0 * fpnorm(-x * sqrt(dk) / 2.0) / dk; }
-    while (fabs((lnu1 - lnu0) / lnu1) > tol) {
-      lnu0 = lnu1;
-      for (int i = 0; i < k; ++i) { dk += 1.0; lnu1 -= 2.0 * fpnorm(-x * sqrt(dk) / 2.0) / dk; }
-      k *= 2;
-    }
-  } else {
-    lnu1 = -0.583 * x;
-  }
-  return exp(lnu1);
-}
 
 double it1tsq(double x, double a) {   // integral of 1/(t(1-t))^2 over [x, x+a]
   double y = x + a - 0.5;

@@ -126,8 +126,10 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   else if (ipl <= 5) WCX_NR_LAUNCH(5);
   else if (ipl <= 6) WCX_NR_LAUNCH(6);
   else if (ipl <= 8) WCX_NR_LAUNCH(8);
+  else if (ipl <= 16) WCX_NR_LAUNCH(16);
+  else if (ipl <= 32) WCX_NR_LAUNCH(32);
   else {
-    wcx_set_error("refsize %d too large for the null-ratio kernel (max 512)", k);
+    wcx_set_error("refsize %d too large for the null-ratio kernel (max 2048)", k);
     return WCX_ERR_UNSUPPORTED;
   }
 #undef WCX_NR_LAUNCH
