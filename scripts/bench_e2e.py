@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""End-to-end wall-clock of the CLI at BASELINE.json's problem size: synthetic sample .npz files ->
+`newref` (load, gender model, masks, PCA, A/F/M searches + null ratios, reference .npz written) ->
+`predict` of one sample (load reference, normalise A + gonosomes, post-process, CBS, segment z,
+_bins/_segments/_aberrations/_statistics tables).  This is the literal "newref+predict
+wall-clock @15kb bins" of BASELINE.json; bench.py times the device-resident hot path only.
+Prints one JSON line with the phase breakdown."""
+import argparse
+import json
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class Phases:
+    def __init__(self):
+        self.t = {}
+
+    def wrap(self, module, name, key):
+        fn = getattr(module, name)
+
+        def timed(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                self.t[key] = self.t.get(key, 0.0) + time.perf_counter() - t0
+        setattr(module, name, timed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--binsize", type=int, default=15000)
+    ap.add_argument("--samples", type=int, default=100)
+    ap.add_argument("--refsize", type=int, default=300)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workdir", default="/tmp/wcx_e2e")
+    a = ap.parse_args()
+
+    from wisecondorx_amd import main as cli, newref_tools, npz_io, predict_tools, prep, synth
+    from wisecondorx_amd import predict_output
+
+    shutil.rmtree(a.workdir, ignore_errors=True)
+    os.makedirs(a.workdir)
+    t0 = time.perf_counter()
+    co = synth.Cohort(a.binsize, female_y=0.1)
+    samples, genders = co.cohort(a.samples)
+    files = []
+    for i, s in enumerate(samples):
+        f = os.path.join(a.workdir, "s{:03d}.npz".format(i))
+        npz_io.save_sample(f, s, a.binsize)
+        files.append(f)
+    test_file = os.path.join(a.workdir, "test.npz")
+    npz_io.save_sample(test_file, co.sample(9001, "F", cnv=[(3, 500, 500 + int(3e7 / a.binsize), 1.5)]),
+                       a.binsize)
+    t_synth = time.perf_counter() - t0
+
+    ph = Phases()
+    ph.wrap(npz_io, "load_sample", "load_samples")
+    ph.wrap(prep, "get_mask", "masks")
+    ph.wrap(prep, "prepare", "prep_pca")
+    ph.wrap(newref_tools, "get_reference_parts", "gpu_search_nullratios")
+    ph.wrap(npz_io, "save_npz", "write_reference")
+    ph.wrap(cli, "train_gender_model", "gender_model")
+
+    ref_file = os.path.join(a.workdir, "ref.npz")
+    import random
+    random.seed(1)
+    t0 = time.perf_counter()
+    cli.main(["--loglevel", "warning", "newref"] + files +
+             [ref_file, "--binsize", str(a.binsize), "--refsize", str(a.refsize), "--yfrac", "0.004",
+              "--gpus", str(a.gpus)])
+    t_newref = time.perf_counter() - t0
+    newref_phases = dict(ph.t)
+
+    ph.t = {}
+    ph.wrap(npz_io, "load_reference", "load_reference")
+    ph.wrap(predict_tools, "normalize", "normalize")
+    ph.wrap(predict_tools, "exec_cbs", "cbs_and_segment_z")
+    ph.wrap(predict_tools, "get_post_processed_result", "post_process")
+    ph.wrap(predict_tools, "attach_null_matrix", "null_matrix_upload")
+    ph.wrap(predict_output, "generate_output_tables", "tables")
+    outid = os.path.join(a.workdir, "out")
+    t0 = time.perf_counter()
+    cli.main(["--loglevel", "warning", "predict", test_file, ref_file, outid, "--bed",
+                    "--seed", "1"])
+    t_predict = time.perf_counter() - t0
+    seg = sum(1 for _ in open(outid + "_segments.bed")) - 1
+    ab = sum(1 for _ in open(outid + "_aberrations.bed")) - 1
+    out = {
+        "workload": "CLI newref ({} samples, {} bp bins, refsize {}) + predict of 1 sample".format(
+            a.samples, a.binsize, a.refsize),
+        "n_gpus": a.gpus, "newref_s": t_newref, "predict_s": t_predict,
+        "newref_plus_predict_s": t_newref + t_predict,
+        "newref_phases_s": newref_phases, "predict_phases_s": dict(ph.t),
+        "synth_and_write_samples_s": t_synth,
+        "reference_npz_bytes": os.path.getsize(ref_file), "segments": seg, "aberrations": ab,
+    }
+    print(json.dumps(out))
+    shutil.rmtree(a.workdir, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

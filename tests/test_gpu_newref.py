@@ -164,3 +164,17 @@ def test_screen_real_valued_outlier_scale(nt):
     X[[3, 1000, 2500]] *= 100.0
     X[[7, 1200]] = 1.0               # zero-norm rows after centring
     _check_vs_c(nt, X, cum, 100, 0, cum[-1], 2)
+
+
+@pytest.mark.parametrize("k", [700, 1500])
+def test_large_refsize(nt, k):
+    """refsize beyond the MFMA screen's 512: all-fp64 search + the 16/32-entries-per-lane median."""
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([900, 700, 500, 300], 20, seed=k)
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, cum[-1])
+    oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, 0, cum[-1], k)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+    ids = list(range(20))
+    np.testing.assert_allclose(nt.get_null_ratios(X, idx, 0, cum[-1], ids),
+                               O.null_ratios(X, idx, 0, cum[-1], ids), rtol=1e-12, atol=1e-13)
