@@ -187,14 +187,11 @@ def main():
     screen_ms = ctx.kernel_ms("topk_screen")
     if screen_ms >= 0:
         # MFMA screen: algorithmic work = the -2 X^T X Gram GEMM, 2*S flop per candidate pair
-        # (SURVEY.md §8d).  The kernel executes 3 fp16 MFMA products (hi.hi+hi.lo+lo.hi) over
-        # K padded to a multiple of 16, reported as executed_tflops.
-        nk = (S + 15) // 16                       # same padding rule as wcx_topk_screen_launch
-        if args.debug_flags & 32 and S <= 128:
-            kpad, nprod, form = nk * 16, 3, "fp16 hi/lo x3"
-        else:
-            nk = (nk + 1) // 2 * 2 if nk <= 8 else (16 if nk <= 16 else 24 if nk <= 24 else 32)
-            kpad, nprod, form = nk * 16, 1, "fp16 hi plane"
+        # (SURVEY.md §8d).  The kernel executes one fp16 product over K = 16*NK >= S + 4 (four
+        # augmented columns carry the norm and the threshold), reported as executed_tflops.
+        nk_list = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32]
+        nk = next(v for v in nk_list if 16 * v >= S + 4)   # same rule as wcx_topk_screen_launch
+        kpad, nprod, form = nk * 16, 1, "fp16 hi plane"
         flops = 2.0 * S * stats["pairs"]
         achieved = flops / (screen_ms * 1e-3) / 1e12
         roofline = {"kernel": "k_screen (v_mfma_f32_32x32x16_f16, {}, fp32 acc) + fused top-k "
@@ -205,7 +202,8 @@ def main():
                     "executed_tflops": nprod * 2.0 * kpad * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
                     "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
                     "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
-                    "fallback_rows": stats["fallback_rows"], "compactions": stats["compactions"]}
+                    "fallback_rows": stats["fallback_rows"], "compactions": stats["compactions"], "appends": stats["appends"],
+                    "phase_cycles": stats["phase_cycles"], "compact_cycles": stats["compact_cycles"]}
     else:
         flops = 3.0 * S * stats["pairs"]         # exact path: sub, mul, add per (pair, sample)
         achieved = flops / (k_ms * 1e-3) / 1e12

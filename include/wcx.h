@@ -60,8 +60,10 @@ int wcx_memcpy_d2h(wcx_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
  * "weights", "cbs", "segment_z"); synchronises the stream.  <0 if never launched. */
 double wcx_last_kernel_ms(wcx_ctx *ctx, const char *name);
 /* Counters of the last wcx_newref_topk*: [0] rows searched, [1] candidate pairs evaluated,
- * [2] shortlist compactions, [3] rows that fell back to the exact brute-force path. */
-int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[4]);
+ * [2] shortlist compactions, [3] rows that fell back to the exact brute-force path,
+ * [4] pairs that passed the MFMA screen (shortlist appends), [5..7] reserved (0),
+ * [8..13] per-phase wave cycles of the screen kernel (only with wcx_debug_flags(4)), [14..15] 0. */
+int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[16]);
 
 /* ---- newref: reference-bin search ------------------------------------------------- */
 /* Replaces newref_tools.get_ref_for_bins (newref_tools.py:255-278) as driven by

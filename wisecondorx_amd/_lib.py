@@ -149,9 +149,11 @@ class Context:
         return float(self.lib.wcx_last_kernel_ms(self.h, name.encode()))
 
     def topk_stats(self):
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 16)()
         check(self.lib.wcx_last_topk_stats(self.h, out))
-        return {"rows": out[0], "pairs": out[1], "compactions": out[2], "fallback_rows": out[3]}
+        return {"rows": out[0], "pairs": out[1], "compactions": out[2], "fallback_rows": out[3],
+                "appends": out[4], "phase_cycles": [out[8 + i] for i in range(6)],
+                "compact_cycles": [out[5], out[6], out[7], out[14]]}
 
 
 _default_ctx = {}

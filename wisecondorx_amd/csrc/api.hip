@@ -110,8 +110,8 @@ int wcx_ctx_create(int device, void *stream, wcx_ctx **out) {
     WCX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
   }
-  WCX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 64));
-  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
+  WCX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 128));
+  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, ctx->stream));
   *out = ctx;
   return WCX_OK;
 }
@@ -183,15 +183,16 @@ double wcx_last_kernel_ms(wcx_ctx *ctx, const char *name) {
   return (double)ms;
 }
 
-int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[4]) {
+int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[16]) {
   WCX_ARG(ctx && out, "NULL argument");
-  unsigned long long h[4] = {0, 0, 0, 0};
-  WCX_HIP(hipMemcpyAsync(h, ctx->d_stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long h[16] = {0};
+  WCX_HIP(hipMemcpyAsync(h, ctx->d_stats, 128, hipMemcpyDeviceToHost, ctx->stream));
   WCX_HIP(hipStreamSynchronize(ctx->stream));
   out[0] = ctx->topk_stats[0];
   out[1] = ctx->topk_stats[1];
   out[2] = (int64_t)h[2];
   out[3] = (int64_t)h[3];
+  for (int i = 4; i < 16; ++i) out[i] = (int64_t)h[i];
   return WCX_OK;
 }
 

@@ -61,7 +61,8 @@ constexpr int RPITCH = RCH + 2;         // LDS row pitch in doubles (144 B)
 template <int IPL>
 __device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S, int Sp,
                                            int64_t row, int64_t cs, int64_t own,
-                                           const uint2 *__restrict__ sl_row, int n, int k,
+                                           const uint2 *__restrict__ sl_row,
+                                           const int *__restrict__ perm, int n, int k,
                                            int32_t *__restrict__ oi, double *__restrict__ od,
                                            double *__restrict__ tile, double *__restrict__ xt_s,
                                            int *__restrict__ g_s) {
@@ -79,9 +80,8 @@ __device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S,
     const int e = q * 64 + lane;
     int g = (int)row;                                        // padding lanes read the target row
     if (e < n) {
-      const int ci = (int)sl_row[e].y;
-      ix[q] = ci;
-      g = ci < cs ? ci : ci + (int)own;
+      g = perm[sl_row[e].y];                                // shortlists hold sweep positions
+      ix[q] = g < cs ? g : g - (int)own;                     // own-chromosome-excluded index
     }
     g_s[lane] = g;
     __builtin_amdgcn_wave_barrier();
@@ -145,7 +145,8 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
                                                const unsigned char *__restrict__ searched,
                                                const uint2 *__restrict__ sl,
                                                const int *__restrict__ cnt_out,
-                                               const unsigned int *__restrict__ flags, int k,
+                                               const unsigned int *__restrict__ flags,
+                                               const int *__restrict__ perm, int k,
                                                int32_t *__restrict__ out_idx,
                                                double *__restrict__ out_dist,
                                                ScreenGlobals *__restrict__ glob) {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
     const int64_t row = row_begin + r;
     int64_t cs = 0, ce = chr.cum[0];
     for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
-    refine_row<8>(Xr, S, Sp, row, cs, ce - cs, sl + r * (int64_t)CAP, n, k,
+    refine_row<8>(Xr, S, Sp, row, cs, ce - cs, sl + r * (int64_t)CAP, perm, n, k,
                   out_idx + r * (int64_t)k, out_dist + r * (int64_t)k, tile, xt_s, g_s);
   }
 }
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr
                                                    const unsigned char *__restrict__ searched,
                                                    const uint2 *__restrict__ sl,
                                                    const int *__restrict__ cnt_out,
-                                                   const unsigned int *__restrict__ flags, int k,
+                                                   const unsigned int *__restrict__ flags,
+                                                   const int *__restrict__ perm, int k,
                                                    int32_t *__restrict__ out_idx,
                                                    double *__restrict__ out_dist) {
   __shared__ double sd[CAP];
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr
       double acc = HUGE_VAL;
       int ci = 0x7fffffff;
       if (e < n) {
-        ci = (int)sl_row[e].y;
-        const int64_t g = ci < cs ? (int64_t)ci : (int64_t)ci + own;
+        const int64_t g = perm[sl_row[e].y];
+        ci = (int)(g < cs ? g : g - own);
         const double *xc = Xr + g * (int64_t)Sp;
         acc = 0.0;
         for (int j = 0; j < S; ++j) {
@@ -241,17 +243,18 @@ __global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr
 
 int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTab &tab,
                       int64_t row_begin, int64_t n_rows, const unsigned char *searched,
-                      const uint2 *sl, const int *cnt_out, const unsigned int *flags, int k,
-                      int32_t *d_out_idx, double *d_out_dist, ScreenGlobals *glob) {
+                      const uint2 *sl, const int *cnt_out, const unsigned int *flags,
+                      const int *perm, int k, int32_t *d_out_idx, double *d_out_dist,
+                      ScreenGlobals *glob) {
   const unsigned gref = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
   const size_t rlds = (NT / 64) * ((size_t)(64 * RPITCH + Sp) * 8 + 64 * 4);
   WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_refine),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
   k_refine<<<gref, NT, rlds, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out,
-                                         flags, k, d_out_idx, d_out_dist, glob);
+                                         flags, perm, k, d_out_idx, d_out_dist, glob);
   const unsigned gbig = (unsigned)(n_rows < 2048 ? n_rows : 2048);
   k_refine_big<<<gbig, NT, 0, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl,
-                                             cnt_out, flags, k, d_out_idx, d_out_dist);
+                                             cnt_out, flags, perm, k, d_out_idx, d_out_dist);
   WCX_HIP(hipGetLastError());
   return WCX_OK;
 }

@@ -200,69 +200,101 @@ __global__ __launch_bounds__(NT) void k_group_mask(const int *__restrict__ perm,
   gmask[g] = m;
 }
 
-template <int NK, int PL>
+// Two fp16 values h1 + h2 bracketing x from below (up = false) or above (up = true), with
+// sum = h1 + h2 EXACT in fp32 and no fp16 subnormals (quantum >= 2^-14; the matrix pipe may
+// flush them).  |x| <= 65000.  Error |x - sum| < max(2^-21 |x|, 2^-14).
+__device__ __forceinline__ void split16(float x, bool up, _Float16 &h1, _Float16 &h2, float &sum) {
+  h1 = (_Float16)x;                       // round to nearest
+  const float f1 = (float)h1;
+  const float r = x - f1;                 // exact (Sterbenz)
+  int eb = (int)((__float_as_uint(f1) >> 23) & 0xffu) - 21;
+  if (eb < 113) eb = 113;
+  const float q = __uint_as_float((unsigned int)eb << 23);
+  const float m = up ? ceilf(r / q) : floorf(r / q);   // |m| <= 1024
+  const float f2 = m * q;
+  h2 = (_Float16)f2;                      // exact
+  sum = f1 + f2;                          // exact: a multiple of q below 2^(e+1)
+}
+
+constexpr float AUG = 32768.f;            // the constant factor of the augmented products
+constexpr float GMAX = 4.0e9f;            // thresholds at or above this count as "none yet"
+constexpr float SLOW_OFF = 3.75e9f;       // slow-path pass offset: real rows pass, padding fails
+
+// One thread per sweep POSITION p (the row it holds is perm[p], -1 = padding): fp16 image of the
+// centred, scaled row in MFMA-fragment order + the augmented columns.
+//
+// Augmented columns (the last four of the padded K = 16 NK; requires S <= K - 4): a candidate row
+// carries (-u1, -u2, AUG, AUG) with 65536 (u1 + u2) = nb' <= |b~|^2, a target row carries
+// (AUG, AUG, w1, w2) with 65536 (w1 + w2) = G' >= G (patched in registers by k_screen), so the
+// matrix product itself delivers  acc = g~ - nb'/2 + G'/2  and the screen test  nb' - 2 g~ <= G'
+// is the sign bit of acc: no per-output VALU work besides collecting that bit.
+template <int NK>
 __global__ __launch_bounds__(NT) void k_screen_prep(
     const double *__restrict__ Xr, int64_t Bpad, int S, int Sp,
     const double *__restrict__ cmean, const int *__restrict__ perm,
     ScreenGlobals *__restrict__ glob, half8 *__restrict__ F, RowInfo *__restrict__ info) {
-  // one thread per sweep POSITION p; the row it holds is perm[p] (-1 = padding)
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
   if (b >= Bpad) return;
   const int64_t row = perm[b];
-  // scale 2^p so that the largest |a| lands in [8192, 16384)  (fp16 max 65504)
+  // scale 2^p so that the largest |a| lands in [1024, 2048): |a~|^2 <= 508 * 2^22 < 2^31.1 keeps
+  // nb/65536 and any threshold/65536 inside the fp16 range
   const double amax = __longlong_as_double((long long)glob->amax_bits);
   int ex = 0;
   double scale = 1.0;
   if (amax > 0.0) {
     frexp(amax, &ex);            // amax = m 2^ex, m in [0.5,1)
-    scale = ldexp(1.0, 14 - ex);
+    scale = ldexp(1.0, 11 - ex);
   }
   const int64_t tile = b >> 5;
   const int rl = (int)(b & 31);
-  double n2 = 0.0, e2 = 0.0, l2 = 0.0;
   bool bad = false;
+  if (row >= 0)
+    for (int j = 0; j < S; ++j) bad |= !(fabs(Xr[row * Sp + j]) < HUGE_VAL);
+  const bool zero = row < 0 || bad;          // padding / NaN-inf rows: all-zero image
+  double n2 = 0.0, e2 = 0.0;
+#pragma unroll 1
   for (int ks = 0; ks < NK; ++ks) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      half8 hi, lo;
+      half8 hi;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int j = ks * 16 + h * 8 + e;
         double a = 0.0;
-        if (row >= 0 && j < S) a = (Xr[row * Sp + j] - cmean[j]) * scale;
-        const _Float16 hh = (_Float16)a;
-        const double r1 = a - (double)hh;
-        const _Float16 ll = PL == 2 ? (_Float16)r1 : (_Float16)0;
-        const double res = r1 - (double)ll;
-        const double at = (double)hh + (double)ll;
-        n2 += at * at;
+        if (!zero && j < S) a = (Xr[row * Sp + j] - cmean[j]) * scale;
+        _Float16 hh = (_Float16)a;
+        if (fabs((double)hh) < 6.103515625e-05) hh = (_Float16)0;   // no fp16 subnormals
+        const double res = a - (double)hh;
+        n2 += (double)hh * (double)hh;
         e2 += res * res;
-        l2 += (double)ll * (double)ll;
-        bad |= !(fabs(a) < HUGE_VAL);
         hi[e] = hh;
-        lo[e] = ll;
       }
-      const int64_t base = ((tile * NK + ks) * PL) * 64 + rl + 32 * h;
-      F[base] = hi;
-      if (PL == 2) F[base + 64] = lo;
+      if (ks < NK - 1 || h == 0) F[(tile * NK + ks) * 64 + rl + 32 * h] = hi;
+      else {
+        // last half fragment: entries 4..7 are the augmented columns (filled below)
+        float nbf = (float)n2;
+        if ((double)nbf > n2) nbf = __uint_as_float(__float_as_uint(nbf) - 1u);
+        _Float16 u1, u2;
+        float usum;
+        split16(nbf * (1.f / 65536.f), false, u1, u2, usum);
+        if (zero) { u1 = (_Float16)65504.f; u2 = (_Float16)65504.f; usum = 131008.f; }
+        hi[4] = -u1; hi[5] = -u2; hi[6] = (_Float16)AUG; hi[7] = (_Float16)AUG;
+        F[(tile * NK + ks) * 64 + rl + 32 * h] = hi;
+        RowInfo ri;
+        ri.nb = usum * 65536.f;               // nb' exactly as the matrix pipe sees it
+        ri.L = 0.f;
+        if (zero) { ri.e = 0.f; ri.N = 0.f; }
+        else {
+          // representation error also covers the fp64 rounding of (x - c) * scale
+          ri.e = up((float)(sqrt(e2) + 1e-15 * sqrt(n2)));
+          ri.N = up((float)sqrt(n2));
+          atomicMax(&glob->e_max, __float_as_uint(ri.e));
+          atomicMax(&glob->N_max, __float_as_uint(ri.N));
+        }
+        info[b] = ri;
+      }
     }
   }
-  RowInfo ri;
-  if (row < 0) {           // padding position: +inf norm -> every screen test fails
-    ri.nb = HUGE_VALF; ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
-  } else if (bad) {        // NaN/inf row: as in the reference it is never admitted / finds nothing
-    ri.nb = HUGE_VALF; ri.e = 0.f; ri.L = 0.f; ri.N = 0.f;
-  } else {
-    ri.nb = (float)n2;
-    // representation error also covers the fp64 rounding of (x - c) * scale
-    ri.e = up((float)(sqrt(e2) + 1e-15 * sqrt(n2)));
-    ri.L = up((float)sqrt(l2));
-    ri.N = up((float)sqrt(n2));
-    atomicMax(&glob->e_max, __float_as_uint(ri.e));
-    atomicMax(&glob->L_max, __float_as_uint(ri.L));
-    atomicMax(&glob->N_max, __float_as_uint(ri.N));
-  }
-  info[b] = ri;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -273,23 +305,39 @@ struct ScreenBlock {
   int64_t cs, ce;
 };
 
-// Wave-level shortlist compaction of target `c` (0..31) of this wave.
-// Returns the new threshold G (t-space) for that target; updates cnt in LDS.
+// Wave-level shortlist compaction of one target of this wave.  Shortlist entries are
+// (float bits of t, sweep position).  Returns the new threshold G (t-space); updates cnt in LDS.
 __device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl_row, int *cnt_p, int k,
                                                 float na, float E, float Q, float G_old,
-                                                unsigned int *overflow_flag, bool exact) {
+                                                unsigned int *overflow_flag, bool exact,
+                                                unsigned long long *prof = nullptr) {
   const int lane = wcx::lane_id();
+  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  if (prof) c0 = __builtin_amdgcn_s_memtime();
   // the entries were stored by (other lanes of) this wave: make them visible before re-reading
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (prof) c1 = __builtin_amdgcn_s_memtime();
   const int n = *cnt_p;
+  // all CAP slots exist in memory: load unconditionally (16 independent loads in flight; a
+  // load under `if (e < n)` made the compiler wait for each one in turn -- 16 serial round trips
+  // to HBM, ~40k cycles per compaction) and mask afterwards
   unsigned int key[CAP / 64], idx[CAP / 64];
+  uint2 raw[CAP / 64];
+#pragma unroll
+  for (int q = 0; q < CAP / 64; ++q) raw[q] = sl_row[q * 64 + lane];
 #pragma unroll
   for (int q = 0; q < CAP / 64; ++q) {
-    const int e = q * 64 + lane;
-    uint2 v = make_uint2(0xffffffffu, 0u);
-    if (e < n) v = sl_row[e];
-    key[q] = v.x;
-    idx[q] = v.y;
+    const bool in = q * 64 + lane < n;
+    key[q] = in ? f32_key(__uint_as_float(raw[q].x)) : 0xffffffffu;
+    idx[q] = in ? raw[q].y : 0u;
+  }
+  if (prof) {
+    // (forces the loads to have landed)
+    unsigned int x = 0;
+#pragma unroll
+    for (int q = 0; q < CAP / 64; ++q) x ^= key[q];
+    if (__ballot(x == 0x12345678u) == ~0ull) c2 = 1;
+    c2 += __builtin_amdgcn_s_memtime();
   }
   float G = G_old;
   if (n >= k) {
@@ -304,32 +352,17 @@ __device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl
         if (c < k) prefix = trial;
       }
     } else {
-      // Cheap upper bound of the k-th smallest key: bisect a 64-entry strided sample to 16-bit
-      // resolution at a rank a little above k/n, then VERIFY by an exact count (any value with
-      // >= k keys at or below it is a valid bound); raise the sample rank until it holds.
-      unsigned int smp = key[0];
-#pragma unroll
-      for (int q = 1; q < CAP / 64; ++q)
-        if ((lane & (CAP / 64 - 1)) == q) smp = key[q];
-      const bool smp_ok = ((lane & (CAP / 64 - 1)) * 64 + lane) < n;
-      if (!smp_ok) smp = 0xffffffffu;
-      int rs = (64 * k + n - 1) / n;
-      rs += (rs >> 2) + 3;
-      for (;;) {
-        if (rs > 64) rs = 64;
-        unsigned int p = 0;
-        for (int bit = 31; bit >= 16; --bit) {
-          const unsigned int trial = p | (1u << bit);
-          if (__popcll(__ballot(smp < trial)) < rs) p = trial;
-        }
-        p |= 0xffffu;
-        if (rs >= 64) p = 0xfffffffeu;   // everything valid
+      // In-sweep cut: the k-th smallest key to 20 bits (2^-11 relative, the resolution of the fp16
+      // screen itself), low bits rounded up -- a valid upper bound.  A tight threshold matters more
+      // than the ~300 extra ballots: every later candidate passes with probability ~ rank/n.
+      for (int bit = 31; bit >= 12; --bit) {
+        const unsigned int trial = prefix | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] <= p));
-        if (c >= k) { prefix = p; break; }
-        rs += 8;
+        for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] < trial));
+        if (c < k) prefix = trial;
       }
+      prefix |= 0xfffu;
     }
     const float tk = key_f32(prefix);
     // T-space -> distance space -> filter bound F -> back to t-space, rounded outwards
@@ -340,6 +373,7 @@ __device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl
     const float Gn = (Fb - na) + 4e-7f * (Fb + na);
     if (tk < HUGE_VALF && Gn < G_old) G = Gn;   // (NaN / inf bound: keep the old threshold)
   }
+  if (prof) c3 = __builtin_amdgcn_s_memtime();
   // keep entries with t <= G
   const unsigned int gkey = f32_key(G);
   int base = 0;
@@ -348,7 +382,7 @@ __device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl
     const bool keep = (q * 64 + lane < n) && (key[q] <= gkey);
     const unsigned long long m = __ballot(keep);
     const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (keep) sl_row[pos] = make_uint2(key[q], idx[q]);
+    if (keep) sl_row[pos] = make_uint2(__float_as_uint(key_f32(key[q])), idx[q]);
     base += __popcll(m);
   }
   if (base > LIM) {   // cannot make room: hand the row to the exact kernel
@@ -356,16 +390,35 @@ __device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl
     return -HUGE_VALF;
   }
   if (lane == 0) *cnt_p = base;
+  if (prof && lane == 0) {
+    const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&prof[0], c1 - c0);   // fence
+    atomicAdd(&prof[1], c2 - c1);   // shortlist loads
+    atomicAdd(&prof[2], c3 - c2);   // selection
+    atomicAdd(&prof[9], c4 - c3);   // write-back (stats[14])
+  }
   return G;
 }
 
-// NK = k-steps of 16 (K padded), PL = fp16 planes (2: hi+lo, three products; 1: hi only, one
-// product -- larger shortlists, used when the targets' hi+lo fragments would not fit the
-// register file), CTG = candidate sub-tiles of 32 rows per main-loop iteration.
-template <int NK, int PL, int CTG>
-__global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
+// Threshold -> the two fp16 values of the target's augmented columns and the value G' they encode.
+__device__ __forceinline__ void encode_threshold(float G, _Float16 &w1, _Float16 &w2, float &Gp) {
+  if (G < -GMAX) {            // nothing may pass (unused target lane, overflowed row)
+    w1 = (_Float16)-65504.f; w2 = (_Float16)-65504.f; Gp = -131008.f * 65536.f;
+  } else if (G < GMAX) {
+    float s;
+    split16(G * (1.f / 65536.f), true, w1, w2, s);
+    Gp = s * 65536.f;
+  } else {                    // no threshold yet: columns off, the slow path passes every real row
+    w1 = (_Float16)0; w2 = (_Float16)0; Gp = 0.f;
+  }
+}
+
+// NK = k-steps of 16 (K = 16 NK >= S + 4), CTG = candidate sub-tiles of 32 rows per iteration.
+// PROF = per-phase s_memtime accounting into stats[8..13] (diagnostics, debug flag 4).
+template <int NK, int CTG, bool PROF = false>
+__global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
     const half8 *__restrict__ F, const RowInfo *__restrict__ info,
-    const ScreenGlobals *__restrict__ glob, int64_t B, int64_t Bpad,
+    const ScreenGlobals *__restrict__ glob,
     const int *__restrict__ perm, const int *__restrict__ rowpos,
     const unsigned int *__restrict__ gmask,
     const ScreenBlock *__restrict__ blocks, int k, int64_t row_begin,
@@ -377,64 +430,32 @@ __global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
   // come out of the XCD L2s instead of HBM/MALL.  Per-target state (threshold G, shortlist
   // count) lives in g_state/cnt_out between launches; the shortlists are in HBM anyway.
   constexpr int GR = CTG * 32;                      // candidate rows per iteration
-  constexpr int TILE_H8 = CTG * NK * PL * 64;       // half8 elements per staged candidate group
-  constexpr int NPT = TILE_H8 / NT;                 // 16-byte pieces per thread
-  static_assert(TILE_H8 % NT == 0, "staging must divide evenly over the workgroup");
+  constexpr int TILE_H8 = CTG * NK * 64;            // half8 elements per staged candidate group
+  constexpr int NPT = (TILE_H8 + NT - 1) / NT;      // 16-byte pieces per thread
   constexpr int NOUT = CTG * 16;                    // screen outputs per lane per iteration
   extern __shared__ __align__(16) unsigned char smem[];
   half8 *sbuf = reinterpret_cast<half8 *>(smem);                       // [2][TILE_H8]
-  float *snb = reinterpret_cast<float *>(smem + 2 * TILE_H8 * 16);     // [2][GR]
-  int *cnt = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16 + 2 * GR * 4);  // [TGT]
-  int *sperm = cnt + TGT;                                              // [2][GR] rows of the group
+  int *cnt = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16);         // [TGT]
+  int *glist = cnt + TGT;                                              // [groups of the chunk]
+  __shared__ int s_nlist;
 
   const ScreenBlock blk = blocks[blockIdx.x];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tl = wave * 32 + (lane & 31);        // local target of this lane
   const int hf = lane >> 5;
-  const int64_t own = blk.ce - blk.cs;
   const bool tvalid = tl < blk.nrows;
   const int64_t trow = tvalid ? blk.row0 + tl : blk.row0;
   const int64_t srow = trow - row_begin;
+  const int64_t wg_srow = blk.row0 - row_begin;
+  uint2 *wg_sl = sl + wg_srow * (int64_t)CAP;    // this workgroup's TGT shortlists (uniform base)
 
-  if (tid < TGT) cnt[tid] = (first || tid >= blk.nrows) ? 0 : cnt_out[blk.row0 + tid - row_begin];
-
-  // target operand (B operand of the MFMA) stays in registers for the whole sweep
-  half8 th[NK], tlo[PL == 2 ? NK : 1];
-  {
-    const int64_t tpos = rowpos[trow];        // sweep position of the target row
-    const int64_t ttile = tpos >> 5;
-    const int trl = (int)(tpos & 31);
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      const int64_t base = ((ttile * NK + ks) * PL) * 64 + trl + 32 * hf;
-      th[ks] = F[base];
-      if (PL == 2) tlo[ks] = F[base + 64];
-    }
-  }
-  const RowInfo ti = info[rowpos[trow]];
-  const float e_max = __uint_as_float(glob->e_max), L_max = __uint_as_float(glob->L_max),
-              N_max = __uint_as_float(glob->N_max);
-  const float na = ti.nb;
-  const float E = up(ti.e + e_max);
-  const float gamma = (float)((PL == 2 ? 3 : 1) * 16 * NK + 8) * 1.1920929e-7f;   // n * 2^-23
-  // Q also covers the threshold folded into the accumulator (see the main loop) and the
-  // reconstruction t = G - 2 acc:  2.2 gamma (N_a + N_max)^2
-  const float nsum = ti.N + N_max;
-  const float Q = up(2.f * ti.L * L_max + 2.f * gamma * ti.N * N_max +
-                     4.8e-7f * (ti.N * ti.N + N_max * N_max) + 2.2f * gamma * nsum * nsum);
-  constexpr float G_INIT = 3.0e38f;   // "no threshold yet" (finite on purpose)
-  float G = tvalid ? (first ? G_INIT : g_state[srow]) : -HUGE_VALF;
-  uint2 *sl_row = sl + srow * (int64_t)CAP;
-  unsigned long long n_compact = 0;
+  if (tid < TGT) cnt[tid] = (first || tid >= blk.nrows) ? 0 : cnt_out[wg_srow + tid];
 
   // Visit list of this launch's chunk, built once per workgroup in LDS: groups holding only
   // own-chromosome rows are skipped (gmask = chromosomes present per 64 rows); bit 31 marks groups
-  // that also contain own-chromosome rows.  (Reading gmask from global memory inside the loop put
-  // two dependent scalar-load latencies on every iteration: 7 ms of a 20 ms sweep.)
+  // that also contain own-chromosome rows.
   const unsigned int blkbit = 1u << blk.chr;
-  int *glist = sperm + 2 * GR;                 // [gi_end - gi_begin + 1]
-  __shared__ int s_nlist;
   if (wave == 0) {
     int count = 0;
     for (int64_t g0 = gi_begin; g0 < gi_end; g0 += 64) {
@@ -449,150 +470,212 @@ __global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
     }
     if (lane == 0) s_nlist = count;
   }
-  half8 pre[NPT];
-  float pre_nb = 0.f;
-  int pre_row = -1;
-  auto fetch = [&](int64_t gix) {
-    const half8 *src = F + gix * (int64_t)TILE_H8;
+
+  // target operand (B operand of the MFMA) stays in registers for the whole sweep
+  const RowInfo ti = info[rowpos[trow]];
+  half8 th[NK];
+  {
+    const int64_t tpos = rowpos[trow];        // sweep position of the target row
+    const int64_t ttile = tpos >> 5;
+    const int trl = (int)(tpos & 31);
 #pragma unroll
-    for (int p = 0; p < NPT; ++p) pre[p] = src[p * NT + tid];
-    if (tid < GR) { pre_nb = info[gix * GR + tid].nb; pre_row = perm[gix * GR + tid]; }
+    for (int ks = 0; ks < NK; ++ks) th[ks] = F[(ttile * NK + ks) * 64 + trl + 32 * hf];
+  }
+  const float e_max = __uint_as_float(glob->e_max), N_max = __uint_as_float(glob->N_max);
+  const float na = ti.nb;
+  const float E = up(ti.e + e_max);
+  const float gamma = (float)(16 * NK + 8) * 1.1920929e-7f;   // n * 2^-23
+  // |computed t - exact hi-plane t| <= Q: fp32 accumulation of the 16 NK products (data columns
+  // + the nb'/2 and G'/2 columns: sum |x y| <= N_a N_max + (N_a + N_max)^2), the rounding of
+  // t = G' - 2 acc, and nb - nb' < 2^-21 nb + 4.
+  const float nsum = ti.N + N_max;
+  const float Q = up(2.f * gamma * ti.N * N_max + 4.8e-7f * (ti.N * ti.N + 2.f * N_max * N_max) +
+                     2.2f * gamma * nsum * nsum + 4.f);
+  constexpr float G_INIT = 3.0e38f;   // "no threshold yet" (finite on purpose)
+  float G = tvalid ? (first ? G_INIT : g_state[srow]) : -HUGE_VALF;
+  float Gp;
+  {
+    _Float16 w1, w2;
+    encode_threshold(G, w1, w2, Gp);
+    if (hf) { th[NK - 1][4] = (_Float16)AUG; th[NK - 1][5] = (_Float16)AUG;
+              th[NK - 1][6] = w1; th[NK - 1][7] = w2; }
+  }
+  int n_compact = 0, n_app = 0;
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0;
+  auto stamp = [&](int ph) {
+    if (PROF) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      pt[ph] += now - tp;
+      tp = now;
+    }
+  };
+
+  half8 pre[NPT];
+  auto fetch = [&](int gix) {
+    const half8 *src = F + (int64_t)gix * TILE_H8;
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+      if ((p + 1) * NT <= TILE_H8 || p * NT + tid < TILE_H8) pre[p] = src[p * NT + tid];
   };
   int buf = 0;
   __syncthreads();
   const int n_list = s_nlist;
   int cur = n_list > 0 ? glist[0] : 0;
-  if (n_list > 0) fetch(cur & 0x7fffffff);
+  if (n_list > 0) {
+    fetch(cur & 0x7fffffff);
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+      if ((p + 1) * NT <= TILE_H8 || p * NT + tid < TILE_H8) sbuf[p * NT + tid] = pre[p];
+  }
+  int cntr = cnt[tl];                          // shortlist count of my target, kept in a register
+  __syncthreads();
   bool fast = false;
   for (int j = 0; j < n_list; ++j) {
-    const int nxt = (j + 1 < n_list) ? glist[j + 1] : 0;   // LDS read, used after the barrier
+    // Order inside an iteration: issue the next group's global loads, run the MFMA block on the
+    // current LDS buffer, park the loaded group in the other buffer, barrier, THEN do the
+    // shortlist appends.  The appends' stores share the vmcnt counter with the loads; in this order
+    // nobody waits for a store until a whole MFMA block later.
+    const int nxt = (j + 1 < n_list) ? glist[j + 1] : 0;
     half8 *sb = sbuf + buf * TILE_H8;
-    float *nbb = snb + buf * GR;
-    int *prow = sperm + buf * GR;
-#pragma unroll
-    for (int p = 0; p < NPT; ++p) sb[p * NT + tid] = pre[p];
-    if (tid < GR) { nbb[tid] = pre_nb; prow[tid] = pre_row; }
-    __syncthreads();
+    const int gix = cur & 0x7fffffff;
     const bool mixed = cur < 0;                  // some own-chromosome rows in this group
-    if (j + 1 < n_list && !(dbg & 8)) fetch(nxt & 0x7fffffff);
+    if (PROF) tp = __builtin_amdgcn_s_memtime();
+    if (j + 1 < n_list) fetch(nxt & 0x7fffffff);
 
-    // Once every target of the wave has a finite threshold the test is folded into the MFMA:
-    // acc starts at (G - |b~|^2)/2, so after the products acc = g~ - (|b~|^2 - G)/2 and the pair
-    // passes (t = |b~|^2 - 2 g~ <= G) iff acc >= 0 -- one sign bit per output, no extra VALU.
-    if (!fast) fast = __all(G < 1.0e37f);        // G only ever decreases
+    // acc = g~ - nb'/2 + G'/2 straight out of the matrix pipe (see k_screen_prep); A fragments
+    // are read lane-linearly (conflict-free ds_read_b128), a few reads ahead of their MFMA.
     f32x16 acc[CTG];
-    unsigned int pmask = 0;
-    auto products = [&]() {
-      if (!(dbg & 2))
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) {
-        half8 ch[CTG], cl[PL == 2 ? CTG : 1];
+    for (int sub = 0; sub < CTG; ++sub)
 #pragma unroll
-        for (int sub = 0; sub < CTG; ++sub) {
-          ch[sub] = sb[((sub * NK + ks) * PL + 0) * 64 + lane];
-          if (PL == 2) cl[sub] = sb[((sub * NK + ks) * PL + 1) * 64 + lane];
-        }
+      for (int r = 0; r < 16; ++r) acc[sub][r] = 0.f;
+    {
+      half8 a[NK][CTG];
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int sub = 0; sub < CTG; ++sub) a[ks][sub] = sb[(sub * NK + ks) * 64 + lane];
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
         for (int sub = 0; sub < CTG; ++sub)
-          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[sub], th[ks], acc[sub], 0, 0, 0);
-        if (PL == 2) {
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][sub], th[ks], acc[sub], 0, 0, 0);
+      // schedule: PRE reads up front, then one read per MFMA, the last PRE MFMAs back to back
+      constexpr int NM = NK * CTG, PRE = NM < 6 ? NM : 6;
+      __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
 #pragma unroll
-          for (int sub = 0; sub < CTG; ++sub)
-            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[sub], tlo[ks], acc[sub], 0, 0, 0);
-#pragma unroll
-          for (int sub = 0; sub < CTG; ++sub)
-            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[sub], th[ks], acc[sub], 0, 0, 0);
-        }
+      for (int i = 0; i < NM - PRE; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-    };
+      __builtin_amdgcn_sched_group_barrier(0x008, PRE, 0);
+    }
+    stamp(0);                                    // loads issued + MFMA block issued
+    if (j + 1 < n_list) {
+      half8 *so = sbuf + (buf ^ 1) * TILE_H8;
+#pragma unroll
+      for (int p = 0; p < NPT; ++p)
+        if ((p + 1) * NT <= TILE_H8 || p * NT + tid < TILE_H8) so[p * NT + tid] = pre[p];
+    }
+    stamp(1);                                    // wait for the loads + LDS writes
+    __syncthreads();
+    stamp(2);                                    // barrier
     // C[row = candidate][col = target]; output rr = sub*16 + r is candidate row
     // loc(rr) = sub*32 + 8*(r>>2) + 4*(lane>>5) + (r&3) of this group.  Bit (31-rr) of pmask.
+    if (!fast) fast = __all(G < GMAX);           // G only ever decreases
+    unsigned int negs[CTG];                      // one dependent chain per sub-tile
     if (fast) {
-      const float halfG = 0.5f * G;
 #pragma unroll
-      for (int sub = 0; sub < CTG; ++sub)
+      for (int sub = 0; sub < CTG; ++sub) {
+        negs[sub] = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 nb4 = *reinterpret_cast<const float4 *>(&nbb[sub * 32 + 8 * j + 4 * hf]);
-          acc[sub][4 * j + 0] = fmaf(-0.5f, nb4.x, halfG);
-          acc[sub][4 * j + 1] = fmaf(-0.5f, nb4.y, halfG);
-          acc[sub][4 * j + 2] = fmaf(-0.5f, nb4.z, halfG);
-          acc[sub][4 * j + 3] = fmaf(-0.5f, nb4.w, halfG);
-        }
-      products();
-      unsigned int neg = 0;
-#pragma unroll
-      for (int sub = 0; sub < CTG; ++sub)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) neg = (neg << 1) | (__float_as_uint(acc[sub][r]) >> 31);
-      pmask = (~neg) << (32 - NOUT);
+        for (int r = 0; r < 16; ++r)
+          negs[sub] = __builtin_amdgcn_alignbit(negs[sub], __float_as_uint(acc[sub][r]), 31);
+      }
     } else {
       asm volatile("; slow path" ::: "memory");
+      const float off = (G < GMAX) ? 0.f : SLOW_OFF;   // lanes without a threshold: pass real rows
 #pragma unroll
-      for (int sub = 0; sub < CTG; ++sub)
+      for (int sub = 0; sub < CTG; ++sub) {
+        negs[sub] = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[sub][r] = 0.f;
-      products();
-#pragma unroll
-      for (int sub = 0; sub < CTG; ++sub)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float nbr = nbb[sub * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
-          const bool ok = fmaf(-2.f, acc[sub][r], nbr) <= G;
-          pmask |= ok ? (0x80000000u >> (sub * 16 + r)) : 0u;
-        }
+        for (int r = 0; r < 16; ++r)
+          negs[sub] = __builtin_amdgcn_alignbit(negs[sub], __float_as_uint(acc[sub][r] + off), 31);
+      }
     }
+    unsigned int neg = negs[0];
+    if (CTG == 2) neg = (negs[0] << 16) | (negs[CTG - 1] & 0xffffu);
+    unsigned int pmask = (~neg) << (32 - NOUT);
     if (mixed) {   // rare: mask the own-chromosome rows of a mixed group
       asm volatile("; mixed group" ::: "memory");   // keep this a branch (no if-conversion)
       const int cs32 = (int)blk.cs, ce32 = (int)blk.ce;
-#pragma unroll
+#pragma unroll 1
       for (int rr = 0; rr < NOUT; ++rr) {
         const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
-        const int g = prow[loc];
+        const int g = perm[(int64_t)gix * GR + loc];
         if (g >= cs32 && g < ce32) pmask &= ~(0x80000000u >> rr);
       }
     }
     if (dbg & 1) pmask = 0;
-    if (__any(pmask != 0u)) {
-      int pos = 0;
-      if (pmask) pos = atomicAdd(&cnt[tl], __popc(pmask));
+    const unsigned int anym = wcx::wave_or_u32(pmask);       // wave-uniform
+    stamp(3);                                    // MFMA completion + sign bits + OR
+    if (anym) {
+      // slot reservation without LDS: the target's two lanes (l, l+32) swap their pass counts
+      // (appends staged in LDS and flushed as whole 128-byte lines were measured: no gain)
+      const unsigned int pc = (unsigned int)__popc(pmask);
+      const auto pcs = __builtin_amdgcn_permlane32_swap(pc, pc, false, false);   // {low, high} lane's
+      unsigned int ofs = (unsigned int)(tl * CAP + cntr + (hf ? (int)pcs[0] : 0));
+      cntr += (int)(pcs[0] + pcs[1]);
+      n_app += (int)pc;
+      // cntr <= LIM + CT = CAP: the slots exist (counts are cut back to <= LIM below)
+      const unsigned int pbase = (unsigned int)(gix * GR + 4 * hf);
 #pragma unroll
       for (int rr = 0; rr < NOUT; ++rr) {
-        if (pmask & (0x80000000u >> rr)) {
-          const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
-          const int64_t g = prow[loc];
-          const float av = acc[rr >> 4][rr & 15];
-          const float t = fast ? fmaf(-2.f, av, G) : fmaf(-2.f, av, nbb[loc]);
-          if (pos < CAP)
-            sl_row[pos] = make_uint2(f32_key(t), (unsigned int)(g < blk.cs ? g : g - own));
-          ++pos;
+        if (anym & (0x80000000u >> rr)) {                    // scalar branch: skip empty outputs
+          asm volatile("" ::: "memory");                     // (keeps the two tests separate)
+          if (pmask & (0x80000000u >> rr)) {
+            const int loc0 = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + (rr & 3);
+            const float t = fmaf(-2.f, acc[rr >> 4][rr & 15], Gp);
+            wg_sl[ofs] = make_uint2(__float_as_uint(t), pbase + loc0);
+            ++ofs;
+          }
         }
       }
+      stamp(4);                                  // appends
       // shortlist maintenance: wave-private (this wave's 32 targets); counts only change here
-        {
-        const int my_cnt = cnt[tl];
-        unsigned long long need = __ballot(tvalid && my_cnt > LIM) & 0xffffffffull;
+      unsigned int need = (unsigned int)__ballot(tvalid && cntr > LIM);   // low half = targets
+      if (need) {
+        const float G_before = G;
         while (need) {
-          const int c = __ffsll((long long)need) - 1;
+          const int c = __ffs((int)need) - 1;
           need &= need - 1;
-          const int64_t crow_s = (blk.row0 + wave * 32 + c) - row_begin;
+          const int64_t crow_s = wg_srow + wave * 32 + c;
           const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
                       G_c = __shfl(G, c, 64);
+          if (lane == c) cnt[wave * 32 + c] = cntr;
           const float Gn = compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c,
-                                          E_c, Q_c, G_c, &flags[crow_s], false);
-          if ((lane & 31) == c) G = Gn;
+                                          E_c, Q_c, G_c, &flags[crow_s], false,
+                                          PROF ? stats + 5 : nullptr);
+          if ((lane & 31) == c) { G = Gn; cntr = cnt[wave * 32 + c]; }
           ++n_compact;
+        }
+        if (G != G_before) {
+          _Float16 w1, w2;
+          encode_threshold(G, w1, w2, Gp);
+          if (hf) { th[NK - 1][6] = w1; th[NK - 1][7] = w2; }
         }
       }
     }
+    stamp(5);                                    // maintenance (compactions)
     buf ^= 1;
     cur = nxt;
   }
+  if (hf == 0) cnt[tl] = cntr;
   if (last) {
     // final cut of every target's shortlist with its final threshold
     for (int c = 0; c < 32; ++c) {
       if (wave * 32 + c >= blk.nrows) break;
-      const int64_t crow_s = (blk.row0 + wave * 32 + c) - row_begin;
+      const int64_t crow_s = wg_srow + wave * 32 + c;
       const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
                   G_c = __shfl(G, c, 64);
       (void)compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c, E_c, Q_c,
@@ -602,7 +685,15 @@ __global__ __launch_bounds__(NT, (NK * PL <= 8 ? 3 : 2)) void k_screen(
     g_state[srow] = G;
   }
   if (tvalid && hf == 0) cnt_out[srow] = cnt[tl];
-  if (lane == 0 && stats) atomicAdd(&stats[2], n_compact);
+  if (stats) {
+    const int tot_c = wcx::wave_sum_i(n_compact), tot_a = wcx::wave_sum_i(n_app);
+    if (lane == 0) {
+      atomicAdd(&stats[2], (unsigned long long)(tot_c / 64));
+      atomicAdd(&stats[4], (unsigned long long)tot_a);
+      if (PROF)
+        for (int i = 0; i < 6; ++i) atomicAdd(&stats[8 + i], pt[i]);
+    }
+  }
 }
 
 __global__ void k_mark(unsigned char *searched, const ScreenBlock *__restrict__ blocks,
@@ -616,7 +707,7 @@ __global__ void k_mark(unsigned char *searched, const ScreenBlock *__restrict__ 
 // Host side --------------------------------------------------------------------------------
 int wcx_debug_value = 0;   // diagnostics only (wcx_debug_flags): ablation switches for profiling
 bool wcx_screen_supported(int64_t B, int S, int k) {
-  return S <= 512 && k <= 512 && k <= LIM && B >= 2048;
+  return S <= 508 && k <= 512 && k <= LIM && B >= 2048;
 }
 
 int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
@@ -624,18 +715,14 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                            const std::vector<TopkBlock> &exact_blocks, int64_t row_begin,
                            int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist) {
   if (exact_blocks.empty()) return WCX_OK;
-  // Default: hi plane only (one fp16 product).  Its representation error (2^-11 relative) only
-  // widens the shortlists by a few dozen entries, while a third of the MFMA work and half the
-  // LDS traffic of the hi+lo form (three products; kept behind debug flag 32, S <= 128 only) is
-  // enough -- measured 24.5 ms vs 33.0 ms at 15 kb / S=100, refine +1.2 ms.
-  // K is padded so that the staging divides evenly over the workgroup.
-  const bool two_planes = (wcx_debug_value & 32) && S <= 128;
-  const int PL = two_planes ? 2 : 1;
-  int NK = (S + 15) / 16;
-  if (!two_planes) {
-    if (NK <= 8) NK = (NK + 1) & ~1;
-    else NK = NK <= 16 ? 16 : (NK <= 24 ? 24 : 32);
-  }
+  // One fp16 plane (its 2^-11 representation error only widens the shortlists by a few dozen
+  // entries; a hi+lo three-product form was measured 35 % slower end to end).  K = 16 NK holds the
+  // S data columns + 4 augmented columns (see k_screen_prep); NK is rounded up to an instantiated
+  // value.
+  static const int nk_list[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32};
+  int NK = 32;
+  for (int v : nk_list)
+    if (16 * v >= S + 4) { NK = v; break; }
   const int CTG = NK <= 16 ? 2 : 1;
   const int64_t Bpad = (B + CT - 1) / CT * CT;
   // regroup the searched row ranges into workgroups of <= 128 rows (same chromosome)
@@ -668,7 +755,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_mean = carve((size_t)S * 8 * 3);   // mean | sum | count
   const int Sp = (S + 3) & ~3;
   const size_t o_xr = carve((size_t)B * Sp * 8 + 256);   // + slack: refine loads whole 128-B chunks
-  const size_t o_F = carve((size_t)Bpad * NK * PL * 32);  // Bpad/32 tiles * NK * PL planes * 1 KiB
+  const size_t o_F = carve((size_t)Bpad * NK * 32);  // Bpad/32 tiles * NK * 1 KiB
   const size_t o_info = carve((size_t)Bpad * sizeof(RowInfo));
   const int64_t n_groups = Bpad / CT;
   const size_t o_perm = carve((size_t)Bpad * 4);
@@ -714,7 +801,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipMemsetAsync(cnt_out, 0, (size_t)n_rows * 4, st));
   WCX_HIP(hipMemsetAsync(flags, 0, (size_t)n_rows * 4, st));
   WCX_HIP(hipMemsetAsync(searched, 0, (size_t)n_rows, st));
-  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 32, st));
+  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, st));
   rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
   if (rc) return rc;
   k_mark<<<(unsigned)blocks.size(), TGT, 0, st>>>(searched, d_blocks, row_begin);
@@ -744,50 +831,49 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const int GRr = CTG * 32;
   // candidate chunk per launch: ~3 MB of fragments (fits the 4 MB XCD L2)
   const int64_t n_iter_groups = Bpad / GRr;
-  const int64_t group_bytes = (int64_t)GRr * NK * PL * 32;
+  const int64_t group_bytes = (int64_t)GRr * NK * 32;
   int64_t chunk_groups = (3 << 20) / group_bytes;
   if (chunk_groups < 16) chunk_groups = 16;
   if (chunk_groups > 4096) chunk_groups = 4096;
-  const size_t lds = 2 * (size_t)(CTG * NK * PL * 64) * 16 + 2 * GRr * 4 + TGT * 4 + 2 * GRr * 4 +
+  const size_t lds = 2 * (size_t)(CTG * NK * 64) * 16 + TGT * 4 +
                      (size_t)(chunk_groups + 64) * 4;   // + the chunk's visit list
-#define WCX_SCREEN_CASE(N, P, G)                                                               \
-  {                                                                                            \
-    k_screen_prep<N, P><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);     \
+#define WCX_SCREEN_CASE(N, G)                                                                  \
+  case N: {                                                                                    \
+    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);        \
     rc = wcx_timer_end(ctx, "topk_prep");                                                      \
     if (rc) return rc;                                                                         \
     rc = wcx_timer_begin(ctx, "topk_screen");                                                  \
     if (rc) return rc;                                                                         \
-    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<N, P, G>),              \
+    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<N, G>),                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     for (int64_t g0 = 0; g0 < n_iter_groups; g0 += chunk_groups) {                             \
       const int64_t g1 = g0 + chunk_groups < n_iter_groups ? g0 + chunk_groups : n_iter_groups; \
-      k_screen<N, P, G><<<(unsigned)blocks.size(), NT, lds, st>>>(                             \
-          F, info, glob, B, Bpad, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out,    \
-          flags, g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats,                  \
-          wcx_debug_value);                                                                    \
+      k_screen<N, G><<<(unsigned)blocks.size(), NT, lds, st>>>(                                \
+          F, info, glob, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out, flags,      \
+          g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats, wcx_debug_value);       \
     }                                                                                          \
-  }
-  if (two_planes) {
-    switch (NK) {
-      case 1: WCX_SCREEN_CASE(1, 2, 2) break;
-      case 2: WCX_SCREEN_CASE(2, 2, 2) break;
-      case 3: WCX_SCREEN_CASE(3, 2, 2) break;
-      case 4: WCX_SCREEN_CASE(4, 2, 2) break;
-      case 5: WCX_SCREEN_CASE(5, 2, 2) break;
-      case 6: WCX_SCREEN_CASE(6, 2, 2) break;
-      case 7: WCX_SCREEN_CASE(7, 2, 2) break;
-      default: WCX_SCREEN_CASE(8, 2, 2) break;
+  } break;
+  if ((wcx_debug_value & 4) && NK == 7) {
+    k_screen_prep<7><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);
+    rc = wcx_timer_end(ctx, "topk_prep");
+    if (rc) return rc;
+    rc = wcx_timer_begin(ctx, "topk_screen");
+    if (rc) return rc;
+    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<7, 2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int64_t g0 = 0; g0 < n_iter_groups; g0 += chunk_groups) {
+      const int64_t g1 = g0 + chunk_groups < n_iter_groups ? g0 + chunk_groups : n_iter_groups;
+      k_screen<7, 2, true><<<(unsigned)blocks.size(), NT, lds, st>>>(
+          F, info, glob, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out, flags,
+          g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats, wcx_debug_value);
     }
-  } else {
-    switch (NK) {
-      case 2: WCX_SCREEN_CASE(2, 1, 2) break;
-      case 4: WCX_SCREEN_CASE(4, 1, 2) break;
-      case 6: WCX_SCREEN_CASE(6, 1, 2) break;
-      case 8: WCX_SCREEN_CASE(8, 1, 2) break;
-      case 16: WCX_SCREEN_CASE(16, 1, 2) break;
-      case 24: WCX_SCREEN_CASE(24, 1, 1) break;
-      default: WCX_SCREEN_CASE(32, 1, 1) break;
-    }
+  } else
+  switch (NK) {
+    WCX_SCREEN_CASE(1, 2) WCX_SCREEN_CASE(2, 2) WCX_SCREEN_CASE(3, 2) WCX_SCREEN_CASE(4, 2)
+    WCX_SCREEN_CASE(5, 2) WCX_SCREEN_CASE(6, 2) WCX_SCREEN_CASE(7, 2) WCX_SCREEN_CASE(8, 2)
+    WCX_SCREEN_CASE(10, 2) WCX_SCREEN_CASE(12, 2) WCX_SCREEN_CASE(14, 2) WCX_SCREEN_CASE(16, 2)
+    WCX_SCREEN_CASE(20, 1) WCX_SCREEN_CASE(24, 1) WCX_SCREEN_CASE(28, 1)
+    default: WCX_SCREEN_CASE(32, 1)
   }
 #undef WCX_SCREEN_CASE
   WCX_HIP(hipGetLastError());
@@ -798,8 +884,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   ChrTab tab;
   tab.n_chr = n_chr;
   for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
-  rc = wcx_refine_launch(ctx, Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out, flags, k,
-                         d_out_idx, d_out_dist, glob);
+  rc = wcx_refine_launch(ctx, Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out, flags, perm,
+                         k, d_out_idx, d_out_dist, glob);
   if (rc) return rc;
   rc = wcx_timer_end(ctx, "topk_refine");
   if (rc) return rc;

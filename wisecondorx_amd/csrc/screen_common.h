@@ -36,5 +36,6 @@ struct ChrTab {
 struct wcx_ctx;
 int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTab &tab,
                       int64_t row_begin, int64_t n_rows, const unsigned char *searched,
-                      const uint2 *sl, const int *cnt_out, const unsigned int *flags, int k,
-                      int32_t *d_out_idx, double *d_out_dist, ScreenGlobals *glob);
+                      const uint2 *sl, const int *cnt_out, const unsigned int *flags,
+                      const int *perm, int k, int32_t *d_out_idx, double *d_out_dist,
+                      ScreenGlobals *glob);

@@ -45,6 +45,18 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return __builtin_amdgcn_readlane(wave_incl_scan_i(v), 63);
 }
 
+// OR of a 32-bit mask over the wave, as a wave-uniform (scalar) value.
+__device__ __forceinline__ unsigned int wave_or_u32(unsigned int m) {
+  int v = (int)m;
+  v |= dpp_i32<0x111, 0xf>(0, v);
+  v |= dpp_i32<0x112, 0xf>(0, v);
+  v |= dpp_i32<0x114, 0xf>(0, v);
+  v |= dpp_i32<0x118, 0xf>(0, v);
+  v |= dpp_i32<0x142, 0xa>(0, v);
+  v |= dpp_i32<0x143, 0xc>(0, v);
+  return (unsigned int)__builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64<0x111, 0xf>(0.0, v);
   v += dpp_f64<0x112, 0xf>(0.0, v);
