@@ -203,7 +203,7 @@ def main():
                     "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
                     "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
                     "fallback_rows": stats["fallback_rows"], "compactions": stats["compactions"], "appends": stats["appends"],
-                    "phase_cycles": stats["phase_cycles"], "compact_cycles": stats["compact_cycles"]}
+                    "phase_cycles": stats["phase_cycles"]}
     else:
         flops = 3.0 * S * stats["pairs"]         # exact path: sub, mul, add per (pair, sample)
         achieved = flops / (k_ms * 1e-3) / 1e12

@@ -17,6 +17,5 @@ try:
     pc=r["phase_cycles"]; tot=sum(pc)
     names=["issue loads+MFMA","wait loads+ds_write","barrier","MFMA done+sign+OR","appends","maintenance"]
     for n,c in zip(names,pc): print("%-24s %6.1f%%  %.3g"%(n,100*c/tot,c))
-    cc=r["compact_cycles"]; print("per compaction: fence %.0f loads %.0f select %.0f writeback %.0f"%tuple(c/max(r["compactions"],1) for c in cc))
 except Exception as e: print("prof ERR", e)
 PY

@@ -305,65 +305,56 @@ struct ScreenBlock {
   int64_t cs, ce;
 };
 
-// Wave-level shortlist compaction of one target of this wave.  Shortlist entries are
-// (float bits of t, sweep position).  Returns the new threshold G (t-space); updates cnt in LDS.
-__device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl_row, int *cnt_p, int k,
-                                                float na, float E, float Q, float G_old,
-                                                unsigned int *overflow_flag, bool exact,
-                                                unsigned long long *prof = nullptr) {
+// Wave-level shortlist compaction of one target of this wave, in two halves so that a burst of
+// compactions can have the NEXT target's 8 KB in flight while the current one is processed.
+// Shortlist entries are (float bits of t, sweep position).
+//
+// All CAP slots exist in memory: load unconditionally (16 independent loads in flight; a load
+// under `if (e < n)` made the compiler wait for each one in turn -- 16 serial round trips to HBM,
+// ~40k cycles per compaction) and mask afterwards.
+__device__ __forceinline__ void load_shortlist(const uint2 *__restrict__ sl_row, uint2 (&raw)[CAP / 64]) {
   const int lane = wcx::lane_id();
-  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  if (prof) c0 = __builtin_amdgcn_s_memtime();
-  // the entries were stored by (other lanes of) this wave: make them visible before re-reading
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if (prof) c1 = __builtin_amdgcn_s_memtime();
-  const int n = *cnt_p;
-  // all CAP slots exist in memory: load unconditionally (16 independent loads in flight; a
-  // load under `if (e < n)` made the compiler wait for each one in turn -- 16 serial round trips
-  // to HBM, ~40k cycles per compaction) and mask afterwards
-  unsigned int key[CAP / 64], idx[CAP / 64];
-  uint2 raw[CAP / 64];
 #pragma unroll
   for (int q = 0; q < CAP / 64; ++q) raw[q] = sl_row[q * 64 + lane];
+}
+
+// Returns the new threshold G (t-space) and the new count (n_out; 0 + overflow flag when the list
+// cannot be cut below LIM).  exact: resolve the k-th key to the last bit (final cut), else to
+// 2^-11 relative -- the resolution of the fp16 screen itself -- rounded up (in-sweep cuts: a tight
+// threshold matters, every later candidate passes with probability ~ rank/n).
+__device__ __forceinline__ float compact_loaded(const uint2 (&raw)[CAP / 64], int n,
+                                                uint2 *__restrict__ sl_row, int k, float na, float E,
+                                                float Q, float G_old, unsigned int *overflow_flag,
+                                                bool exact, int &n_out) {
+  const int lane = wcx::lane_id();
+  unsigned int key[CAP / 64], idx[CAP / 64];
 #pragma unroll
   for (int q = 0; q < CAP / 64; ++q) {
     const bool in = q * 64 + lane < n;
     key[q] = in ? f32_key(__uint_as_float(raw[q].x)) : 0xffffffffu;
     idx[q] = in ? raw[q].y : 0u;
   }
-  if (prof) {
-    // (forces the loads to have landed)
-    unsigned int x = 0;
-#pragma unroll
-    for (int q = 0; q < CAP / 64; ++q) x ^= key[q];
-    if (__ballot(x == 0x12345678u) == ~0ull) c2 = 1;
-    c2 += __builtin_amdgcn_s_memtime();
-  }
   float G = G_old;
   if (n >= k) {
-    unsigned int prefix = 0;
-    if (exact) {
-      // k-th smallest key by bitwise bisection (ballot counts): largest v with #(key < v) < k
-      for (int bit = 31; bit >= 0; --bit) {
-        const unsigned int trial = prefix | (1u << bit);
-        int c = 0;
+    // k-th smallest key by bitwise bisection (ballot counts): largest v with #(key < v) < k.
+    // The keys share their leading bits (sign, exponent, ...): start below the common prefix.
+    const unsigned int kref = (unsigned int)__builtin_amdgcn_readfirstlane((int)key[0]);
+    unsigned int x = 0;
 #pragma unroll
-        for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] < trial));
-        if (c < k) prefix = trial;
-      }
-    } else {
-      // In-sweep cut: the k-th smallest key to 20 bits (2^-11 relative, the resolution of the fp16
-      // screen itself), low bits rounded up -- a valid upper bound.  A tight threshold matters more
-      // than the ~300 extra ballots: every later candidate passes with probability ~ rank/n.
-      for (int bit = 31; bit >= 12; --bit) {
-        const unsigned int trial = prefix | (1u << bit);
-        int c = 0;
+    for (int q = 0; q < CAP / 64; ++q) x |= (q * 64 + lane < n) ? (key[q] ^ kref) : 0u;
+    x = wcx::wave_or_u32(x);
+    const int hb = 31 - __builtin_clz(x | 1u);              // highest differing bit (0 if none)
+    unsigned int prefix = kref & ~((2u << hb) - 1u);
+    const int low = exact ? 0 : 12;
+    for (int bit = hb; bit >= low; --bit) {
+      const unsigned int trial = prefix | (1u << bit);
+      int c = 0;
 #pragma unroll
-        for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] < trial));
-        if (c < k) prefix = trial;
-      }
-      prefix |= 0xfffu;
+      for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] < trial));
+      if (c < k) prefix = trial;
     }
+    if (!exact && hb >= 12) prefix |= 0xfffu;
+    if (!exact && hb < 12) prefix |= (2u << hb) - 1u;       // all keys within the low bits: upper end
     const float tk = key_f32(prefix);
     // T-space -> distance space -> filter bound F -> back to t-space, rounded outwards
     float dk = tk + na;
@@ -373,7 +364,6 @@ __device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl
     const float Gn = (Fb - na) + 4e-7f * (Fb + na);
     if (tk < HUGE_VALF && Gn < G_old) G = Gn;   // (NaN / inf bound: keep the old threshold)
   }
-  if (prof) c3 = __builtin_amdgcn_s_memtime();
   // keep entries with t <= G
   const unsigned int gkey = f32_key(G);
   int base = 0;
@@ -386,17 +376,11 @@ __device__ __attribute__((noinline)) float compact_target(uint2 *__restrict__ sl
     base += __popcll(m);
   }
   if (base > LIM) {   // cannot make room: hand the row to the exact kernel
-    if (lane == 0) { *overflow_flag = 1u; *cnt_p = 0; }
+    if (lane == 0) *overflow_flag = 1u;
+    n_out = 0;
     return -HUGE_VALF;
   }
-  if (lane == 0) *cnt_p = base;
-  if (prof && lane == 0) {
-    const unsigned long long c4 = __builtin_amdgcn_s_memtime();
-    atomicAdd(&prof[0], c1 - c0);   // fence
-    atomicAdd(&prof[1], c2 - c1);   // shortlist loads
-    atomicAdd(&prof[2], c3 - c2);   // selection
-    atomicAdd(&prof[9], c4 - c3);   // write-back (stats[14])
-  }
+  n_out = base;
   return G;
 }
 
@@ -435,8 +419,7 @@ __global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
   constexpr int NOUT = CTG * 16;                    // screen outputs per lane per iteration
   extern __shared__ __align__(16) unsigned char smem[];
   half8 *sbuf = reinterpret_cast<half8 *>(smem);                       // [2][TILE_H8]
-  int *cnt = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16);         // [TGT]
-  int *glist = cnt + TGT;                                              // [groups of the chunk]
+  int *glist = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16);       // [groups of the chunk]
   __shared__ int s_nlist;
 
   const ScreenBlock blk = blocks[blockIdx.x];
@@ -449,8 +432,6 @@ __global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
   const int64_t srow = trow - row_begin;
   const int64_t wg_srow = blk.row0 - row_begin;
   uint2 *wg_sl = sl + wg_srow * (int64_t)CAP;    // this workgroup's TGT shortlists (uniform base)
-
-  if (tid < TGT) cnt[tid] = (first || tid >= blk.nrows) ? 0 : cnt_out[wg_srow + tid];
 
   // Visit list of this launch's chunk, built once per workgroup in LDS: groups holding only
   // own-chromosome rows are skipped (gmask = chromosomes present per 64 rows); bit 31 marks groups
@@ -527,9 +508,49 @@ __global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
     for (int p = 0; p < NPT; ++p)
       if ((p + 1) * NT <= TILE_H8 || p * NT + tid < TILE_H8) sbuf[p * NT + tid] = pre[p];
   }
-  int cntr = cnt[tl];                          // shortlist count of my target, kept in a register
+  // shortlist count of my target, kept in a register (identical in the target's two lanes)
+  int cntr = (first || !tvalid) ? 0 : cnt_out[srow];
   __syncthreads();
   bool fast = false;
+  // A burst of compactions (targets of this wave flagged in `need`): the next target's shortlist
+  // is loaded while the current one is selected and written back.
+  auto run_compactions = [&](unsigned int need, bool exact) {
+    const float G_before = G;
+    // this wave's appends must be visible before they are re-read
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    int c = __ffs((int)need) - 1;
+    need &= need - 1;
+    uint2 raw[CAP / 64];
+    load_shortlist(sl + (wg_srow + wave * 32 + c) * (int64_t)CAP, raw);
+    for (;;) {
+      const int cn = need ? __ffs((int)need) - 1 : -1;
+      need &= need - 1;
+      uint2 rawn[CAP / 64];
+      if (NK <= 8 && cn >= 0) load_shortlist(sl + (wg_srow + wave * 32 + cn) * (int64_t)CAP, rawn);
+      const int64_t crow_s = wg_srow + wave * 32 + c;
+      const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
+                  G_c = __shfl(G, c, 64);
+      const int n_c = __builtin_amdgcn_readlane(cntr, c);
+      int n_new;
+      const float Gn = compact_loaded(raw, n_c, sl + crow_s * (int64_t)CAP, k, na_c, E_c, Q_c, G_c,
+                                      &flags[crow_s], exact, n_new);
+      if ((lane & 31) == c) { G = Gn; cntr = n_new; }
+      ++n_compact;
+      if (cn < 0) break;
+      c = cn;
+      if (NK <= 8) {
+#pragma unroll
+        for (int q = 0; q < CAP / 64; ++q) raw[q] = rawn[q];
+      } else {                       // large K: no registers to spare for the look-ahead
+        load_shortlist(sl + (wg_srow + wave * 32 + c) * (int64_t)CAP, raw);
+      }
+    }
+    if (G != G_before) {
+      _Float16 w1, w2;
+      encode_threshold(G, w1, w2, Gp);
+      if (hf) { th[NK - 1][6] = w1; th[NK - 1][7] = w2; }
+    }
+  };
   for (int j = 0; j < n_list; ++j) {
     // Order inside an iteration: issue the next group's global loads, run the MFMA block on the
     // current LDS buffer, park the loaded group in the other buffer, barrier, THEN do the
@@ -643,48 +664,22 @@ __global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
       }
       stamp(4);                                  // appends
       // shortlist maintenance: wave-private (this wave's 32 targets); counts only change here
-      unsigned int need = (unsigned int)__ballot(tvalid && cntr > LIM);   // low half = targets
-      if (need) {
-        const float G_before = G;
-        while (need) {
-          const int c = __ffs((int)need) - 1;
-          need &= need - 1;
-          const int64_t crow_s = wg_srow + wave * 32 + c;
-          const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
-                      G_c = __shfl(G, c, 64);
-          if (lane == c) cnt[wave * 32 + c] = cntr;
-          const float Gn = compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c,
-                                          E_c, Q_c, G_c, &flags[crow_s], false,
-                                          PROF ? stats + 5 : nullptr);
-          if ((lane & 31) == c) { G = Gn; cntr = cnt[wave * 32 + c]; }
-          ++n_compact;
-        }
-        if (G != G_before) {
-          _Float16 w1, w2;
-          encode_threshold(G, w1, w2, Gp);
-          if (hf) { th[NK - 1][6] = w1; th[NK - 1][7] = w2; }
-        }
-      }
+      const int trig = (dbg >> 8) ? (dbg >> 8) : LIM;         // (diagnostics: earlier cuts)
+      const unsigned int need = (unsigned int)__ballot(tvalid && cntr > trig);   // low half = targets
+      if (need) run_compactions(need, false);
     }
     stamp(5);                                    // maintenance (compactions)
     buf ^= 1;
     cur = nxt;
   }
-  if (hf == 0) cnt[tl] = cntr;
   if (last) {
-    // final cut of every target's shortlist with its final threshold
-    for (int c = 0; c < 32; ++c) {
-      if (wave * 32 + c >= blk.nrows) break;
-      const int64_t crow_s = wg_srow + wave * 32 + c;
-      const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
-                  G_c = __shfl(G, c, 64);
-      (void)compact_target(sl + crow_s * (int64_t)CAP, &cnt[wave * 32 + c], k, na_c, E_c, Q_c,
-                           G_c, &flags[crow_s], true);
-    }
+    // final cut of every target's shortlist with its final threshold (exact k-th key)
+    const int nv = blk.nrows - wave * 32;
+    if (nv > 0) run_compactions(nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u), true);
   } else if (tvalid && hf == 0) {
     g_state[srow] = G;
   }
-  if (tvalid && hf == 0) cnt_out[srow] = cnt[tl];
+  if (tvalid && hf == 0) cnt_out[srow] = cntr;
   if (stats) {
     const int tot_c = wcx::wave_sum_i(n_compact), tot_a = wcx::wave_sum_i(n_app);
     if (lane == 0) {
@@ -835,7 +830,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   int64_t chunk_groups = (3 << 20) / group_bytes;
   if (chunk_groups < 16) chunk_groups = 16;
   if (chunk_groups > 4096) chunk_groups = 4096;
-  const size_t lds = 2 * (size_t)(CTG * NK * 64) * 16 + TGT * 4 +
+  const size_t lds = 2 * (size_t)(CTG * NK * 64) * 16 +
                      (size_t)(chunk_groups + 64) * 4;   // + the chunk's visit list
 #define WCX_SCREEN_CASE(N, G)                                                                  \
   case N: {                                                                                    \
