@@ -2,59 +2,205 @@
 //
 //   out[r][m] = log2( x_m[row_begin+r] / median_t x_m[idx[r][t]] ),  x_m = sample sid[m]
 //
-// One wave owns one (row, sample) pair at a time: 64 lanes gather the k reference values
-// (the sample vector is a contiguous double[B] slice of the sample-major matrix, L2
-// resident), sort them in registers (wave_sort.h) and take the median.  The index row is
-// applied to the FULL bin vector exactly like the reference does (newref_tools.py:219-221);
-// index -1 (padding) wraps to the last bin as NumPy's negative indexing does.
+// The index row is applied to the FULL bin vector exactly like the reference does
+// (newref_tools.py:219-221); index -1 (padding) wraps to the last bin as NumPy's negative
+// indexing does.
 //
-// Roofline: HBM/L2-gather bound in principle (k*4 bytes of indices per row are read once per
-// workgroup and reused for all samples); in practice the register sort (VALU + ds_bpermute)
-// dominates -- see DESIGN.md.
+// 1.8e7 medians of 300 gathered doubles each (15 kb, 100 null samples).  Selecting on doubles costs
+// three instructions per compare and 80 VGPRs per wave; instead every null sample is ranked ONCE
+// (stable two-pass radix sort of all samples together: low 32 key bits, then sample | high 32
+// bits), and the medians are selected on the 32-bit RANKS -- exact, because rank order is value
+// order and equal values give equal medians whichever of them is picked:
+//   k_nr_keys / hipcub radix sort x2 / k_nr_key64 / k_nr_scatter   ranks R and sorted values V
+//   k_null_ratios   one wave per (row, 8 samples): the 8 samples' ranks of a bin share one 32-byte
+//                   piece (Rg[group][bin][8]); per sample: min/max, 64 buckets (LDS atomics), scan
+//                   to the bucket holding the median rank, exact ranks inside it; the median value
+//                   is V[rank] (mean of the two middle ones).
+// Roofline: gather bound in principle (k * 32 B per row and sample group through L2 = 22 GB at
+// 15 kb); the selection arithmetic still dominates -- see DESIGN.md.
+#include <hipcub/hipcub.hpp>
+
 #include "wave_sort.h"
 #include "wcx_common.h"
 
+extern int wcx_debug_value;
+
 namespace {
 
-constexpr int NT = 256;  // 4 waves per workgroup
+constexpr int NT = 256;        // 4 waves per workgroup
+constexpr int BIN_BITS = 25;   // payload = sample << 25 | bin
 
-// The null samples are first packed 8 to a 64-byte line:  Xg[sg][b][8] = X[b][sid[8 sg + 0..7]]
-// so that ONE gathered cache line serves 8 medians (the gather traffic, not the selection, is
-// what bounds this kernel).
-__global__ __launch_bounds__(NT) void k_nr_pack(const double *__restrict__ Xs, int64_t B,
-                                                const int32_t *__restrict__ sids, int n_ids,
-                                                double *__restrict__ Xg) {
+// order-preserving 64-bit image of a double; NaN sorts last, -0 == +0
+__device__ __forceinline__ unsigned long long dkey(double x) {
+  if (x != x) return ~0ull;
+  x = x + 0.0;
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(NT) void k_nr_keys(const double *__restrict__ Xs, int64_t B,
+                                                const int32_t *__restrict__ sids,
+                                                unsigned int *__restrict__ k32,
+                                                unsigned int *__restrict__ pay,
+                                                int *__restrict__ n_nan) {
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
-  const int sg = blockIdx.y;
+  const int m = blockIdx.y;
   if (b >= B) return;
-  double v[8];
+  const double x = Xs[(int64_t)sids[m] * B + b];
+  k32[(int64_t)m * B + b] = (unsigned int)dkey(x);
+  pay[(int64_t)m * B + b] = ((unsigned int)m << BIN_BITS) | (unsigned int)b;
+  if (x != x) atomicAdd(&n_nan[m], 1);
+}
+
+__global__ __launch_bounds__(NT) void k_nr_key64(const double *__restrict__ Xs, int64_t B,
+                                                 const int32_t *__restrict__ sids,
+                                                 const unsigned int *__restrict__ pay, int64_t n,
+                                                 unsigned long long *__restrict__ k64) {
+  const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int p = pay[i];
+  const int m = (int)(p >> BIN_BITS);
+  const int64_t b = p & ((1u << BIN_BITS) - 1u);
+  k64[i] = ((unsigned long long)m << 32) | (dkey(Xs[(int64_t)sids[m] * B + b]) >> 32);
+}
+
+// sorted position -> rank of (sample, bin), packed 8 samples to a 32-byte piece, + sorted values
+__global__ __launch_bounds__(NT) void k_nr_scatter(const double *__restrict__ Xs, int64_t B,
+                                                   const int32_t *__restrict__ sids,
+                                                   const unsigned int *__restrict__ pay, int64_t n,
+                                                   unsigned int *__restrict__ Rg,
+                                                   double *__restrict__ V) {
+  const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int p = pay[i];
+  const int m = (int)(p >> BIN_BITS);
+  const int64_t b = p & ((1u << BIN_BITS) - 1u);
+  const int64_t r = i - (int64_t)m * B;
+  Rg[((int64_t)(m >> 3) * B + b) * 8 + (m & 7)] = (unsigned int)r;
+  V[i] = Xs[(int64_t)sids[m] * B + b];
+}
+
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
+  using wcx::dpp_i32;
+  unsigned int o;
+  o = (unsigned int)dpp_i32<0x111, 0xf>(-1, (int)v); v = o < v ? o : v;
+  o = (unsigned int)dpp_i32<0x112, 0xf>(-1, (int)v); v = o < v ? o : v;
+  o = (unsigned int)dpp_i32<0x114, 0xf>(-1, (int)v); v = o < v ? o : v;
+  o = (unsigned int)dpp_i32<0x118, 0xf>(-1, (int)v); v = o < v ? o : v;
+  o = (unsigned int)dpp_i32<0x142, 0xa>(-1, (int)v); v = o < v ? o : v;
+  o = (unsigned int)dpp_i32<0x143, 0xc>(-1, (int)v); v = o < v ? o : v;
+  return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// rank-th smallest (0-based, rank < n) of the active 32-bit values by bitwise bisection: exact for
+// any input (duplicates included).  Rare path (a bucket with more than 64 members).
+template <int IPL>
+__device__ __forceinline__ unsigned int select_u32_bisect(const unsigned int (&v)[IPL],
+                                                                    unsigned int act, int rank) {
+  unsigned int prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned int trial = prefix | (1u << bit);
+    int c = 0;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int m = sg * 8 + s;
-    v[s] = m < n_ids ? Xs[(int64_t)sids[m] * B + b] : 1.0;
+    for (int q = 0; q < IPL; ++q) c += __popcll(__ballot(((act >> q) & 1u) && v[q] < trial));
+    if (c <= rank) prefix = trial;
   }
-  double2 *dst = reinterpret_cast<double2 *>(Xg + ((int64_t)sg * B + b) * 8);
-  dst[0] = make_double2(v[0], v[1]);
-  dst[1] = make_double2(v[2], v[3]);
-  dst[2] = make_double2(v[4], v[5]);
-  dst[3] = make_double2(v[6], v[7]);
+  return prefix;
+}
+
+// The two middle order statistics (ranks r0 = (n-1)/2 and r1 = n/2) of the active values.
+// hist: int[64], slots: unsigned[64], wave-private LDS.  hi_out = the maximum (NaN detection).
+template <int IPL>
+__device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], unsigned int act,
+                                                int n, int *hist, unsigned int *slots,
+                                                unsigned int &a0, unsigned int &a1,
+                                                unsigned int &hi_out) {
+  const int lane = wcx::lane_id();
+  const int r0 = (n - 1) >> 1, r1 = n >> 1;
+  unsigned int lo = 0xffffffffu, nhi = 0xffffffffu;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q)
+    if ((act >> q) & 1u) { lo = v[q] < lo ? v[q] : lo; nhi = ~v[q] < nhi ? ~v[q] : nhi; }
+  lo = wave_min_u32(lo);
+  const unsigned int hi = ~wave_min_u32(nhi);
+  hi_out = hi;
+  if (hi == lo) { a0 = lo; a1 = lo; return; }
+  const float scale = 64.0f / ((float)(hi - lo) * 1.0000002f + 1.0f);   // bucket(hi) <= 63
+  hist[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  int b[IPL];
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    b[q] = 0;
+    if ((act >> q) & 1u) {
+      int bb = (int)((float)(v[q] - lo) * scale);          // monotone in v
+      bb = bb > 63 ? 63 : bb;
+      b[q] = bb;
+      atomicAdd(&hist[bb], 1);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int h = hist[lane];
+  const int cum = wcx::wave_incl_scan_i(h);
+  const unsigned long long gt = __ballot(cum > r0);
+  const int B0 = __ffsll((long long)gt) - 1;                 // gt != 0: cum[63] = n > r0
+  const int before = B0 > 0 ? __builtin_amdgcn_readlane(cum, B0 - 1) : 0;
+  const int need = r0 - before;
+  const int cB = __builtin_amdgcn_readlane(h, B0);
+  if (cB > 64) {                                             // heavy duplicates: general path
+    a0 = select_u32_bisect<IPL>(v, act, r0);
+    a1 = r1 == r0 ? a0 : select_u32_bisect<IPL>(v, act, r1);
+    return;
+  }
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const bool m = ((act >> q) & 1u) && b[q] == B0;
+    const unsigned long long mm = __ballot(m);
+    if (m) slots[base + __popcll(mm & ((1ull << lane) - 1ull))] = v[q];
+    base += __popcll(mm);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned int w = lane < cB ? slots[lane] : 0xffffffffu;
+  int rk = 0;
+  for (int L = 0; L < cB; ++L) {
+    const unsigned int p = (unsigned int)__builtin_amdgcn_readlane((int)w, L);
+    rk += ((p < w) || (p == w && L < lane)) ? 1 : 0;
+  }
+  const unsigned long long hit = __ballot(lane < cB && rk == need);
+  a0 = (unsigned int)__builtin_amdgcn_readlane((int)w, __ffsll((long long)hit) - 1);
+  a1 = a0;
+  if (r1 != r0) {
+    if (need + 1 < cB) {
+      const unsigned long long hit1 = __ballot(lane < cB && rk == need + 1);
+      a1 = (unsigned int)__builtin_amdgcn_readlane((int)w, __ffsll((long long)hit1) - 1);
+    } else {                         // next order statistic = smallest value of the later buckets
+      unsigned int mn = 0xffffffffu;
+#pragma unroll
+      for (int q = 0; q < IPL; ++q)
+        if (((act >> q) & 1u) && b[q] > B0 && v[q] < mn) mn = v[q];
+      a1 = wave_min_u32(mn);
+    }
+  }
 }
 
 // One wave per (row, group of 8 samples).  blockIdx.x (fastest in dispatch order) walks the rows,
-// blockIdx.y the sample groups: at any moment the whole chip gathers from ONE 64*B-byte slab.
+// blockIdx.y the sample groups: at any moment the whole chip gathers from ONE 32*B-byte slab.
 template <int IPL>
 __global__ __launch_bounds__(NT) void k_null_ratios(
-    const double *__restrict__ Xg, int64_t B, const int32_t *__restrict__ idx,
-    int64_t row_begin, int64_t n_rows, int k, int n_ids, double *__restrict__ out) {
+    const unsigned int *__restrict__ Rg, const double *__restrict__ V,
+    const int *__restrict__ n_nan, const double *__restrict__ Xs,
+    const int32_t *__restrict__ sids, int64_t B, const int32_t *__restrict__ idx,
+    int64_t row_begin, int64_t n_rows, int k, int n_ids, double *__restrict__ out, int dbg) {
   const int lane = wcx::lane_id();
   const int wave = threadIdx.x >> 6;
   __shared__ int s_hist[NT / 64][64];
-  __shared__ double s_slots[NT / 64][64];
+  __shared__ unsigned int s_slots[NT / 64][64];
   const int64_t r = (int64_t)blockIdx.x * (NT / 64) + wave;
   if (r >= n_rows) return;
   const int sg = blockIdx.y;
-  const double *slab = Xg + (int64_t)sg * B * 8;
-  double v[8][IPL];
+  const uint4 *slab = reinterpret_cast<const uint4 *>(Rg + (int64_t)sg * B * 8);
+  unsigned int v[8][IPL];
   unsigned int act = 0;
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
@@ -63,26 +209,35 @@ __global__ __launch_bounds__(NT) void k_null_ratios(
     int64_t c = valid ? (int64_t)idx[r * (int64_t)k + t] : 0;
     if (c < 0) c += B;  // NumPy negative index
     act |= valid ? (1u << q) : 0u;
-    const double2 *src = reinterpret_cast<const double2 *>(slab + c * 8);
-    const double2 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
-    v[0][q] = a0.x; v[1][q] = a0.y; v[2][q] = a1.x; v[3][q] = a1.y;
-    v[4][q] = a2.x; v[5][q] = a2.y; v[6][q] = a3.x; v[7][q] = a3.y;
+    uint4 a0, a1;
+    if (dbg & 16) {            // ablation: no gathers
+      a0 = make_uint4((unsigned)c, (unsigned)c * 3u, (unsigned)c ^ 0x55u, (unsigned)c + 7u);
+      a1 = make_uint4((unsigned)c * 5u, (unsigned)c + 1u, (unsigned)c ^ 0x33u, (unsigned)c + 9u);
+    } else { a0 = slab[c * 2]; a1 = slab[c * 2 + 1]; }
+    v[0][q] = a0.x; v[1][q] = a0.y; v[2][q] = a0.z; v[3][q] = a0.w;
+    v[4][q] = a1.x; v[5][q] = a1.y; v[6][q] = a1.z; v[7][q] = a1.w;
   }
-  double my_med = 0.0;
+  unsigned int my_a0 = 0, my_a1 = 0, my_hi = 0;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    bool has_nan = false;
+    unsigned int a0, a1, hi;
+    if (dbg & 64) {            // ablation: no selection
+      a0 = 0;
 #pragma unroll
-    for (int q = 0; q < IPL; ++q) has_nan |= ((act >> q) & 1u) && (v[s][q] != v[s][q]);
-    double med;
-    if (__any(has_nan)) med = __builtin_nan("");  // np.median propagates NaN
-    else med = wcx::wave_median_bucket<IPL>(v[s], act, k, s_hist[wave], s_slots[wave]);
-    if (lane == s) my_med = med;
+      for (int q = 0; q < IPL; ++q) a0 ^= v[s][q];
+      a0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)a0) % (unsigned int)B; a1 = a0; hi = 0;
+    } else
+    wave_middle_u32<IPL>(v[s], act, k, s_hist[wave], s_slots[wave], a0, a1, hi);
+    if (lane == s) { my_a0 = a0; my_a1 = a1; my_hi = hi; }
   }
   const int m = sg * 8 + lane;
   if (lane < 8 && m < n_ids) {
-    const double xr = slab[(row_begin + r) * 8 + lane];
-    out[r * (int64_t)n_ids + m] = log2(xr / my_med);
+    const double *Vm = V + (int64_t)m * B;
+    if (dbg & 16) { my_a0 %= (unsigned int)B; my_a1 %= (unsigned int)B; }
+    double med = (Vm[my_a0] + Vm[my_a1]) / 2.0;
+    if ((int64_t)my_hi >= B - n_nan[m]) med = __builtin_nan("");   // np.median propagates NaN
+    const double xr = Xs[(int64_t)sids[m] * B + row_begin + r];
+    out[r * (int64_t)n_ids + m] = log2(xr / med);
   }
 }
 
@@ -96,28 +251,70 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_ARG(ctx && dXs && d_idx && sample_ids && d_out, "NULL argument");
   WCX_ARG(B > 0 && S > 0 && k > 0 && n_ids >= 0, "bad sizes");
   WCX_ARG(0 <= row_begin && row_begin <= row_end && row_end <= B, "bad row range");
+  WCX_ARG(B < (1ll << BIN_BITS) && n_ids <= 128, "too many bins / null samples");
+  WCX_ARG((int64_t)n_ids * B < (1ll << 31), "null samples x bins exceeds 2^31");
   for (int i = 0; i < n_ids; ++i)
     WCX_ARG(sample_ids[i] >= 0 && sample_ids[i] < S, "sample id out of range");
   WCX_HIP(hipSetDevice(ctx->device));
   const int64_t n_rows = row_end - row_begin;
   if (n_rows == 0 || n_ids == 0) return WCX_OK;
   const int n_sg = (n_ids + 7) / 8;
-  const size_t xg_bytes = (size_t)n_sg * B * 64;
+  const int64_t n = (int64_t)n_ids * B;
+  hipStream_t st = ctx->stream;
+
+  // temp storage of the two sorts (sizes only)
+  size_t tmp_a = 0, tmp_b = 0;
+  int sample_bits = 1;
+  while ((1 << sample_bits) < n_ids) ++sample_bits;
+  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_a, (const unsigned int *)nullptr,
+                                             (unsigned int *)nullptr, (const unsigned int *)nullptr,
+                                             (unsigned int *)nullptr, (int)n, 0, 32, st));
+  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_b, (const unsigned long long *)nullptr,
+                                             (unsigned long long *)nullptr,
+                                             (const unsigned int *)nullptr, (unsigned int *)nullptr,
+                                             (int)n, 0, 32 + sample_bits, st));
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_sid = carve((size_t)n_ids * 4);
+  const size_t o_nan = carve((size_t)n_ids * 4);
+  const size_t o_k32a = carve((size_t)n * 4), o_k32b = carve((size_t)n * 4);
+  const size_t o_pa = carve((size_t)n * 4), o_pb = carve((size_t)n * 4);
+  const size_t o_k64a = carve((size_t)n * 8), o_k64b = carve((size_t)n * 8);
+  const size_t o_rg = carve((size_t)n_sg * B * 32);
+  const size_t o_v = carve((size_t)n * 8);
+  const size_t o_tmp = carve(tmp_a > tmp_b ? tmp_a : tmp_b);
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, xg_bytes + (size_t)n_ids * 4 + 256, &scr);
+  int rc = wcx_scratch(ctx, off, &scr);
   if (rc) return rc;
-  double *Xg = reinterpret_cast<double *>(scr);
-  int32_t *d_sids = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(scr) + xg_bytes);
+  char *base = reinterpret_cast<char *>(scr);
+  int32_t *d_sids = reinterpret_cast<int32_t *>(base + o_sid);
+  int *d_nan = reinterpret_cast<int *>(base + o_nan);
+  unsigned int *k32a = reinterpret_cast<unsigned int *>(base + o_k32a);
+  unsigned int *k32b = reinterpret_cast<unsigned int *>(base + o_k32b);
+  unsigned int *pa = reinterpret_cast<unsigned int *>(base + o_pa);
+  unsigned int *pb = reinterpret_cast<unsigned int *>(base + o_pb);
+  unsigned long long *k64a = reinterpret_cast<unsigned long long *>(base + o_k64a);
+  unsigned long long *k64b = reinterpret_cast<unsigned long long *>(base + o_k64b);
+  unsigned int *Rg = reinterpret_cast<unsigned int *>(base + o_rg);
+  double *V = reinterpret_cast<double *>(base + o_v);
+  void *tmp = base + o_tmp;
   rc = wcx_upload_small(ctx, d_sids, sample_ids, (size_t)n_ids * 4);
   if (rc) return rc;
   rc = wcx_timer_begin(ctx, "null_ratios");
   if (rc) return rc;
-  k_nr_pack<<<dim3((unsigned)((B + NT - 1) / NT), (unsigned)n_sg), NT, 0, ctx->stream>>>(
-      dXs, B, d_sids, n_ids, Xg);
+  WCX_HIP(hipMemsetAsync(d_nan, 0, (size_t)n_ids * 4, st));
+  if (n_ids & 7) WCX_HIP(hipMemsetAsync(Rg + (int64_t)(n_sg - 1) * B * 8, 0, (size_t)B * 32, st));
+  const unsigned gb = (unsigned)((B + NT - 1) / NT), gn = (unsigned)((n + NT - 1) / NT);
+  k_nr_keys<<<dim3(gb, (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, k32a, pa, d_nan);
+  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_a, k32a, k32b, pa, pb, (int)n, 0, 32, st));
+  k_nr_key64<<<gn, NT, 0, st>>>(dXs, B, d_sids, pb, n, k64a);
+  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_b, k64a, k64b, pb, pa, (int)n, 0,
+                                             32 + sample_bits, st));
+  k_nr_scatter<<<gn, NT, 0, st>>>(dXs, B, d_sids, pa, n, Rg, V);
   const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)n_sg);
-#define WCX_NR_LAUNCH(IPL)                                                                    \
-  k_null_ratios<IPL><<<grid, NT, 0, ctx->stream>>>(Xg, B, d_idx, row_begin, n_rows, k, n_ids, \
-                                                   d_out)
+#define WCX_NR_LAUNCH(IPL)                                                                      \
+  k_null_ratios<IPL><<<grid, NT, 0, st>>>(Rg, V, d_nan, dXs, d_sids, B, d_idx, row_begin, n_rows, \
+                                          k, n_ids, d_out, wcx_debug_value)
   const int ipl = (k + 63) / 64;
   if (ipl <= 1) WCX_NR_LAUNCH(1);
   else if (ipl <= 2) WCX_NR_LAUNCH(2);
