@@ -141,19 +141,28 @@ __global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xr, 
   rbits[b] = u;
 }
 
+// Cell histogram with workgroup-private LDS counters (the rows pile into a few dozen cells: global
+// atomics straight from every row serialise).
 __global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict__ rbits,
                                                  const int *__restrict__ rchr, int64_t B,
                                                  const ScreenGlobals *__restrict__ glob,
                                                  int *__restrict__ rkey, int *__restrict__ cellcnt) {
+  __shared__ int lh[NCELL];
+  for (int i = threadIdx.x; i < NCELL; i += NT) lh[i] = 0;
+  __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (b >= B) return;
-  const unsigned int umin = 0xffffffffu - glob->uinv;
-  const unsigned int u = rbits[b];
-  unsigned int bucket = NBUCKET - 1;
-  if (u != 0xffffffffu && u >= umin && u - umin < NBUCKET - 1) bucket = u - umin;
-  const int key = (int)bucket * 32 + rchr[b];
-  rkey[b] = key;
-  atomicAdd(&cellcnt[key], 1);
+  if (b < B) {
+    const unsigned int umin = 0xffffffffu - glob->uinv;
+    const unsigned int u = rbits[b];
+    unsigned int bucket = NBUCKET - 1;
+    if (u != 0xffffffffu && u >= umin && u - umin < NBUCKET - 1) bucket = u - umin;
+    const int key = (int)bucket * 32 + rchr[b];
+    rkey[b] = key;
+    atomicAdd(&lh[key], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NCELL; i += NT)
+    if (lh[i]) atomicAdd(&cellcnt[i], lh[i]);
 }
 
 __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cellcnt,
@@ -177,14 +186,25 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cel
   for (int i = 0; i < PER; ++i) cursor[t * PER + i] = base + loc[i];
 }
 
+// Rows -> sweep positions: each workgroup reserves one range per cell it touches.
 __global__ __launch_bounds__(NT) void k_scatter(const int *__restrict__ rkey, int64_t B,
                                                 int *__restrict__ cursor, int *__restrict__ perm,
                                                 int *__restrict__ rowpos) {
+  __shared__ int lh[NCELL];
+  for (int i = threadIdx.x; i < NCELL; i += NT) lh[i] = 0;
+  __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (b >= B) return;
-  const int pos = atomicAdd(&cursor[rkey[b]], 1);
-  perm[pos] = (int)b;
-  rowpos[b] = pos;
+  int key = 0, local = 0;
+  if (b < B) { key = rkey[b]; local = atomicAdd(&lh[key], 1); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NCELL; i += NT)
+    if (lh[i]) lh[i] = atomicAdd(&cursor[i], lh[i]);        // count -> base of this workgroup's range
+  __syncthreads();
+  if (b < B) {
+    const int pos = lh[key] + local;
+    perm[pos] = (int)b;
+    rowpos[b] = pos;
+  }
 }
 
 __global__ __launch_bounds__(NT) void k_group_mask(const int *__restrict__ perm,

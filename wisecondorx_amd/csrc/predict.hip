@@ -236,15 +236,31 @@ __global__ __launch_bounds__(NTM) void k_nanmedian(const double *__restrict__ a0
     if (tid < 256) { hist[0][tid] = 0; hist[1][tid] = 0; }
     __syncthreads();
     const unsigned long long p0 = prefix[0], p1 = prefix[1];
-    for (int64_t i = tid; i < n; i += NTM) {
-      const double x = a[i];
-      if (x == x) {
-        const unsigned long long kx = f64_key(x);
-        const unsigned int dg = (unsigned int)((kx >> shift) & 255ull);
-        if ((kx & himask) == p0) atomicAdd(&hist[0][dg], 1u);
-        if ((kx & himask) == p1) atomicAdd(&hist[1][dg], 1u);
+    const bool two = p1 != p0;                     // the two middle ranks usually share a prefix
+    // wave-aggregated counting: in the leading digits (sign, exponent) whole waves agree, and 64
+    // lanes adding to one LDS counter would serialise
+    auto count = [&](bool on, unsigned int dg, unsigned int *h) {
+      const unsigned long long m = __ballot(on);
+      if (m == 0ull) return;
+      const int first = __ffsll((long long)m) - 1;
+      const unsigned int dgf = (unsigned int)__builtin_amdgcn_readlane((int)dg, first);
+      if (__ballot(on && dg == dgf) == m) {
+        if ((tid & 63) == first) atomicAdd(&h[dgf], (unsigned int)__popcll(m));
+      } else if (on) {
+        atomicAdd(&h[dg], 1u);
       }
+    };
+    for (int64_t i0 = 0; i0 < n; i0 += NTM) {
+      const int64_t i = i0 + tid;
+      const double x = i < n ? a[i] : __builtin_nan("");
+      const bool ok = x == x;
+      const unsigned long long kx = f64_key(x);
+      const unsigned int dg = (unsigned int)((kx >> shift) & 255ull);
+      count(ok && (kx & himask) == p0, dg, hist[0]);
+      if (two) count(ok && (kx & himask) == p1, dg, hist[1]);
     }
+    __syncthreads();
+    if (!two && tid < 256) hist[1][tid] = hist[0][tid];
     __syncthreads();
     if (tid < 2) {
       long long rk = rank[tid];
