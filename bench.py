@@ -218,9 +218,9 @@ def main():
     if screen_ms >= 0 and (args.binsize, args.samples, args.refsize) == (15000, 100, 300) \
             and os.path.exists(tpath):
         tj = json.load(open(tpath))
-        roofline["traffic"] = tj["fetch_bytes_per_step_corrected_x2"] + tj["write_bytes_per_step"]
+        roofline["traffic"] = tj["fetch_bytes_per_sweep_corrected_x2"] + tj["write_bytes_per_sweep"]
         roofline["traffic_source"] = "profiles/r01/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
-                                     "WRITE_SIZE; bytes per screen sweep = 15 chunk launches)"
+                                     "WRITE_SIZE; bytes per screen sweep = the chunk launches of one search)"
     roofline["null_ratios_ms"] = float(np.mean(nr_ms))
     roofline["normalize_ms"] = float(np.mean(norm_ms)) if norm_ms else None
 
