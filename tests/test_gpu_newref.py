@@ -178,3 +178,54 @@ def test_large_refsize(nt, k):
     ids = list(range(20))
     np.testing.assert_allclose(nt.get_null_ratios(X, idx, 0, cum[-1], ids),
                                O.null_ratios(X, idx, 0, cum[-1], ids), rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("S", [12, 13, 28, 29, 108, 109, 124, 125, 156, 253, 444, 508])
+def test_screen_k_step_boundaries(nt, S):
+    """Every instantiated K = 16*NK of the screen kernel, at the S values where the four augmented
+    columns (norm / threshold) just fit or spill into the next k-step."""
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([800, 700, 600, 500], S, seed=S)
+    k = 50
+    rows = [(0, 130), (790, 930), (cum[-1] - 140, cum[-1])]
+    Xc = np.ascontiguousarray(np.asarray(X).T)
+    for s, e in rows:
+        idx, dist = nt.get_ref_for_rows(X, cum, k, s, e, mode=2)
+        oi, od = CO.get_reference_rows(Xc, cum, s, e, k)
+        assert np.array_equal(idx, oi)
+        assert np.array_equal(dist, od)
+
+
+def test_beyond_screen_sample_limit_falls_back_to_exact(nt):
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([900, 700, 500], 510, seed=3)
+    idx, dist = nt.get_ref_for_rows(X, cum, 30, 100, 200)          # mode 0: auto
+    oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, 100, 200, 30)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+
+
+def test_null_ratios_nan_duplicates_and_ties(nt):
+    """Rank-based medians: NaN in a null sample propagates like np.median, index rows made of one
+    or two repeated bins (more than 64 equal ranks in a bucket), tied values, -0.0."""
+    rng = np.random.default_rng(5)
+    B, S, k = 700, 11, 90
+    X = np.asfortranarray(1.0 + 0.1 * rng.standard_normal((B, S)))
+    X[17, 3] = np.nan
+    X[40:60, 5] = 1.25                 # ties inside a sample
+    X[61, 6] = -0.0
+    X[62, 6] = 0.0
+    idx = rng.integers(0, B - 50, (B, k)).astype(np.int32)
+    idx[0, :] = 17                     # all NaN for sample 3, constant otherwise
+    idx[1, :] = 5                      # one bin repeated
+    idx[2, :45] = 7
+    idx[2, 45:] = 9                    # two bins, half / half: median = mean of the two values
+    idx[3, :70] = -1                   # padding wraps to the last bin
+    idx[4, :] = np.arange(40, 40 + k)  # covers the tie block
+    idx[5, :] = np.where(np.arange(k) % 2 == 0, 61, 62)
+    ids = list(range(S))
+    nr = nt.get_null_ratios(X, idx, 0, B, ids)
+    with np.errstate(all="ignore"):
+        onr = O.null_ratios(X, idx, 0, B, ids)
+    np.testing.assert_allclose(nr, onr, rtol=1e-12, atol=1e-13, equal_nan=True)
+    assert np.isnan(nr[0, 3]) and not np.isnan(nr[0, 2])
