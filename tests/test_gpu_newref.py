@@ -229,3 +229,16 @@ def test_null_ratios_nan_duplicates_and_ties(nt):
         onr = O.null_ratios(X, idx, 0, B, ids)
     np.testing.assert_allclose(nr, onr, rtol=1e-12, atol=1e-13, equal_nan=True)
     assert np.isnan(nr[0, 3]) and not np.isnan(nr[0, 2])
+
+
+@pytest.mark.parametrize("segments", ["2", "4"])
+def test_candidate_segments(nt, segments, monkeypatch):
+    """Row shards of a multi-GPU build have few target blocks: the sweep is then split over
+    candidate segments with separate shortlists that are merged before the refine."""
+    from wisecondorx_amd.synth import corrected_matrix
+    monkeypatch.setenv("WCX_SCREEN_SEGMENTS", segments)
+    X, mbpc, cum = corrected_matrix([900, 800, 700, 600, 500], 40, seed=17)
+    X = np.array(X, order="F")
+    X[11] = np.nan
+    _check_vs_c(nt, X, cum, 120, 0, cum[-1], 2)
+    _check_vs_c(nt, X, cum, 120, 850, 1900, 2)

@@ -325,6 +325,20 @@ struct ScreenBlock {
   int64_t cs, ce;
 };
 
+// Error budget of one target row (see the file header): na = |a~|^2 as encoded, E, Q.
+// |computed t - exact hi-plane t| <= Q: fp32 accumulation of the 16 NK products (data columns
+// + the nb'/2 and G'/2 columns: sum |x y| <= N_a N_max + (N_a + N_max)^2), the rounding of
+// t = G' - 2 acc, and nb - nb' < 2^-21 nb + 4.  gamma = (16 NK + 8) 2^-23.
+__device__ __forceinline__ void row_budget(const RowInfo &ti, float e_max, float N_max, float gamma,
+                                           float &na, float &E, float &Q) {
+  na = ti.nb;
+  E = up(ti.e + e_max);
+  const float nsum = ti.N + N_max;
+  Q = up(2.f * gamma * ti.N * N_max + 4.8e-7f * (ti.N * ti.N + 2.f * N_max * N_max) +
+         2.2f * gamma * nsum * nsum + 4.f);
+}
+constexpr float G_INIT = 3.0e38f;   // "no threshold yet" (finite on purpose)
+
 // Wave-level shortlist compaction of one target of this wave, in two halves so that a burst of
 // compactions can have the NEXT target's 8 KB in flight while the current one is processed.
 // Shortlist entries are (float bits of t, sweep position).
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
     const ScreenBlock *__restrict__ blocks, int k, int64_t row_begin,
     uint2 *__restrict__ sl, int *__restrict__ cnt_out, unsigned int *__restrict__ flags,
     float *__restrict__ g_state, int64_t gi_begin, int64_t gi_end, int first, int last,
-    unsigned long long *__restrict__ stats, int dbg) {
+    unsigned long long *__restrict__ stats, int dbg, int n_seg, int64_t n_rows_all) {
   // The candidate sweep is cut into chunks [gi_begin,gi_end) of groups, one launch per chunk:
   // every workgroup of a launch streams the SAME few MB of candidate fragments, which therefore
   // come out of the XCD L2s instead of HBM/MALL.  Per-target state (threshold G, shortlist
@@ -442,15 +456,21 @@ __global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
   int *glist = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16);       // [groups of the chunk]
   __shared__ int s_nlist;
 
-  const ScreenBlock blk = blocks[blockIdx.x];
+  // Candidate segments: with few target blocks (a row shard of a multi-GPU build) every block is
+  // issued n_seg times; copy `seg` sweeps the candidate groups g = seg (mod n_seg) into its own
+  // shortlists / thresholds (arrays offset by seg * n_rows_all); k_merge_segments joins them.
+  const int n_blocks = (int)gridDim.x / n_seg;
+  const int seg = (int)blockIdx.x / n_blocks;
+  const ScreenBlock blk = blocks[(int)blockIdx.x - seg * n_blocks];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tl = wave * 32 + (lane & 31);        // local target of this lane
   const int hf = lane >> 5;
   const bool tvalid = tl < blk.nrows;
   const int64_t trow = tvalid ? blk.row0 + tl : blk.row0;
-  const int64_t srow = trow - row_begin;
-  const int64_t wg_srow = blk.row0 - row_begin;
+  const int64_t soff = (int64_t)seg * n_rows_all;
+  const int64_t srow = trow - row_begin + soff;
+  const int64_t wg_srow = blk.row0 - row_begin + soff;
   uint2 *wg_sl = sl + wg_srow * (int64_t)CAP;    // this workgroup's TGT shortlists (uniform base)
 
   // Visit list of this launch's chunk, built once per workgroup in LDS: groups holding only
@@ -463,7 +483,7 @@ __global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
       const int64_t g = g0 + lane;
       unsigned int m = blkbit;
       if (g < gi_end) m = gmask[(g * GR) >> 6];
-      const bool keep = (g < gi_end) && m != blkbit;
+      const bool keep = (g < gi_end) && m != blkbit && ((int)g & (n_seg - 1)) == seg;
       const unsigned long long bal = __ballot(keep);
       if (keep) glist[count + __popcll(bal & ((1ull << lane) - 1ull))] =
           (int)g | ((m & blkbit) ? (int)0x80000000 : 0);
@@ -483,16 +503,8 @@ __global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
     for (int ks = 0; ks < NK; ++ks) th[ks] = F[(ttile * NK + ks) * 64 + trl + 32 * hf];
   }
   const float e_max = __uint_as_float(glob->e_max), N_max = __uint_as_float(glob->N_max);
-  const float na = ti.nb;
-  const float E = up(ti.e + e_max);
-  const float gamma = (float)(16 * NK + 8) * 1.1920929e-7f;   // n * 2^-23
-  // |computed t - exact hi-plane t| <= Q: fp32 accumulation of the 16 NK products (data columns
-  // + the nb'/2 and G'/2 columns: sum |x y| <= N_a N_max + (N_a + N_max)^2), the rounding of
-  // t = G' - 2 acc, and nb - nb' < 2^-21 nb + 4.
-  const float nsum = ti.N + N_max;
-  const float Q = up(2.f * gamma * ti.N * N_max + 4.8e-7f * (ti.N * ti.N + 2.f * N_max * N_max) +
-                     2.2f * gamma * nsum * nsum + 4.f);
-  constexpr float G_INIT = 3.0e38f;   // "no threshold yet" (finite on purpose)
+  float na, E, Q;
+  row_budget(ti, e_max, N_max, (float)(16 * NK + 8) * 1.1920929e-7f, na, E, Q);
   float G = tvalid ? (first ? G_INIT : g_state[srow]) : -HUGE_VALF;
   float Gp;
   {
@@ -717,6 +729,40 @@ __global__ void k_mark(unsigned char *searched, const ScreenBlock *__restrict__ 
   if ((int)threadIdx.x < b.nrows) searched[b.row0 - row_begin + threadIdx.x] = 1;
 }
 
+// Joins the shortlists of candidate segments s0 and s1 of every row into s0's: exact cut of the
+// union at its k-th smallest screen value (every row's true neighbours are in the union of the
+// segments' own top lists).  One wave per row.
+__global__ __launch_bounds__(NT) void k_merge_segments(
+    const RowInfo *__restrict__ info, const ScreenGlobals *__restrict__ glob,
+    const int *__restrict__ rowpos, int64_t row_begin, int64_t n_rows,
+    const unsigned char *__restrict__ searched, uint2 *__restrict__ sl, int *__restrict__ cnt,
+    unsigned int *__restrict__ flags, int s0, int s1, int k, float gamma) {
+  const int lane = wcx::lane_id();
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  const float e_max = __uint_as_float(glob->e_max), N_max = __uint_as_float(glob->N_max);
+  for (int64_t r = w0; r < n_rows; r += nw) {
+    if (!searched[r]) continue;
+    const int64_t i0 = (int64_t)s0 * n_rows + r, i1 = (int64_t)s1 * n_rows + r;
+    const int n0 = cnt[i0], n1 = cnt[i1];
+    if (flags[i0] | flags[i1] | (unsigned int)(n0 + n1 > CAP)) {   // -> exact fallback
+      if (lane == 0) flags[i0] = 1u;
+      continue;
+    }
+    uint2 raw[CAP / 64];
+#pragma unroll
+    for (int q = 0; q < CAP / 64; ++q) {
+      const int e = q * 64 + lane;
+      raw[q] = e < n0 ? sl[i0 * CAP + e] : sl[i1 * CAP + (e - n0 < CAP ? e - n0 : 0)];
+    }
+    float na, E, Q;
+    row_budget(info[rowpos[row_begin + r]], e_max, N_max, gamma, na, E, Q);
+    int n_new;
+    (void)compact_loaded(raw, n0 + n1, sl + i0 * CAP, k, na, E, Q, G_INIT, &flags[i0], true, n_new);
+    if (lane == 0) cnt[i0] = n_new;
+  }
+}
+
 }  // namespace
 
 // Host side --------------------------------------------------------------------------------
@@ -763,6 +809,13 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       i = j;
     }
   }
+  // candidate segments: fill the chip when a row shard has few target blocks (multi-GPU builds)
+  int n_seg = 1;
+  if (blocks.size() < 512) n_seg = 2;      // measured: 2 helps below ~500 blocks, 4 never does
+  if (const char *e = getenv("WCX_SCREEN_SEGMENTS")) {   // testing / tuning: 1, 2 or 4
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) n_seg = v;
+  }
   // scratch layout
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
@@ -781,10 +834,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_cell = carve((size_t)NCELL * 4);
   const size_t o_curs = carve((size_t)NCELL * 4);
   const size_t o_gmsk = carve((size_t)n_groups * 4);
-  const size_t o_sl = carve((size_t)n_rows * CAP * 8);
-  const size_t o_cnt = carve((size_t)n_rows * 4);
-  const size_t o_gst = carve((size_t)n_rows * 4);
-  const size_t o_flag = carve((size_t)n_rows * 4);
+  const size_t o_sl = carve((size_t)n_seg * n_rows * CAP * 8);
+  const size_t o_cnt = carve((size_t)n_seg * n_rows * 4);
+  const size_t o_gst = carve((size_t)n_seg * n_rows * 4);
+  const size_t o_flag = carve((size_t)n_seg * n_rows * 4);
   const size_t o_srch = carve((size_t)n_rows);
   const size_t o_blk = carve(blocks.size() * sizeof(ScreenBlock));
   void *scr = nullptr;
@@ -813,8 +866,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
 
   hipStream_t st = ctx->stream;
   WCX_HIP(hipMemsetAsync(glob, 0, sizeof(ScreenGlobals), st));
-  WCX_HIP(hipMemsetAsync(cnt_out, 0, (size_t)n_rows * 4, st));
-  WCX_HIP(hipMemsetAsync(flags, 0, (size_t)n_rows * 4, st));
+  WCX_HIP(hipMemsetAsync(cnt_out, 0, (size_t)n_seg * n_rows * 4, st));
+  WCX_HIP(hipMemsetAsync(flags, 0, (size_t)n_seg * n_rows * 4, st));
   WCX_HIP(hipMemsetAsync(searched, 0, (size_t)n_rows, st));
   WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, st));
   rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
@@ -863,9 +916,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     for (int64_t g0 = 0; g0 < n_iter_groups; g0 += chunk_groups) {                             \
       const int64_t g1 = g0 + chunk_groups < n_iter_groups ? g0 + chunk_groups : n_iter_groups; \
-      k_screen<N, G><<<(unsigned)blocks.size(), NT, lds, st>>>(                                \
+      k_screen<N, G><<<(unsigned)(blocks.size() * n_seg), NT, lds, st>>>(                                \
           F, info, glob, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out, flags,      \
-          g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats, wcx_debug_value);       \
+          g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats, wcx_debug_value, n_seg,   \
+          n_rows);                                                                             \
     }                                                                                          \
   } break;
   if ((wcx_debug_value & 4) && NK == 7) {
@@ -878,9 +932,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int64_t g0 = 0; g0 < n_iter_groups; g0 += chunk_groups) {
       const int64_t g1 = g0 + chunk_groups < n_iter_groups ? g0 + chunk_groups : n_iter_groups;
-      k_screen<7, 2, true><<<(unsigned)blocks.size(), NT, lds, st>>>(
+      k_screen<7, 2, true><<<(unsigned)(blocks.size() * n_seg), NT, lds, st>>>(
           F, info, glob, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out, flags,
-          g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats, wcx_debug_value);
+          g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats, wcx_debug_value, n_seg,
+          n_rows);
     }
   } else
   switch (NK) {
@@ -891,6 +946,14 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     default: WCX_SCREEN_CASE(32, 1)
   }
 #undef WCX_SCREEN_CASE
+  if (n_seg > 1) {
+    const float gamma = (float)(16 * NK + 8) * 1.1920929e-7f;
+    const unsigned gm = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
+    for (int step = 1; step < n_seg; step *= 2)
+      for (int s0 = 0; s0 + step < n_seg; s0 += 2 * step)
+        k_merge_segments<<<gm, NT, 0, st>>>(info, glob, rowpos, row_begin, n_rows, searched, sl,
+                                            cnt_out, flags, s0, s0 + step, k, gamma);
+  }
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_screen");
   if (rc) return rc;
