@@ -82,21 +82,50 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y,
   const int tid = threadIdx.x;
   const int p = perm0 + blockIdx.x;
   const unsigned long long s0 = mix64(seed ^ ((unsigned long long)p * 0xd1342543de82ef95ull));
-  for (int i = tid; i < npad; i += NTP) {
-    unsigned int key = 0xffffffffu;
-    if (i < n) key = ((unsigned int)(mix64(s0 + (unsigned long long)i) >> (32 + ibits)) << ibits) | (unsigned int)i;
-    sk[i] = key;
-  }
-  for (int size = 2; size <= npad; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+  // Random permutation = order of the hashed keys (unique: the index sits in the low bits).  The
+  // keys are uniform, so a bucket sort on their leading bits is O(n): count, scan, scatter (keys
+  // are re-hashed, no second array), then an insertion sort of the ~16 keys of each bucket --
+  // the same permutation as a full sort of the keys at a tenth of the LDS traffic.
+  unsigned int *bc = sk + npad;                       // [nbk] bucket counters / cursors
+  const int nbk = npad >= 1024 ? npad / 16 : (npad >= 16 ? npad / 16 : 1);
+  int lb = 0;
+  while ((1 << lb) < nbk) ++lb;
+  auto key_of = [&](int i) {
+    return ((unsigned int)(mix64(s0 + (unsigned long long)i) >> (32 + ibits)) << ibits) | (unsigned int)i;
+  };
+  auto bucket_of = [&](unsigned int key) { return lb ? (int)(key >> (32 - lb)) : 0; };
+  for (int b = tid; b < nbk; b += NTP) bc[b] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += NTP) atomicAdd(&bc[bucket_of(key_of(i))], 1u);
+  __syncthreads();
+  {   // exclusive scan of the bucket counts (nbk <= NTP)
+    __shared__ unsigned int iscan[NTP];
+    const unsigned int mine = tid < nbk ? bc[tid] : 0u;
+    iscan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < NTP; off <<= 1) {
+      const unsigned int v = tid >= off ? iscan[tid - off] : 0u;
       __syncthreads();
-      for (int t = tid; t < (npad >> 1); t += NTP) {
-        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-        const bool asc = ((lo & size) == 0);
-        const unsigned int a = sk[lo], b = sk[hi];
-        if ((b < a) == asc) { sk[lo] = b; sk[hi] = a; }
-      }
+      iscan[tid] += v;
+      __syncthreads();
     }
+    if (tid < nbk) bc[tid] = iscan[tid] - mine;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += NTP) {
+    const unsigned int key = key_of(i);
+    sk[atomicAdd(&bc[bucket_of(key)], 1u)] = key;     // afterwards bc[b] = end of bucket b
+  }
+  __syncthreads();
+  for (int b = tid; b < nbk; b += NTP) {
+    const int lo = b ? (int)bc[b - 1] : 0, hi = (int)bc[b];
+    for (int i = lo + 1; i < hi; ++i) {
+      const unsigned int kx = sk[i];
+      int j = i - 1;
+      while (j >= lo && sk[j] > kx) { sk[j + 1] = sk[j]; --j; }
+      sk[j + 1] = kx;
+    }
+  }
   __syncthreads();
   const unsigned int imask = (1u << ibits) - 1u;
   // weighted mean of the permuted series: sum_i w_i (y_pi(i) / rw_i) = sum_i rw_i y_pi(i)
@@ -373,10 +402,10 @@ int cbs_test(wcx_ctx *ctx, CbsWork &wk, const double *x, const double *w, int n,
   const int batch = 256;
   std::vector<float> hout(batch);
   WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cbs_perm),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, npad * 4));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, npad * 4 + (npad / 16 + 1) * 4));
   for (int p0 = 0; p0 < P.nperm && significant; p0 += batch) {
     const int nb = P.nperm - p0 < batch ? P.nperm - p0 : batch;
-    k_cbs_perm<<<nb, NTP, (size_t)npad * 4, st>>>(wk.dy, wk.drw, wk.dWpf, n, npad, ibits, P.minw,
+    k_cbs_perm<<<nb, NTP, (size_t)npad * 4 + (size_t)(npad / 16 + 1) * 4, st>>>(wk.dy, wk.drw, wk.dWpf, n, npad, ibits, P.minw,
                                                   P.kmax, hybrid ? 1 : 0,
                                                   P.seed ^ (test_id * 0x2545f4914f6cdd1dull), p0,
                                                   wk.dout);
@@ -400,11 +429,39 @@ int cbs_test(wcx_ctx *ctx, CbsWork &wk, const double *x, const double *w, int n,
 }
 
 // ------------------------------------------------------------------ a17 segment z
-__global__ __launch_bounds__(128) void k_segment_z(const double *__restrict__ r,
-                                                   const double *__restrict__ w,
-                                                   const double *__restrict__ nr, int m,
-                                                   const int64_t *__restrict__ bin0,
-                                                   const int64_t *__restrict__ bin1,
+// Segment z in two steps so that long segments (a whole chromosome = 16 k bins at 15 kb) do not
+// serialise on one workgroup: per-chunk partial weighted sums of every null column (chunks of
+// <= SZ_CHUNK bins, accumulated in bin order), then one workgroup per segment adds its chunks in
+// order -- deterministic, the same association for every launch.
+constexpr int SZ_CHUNK = 256;
+
+__global__ __launch_bounds__(128) void k_segz_partial(const double *__restrict__ r,
+                                                      const double *__restrict__ w,
+                                                      const double *__restrict__ nr, int m,
+                                                      const int64_t *__restrict__ cb0,
+                                                      const int64_t *__restrict__ cb1,
+                                                      double *__restrict__ pnum,
+                                                      double *__restrict__ pden,
+                                                      int *__restrict__ pany) {
+  const int c = blockIdx.x;
+  const int j = threadIdx.x;
+  if (j >= m) return;
+  double num = 0.0, den = 0.0;
+  int any = 0;
+  for (int64_t b = cb0[c]; b < cb1[c]; ++b) {
+    if (r[b] == 0.0) continue;                      // overall_tools.py:98-100
+    const double v = nr[b * m + j];
+    if (fabs(v) < HUGE_VAL) { num += v * w[b]; den += w[b]; any = 1; }   // :101-110
+  }
+  pnum[(int64_t)c * m + j] = num;
+  pden[(int64_t)c * m + j] = den;
+  pany[(int64_t)c * m + j] = any;
+}
+
+__global__ __launch_bounds__(128) void k_segment_z(const double *__restrict__ pnum,
+                                                   const double *__restrict__ pden,
+                                                   const int *__restrict__ pany, int m,
+                                                   const int *__restrict__ chunk0,
                                                    const double *__restrict__ seg_r, int n_seg,
                                                    double *__restrict__ out_z,
                                                    double *__restrict__ out_nnull) {
@@ -416,10 +473,10 @@ __global__ __launch_bounds__(128) void k_segment_z(const double *__restrict__ r,
   if (j < m) {
     double num = 0.0, den = 0.0;
     bool any = false;
-    for (int64_t b = bin0[s]; b < bin1[s]; ++b) {
-      if (r[b] == 0.0) continue;                      // overall_tools.py:98-100
-      const double v = nr[b * m + j];
-      if (fabs(v) < HUGE_VAL) { num += v * w[b]; den += w[b]; any = true; }   // :101-110
+    for (int c = chunk0[s]; c < chunk0[s + 1]; ++c) {
+      num += pnum[(int64_t)c * m + j];
+      den += pden[(int64_t)c * m + j];
+      any |= pany[(int64_t)c * m + j] != 0;
     }
     if (any) a = num / den;
   }
@@ -606,30 +663,52 @@ int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *
     WCX_ARG(b0[s] >= chr_off[c] && b1[s] <= chr_off[c + 1] && b0[s] <= b1[s], "segment out of range");
     sr[s] = seg[s * 4 + 3];
   }
+  // chunk table: segment s owns chunks [chunk0[s], chunk0[s+1])
+  std::vector<int64_t> cb0, cb1;
+  std::vector<int> chunk0(n_seg + 1);
+  for (int s = 0; s < n_seg; ++s) {
+    chunk0[s] = (int)cb0.size();
+    for (int64_t b = b0[s]; b < b1[s]; b += SZ_CHUNK) {
+      cb0.push_back(b);
+      cb1.push_back(std::min<int64_t>(b + SZ_CHUNK, b1[s]));
+    }
+  }
+  chunk0[n_seg] = (int)cb0.size();
+  const size_t n_chunks = cb0.size();
   const size_t vb = (size_t)nb * 8, nrb = attached ? 0 : (size_t)nb * m * 8, sb = (size_t)n_seg * 8;
+  const size_t cb = (n_chunks + 1) * 8, pb = (n_chunks + 1) * (size_t)m * 8;
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, 2 * vb + nrb + 5 * sb + 1024, &scr);
+  int rc = wcx_scratch(ctx, 2 * vb + nrb + 4 * sb + 2 * cb + 3 * pb + 4096, &scr);
   if (rc) return rc;
   char *p = reinterpret_cast<char *>(scr);
   double *dr = (double *)p; p += vb;
   double *dw = (double *)p; p += vb;
   double *dnr = (double *)p; p += nrb;
-  int64_t *db0 = (int64_t *)p; p += sb;
-  int64_t *db1 = (int64_t *)p; p += sb;
   double *dsr = (double *)p; p += sb;
   double *dz = (double *)p; p += sb;
-  double *dn = (double *)p;
+  double *dn = (double *)p; p += sb;
+  int *dchunk0 = (int *)p; p += sb + 8;
+  int64_t *dcb0 = (int64_t *)p; p += cb;
+  int64_t *dcb1 = (int64_t *)p; p += cb;
+  double *dpnum = (double *)p; p += pb;
+  double *dpden = (double *)p; p += pb;
+  int *dpany = (int *)p;
   hipStream_t st = ctx->stream;
   WCX_HIP(hipMemcpyAsync(dr, r, vb, hipMemcpyHostToDevice, st));
   WCX_HIP(hipMemcpyAsync(dw, w, vb, hipMemcpyHostToDevice, st));
   if (!attached) WCX_HIP(hipMemcpyAsync(dnr, nr, nrb, hipMemcpyHostToDevice, st));
-  WCX_HIP(hipMemcpyAsync(db0, b0.data(), sb, hipMemcpyHostToDevice, st));
-  WCX_HIP(hipMemcpyAsync(db1, b1.data(), sb, hipMemcpyHostToDevice, st));
   WCX_HIP(hipMemcpyAsync(dsr, sr.data(), sb, hipMemcpyHostToDevice, st));
+  WCX_HIP(hipMemcpyAsync(dchunk0, chunk0.data(), (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, st));
+  if (n_chunks) {
+    WCX_HIP(hipMemcpyAsync(dcb0, cb0.data(), n_chunks * 8, hipMemcpyHostToDevice, st));
+    WCX_HIP(hipMemcpyAsync(dcb1, cb1.data(), n_chunks * 8, hipMemcpyHostToDevice, st));
+  }
   rc = wcx_timer_begin(ctx, "segment_z");
   if (rc) return rc;
-  k_segment_z<<<n_seg, 128, 0, st>>>(dr, dw, attached ? ctx->d_nullm : dnr, m, db0, db1, dsr, n_seg,
-                                     dz, dn);
+  if (n_chunks)
+    k_segz_partial<<<(unsigned)n_chunks, 128, 0, st>>>(dr, dw, attached ? ctx->d_nullm : dnr, m, dcb0,
+                                                       dcb1, dpnum, dpden, dpany);
+  k_segment_z<<<n_seg, 128, 0, st>>>(dpnum, dpden, dpany, m, dchunk0, dsr, n_seg, dz, dn);
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "segment_z");
   if (rc) return rc;
