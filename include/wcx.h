@@ -40,8 +40,10 @@ typedef struct wcx_ctx wcx_ctx; /* one per (process, GPU): device id, stream, sc
 typedef struct wcx_ref wcx_ref; /* a reference (indexes/distances) resident in HBM    */
 
 int wcx_version(void);
-/* Diagnostics only: ablation switches used by the profiling scripts (0 = normal operation;
- * any other value makes results INVALID).  Returns the previous value. */
+/* Diagnostics only: switches used by the profiling scripts (0 = normal operation).  4 = per-phase
+ * cycle accounting of the screen kernel (results stay valid, ~20 % slower); 1 (no shortlist
+ * appends), 16 / 64 (null ratios without gathers / without selection) are ablations whose results
+ * are INVALID; bits 8.. = compaction trigger level.  Returns the previous value. */
 int wcx_debug_flags(int flags);
 const char *wcx_last_error(void); /* thread-local, never NULL */
 
@@ -90,7 +92,8 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
  * log2(X[row_begin+r][sid[m]] / median_k X[idx[r][k]][sid[m]]), the index row applied to the
  * FULL bin vector without re-offsetting (reference quirk, newref_tools.py:219-221; index -1
  * wraps to the last bin as in NumPy).  sample_ids are chosen by the host (random.sample,
- * newref_tools.py:214-217).  idx int32[n][k]; out double[n][n_ids]. */
+ * newref_tools.py:214-217).  idx int32[n][k]; out double[n][n_ids].  Limits: n_ids <= 128
+ * (the reference uses min(S, 100)), B < 2^25, n_ids * B < 2^31, k <= 2048. */
 int wcx_null_ratios(wcx_ctx *ctx, const double *Xs, int64_t B, int S, const int32_t *idx,
                     int64_t row_begin, int64_t row_end, int k, const int32_t *sample_ids,
                     int n_ids, double *out);
