@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--samples", type=int, default=100)
     ap.add_argument("--batch", type=int, default=96)
     ap.add_argument("--cbs-samples", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=4, help="host threads / HIP streams for the CBS stage")
     a = ap.parse_args()
     import bench
     from wisecondorx_amd import _lib, newref_tools, predict_tools as pt
@@ -71,6 +72,21 @@ def main():
         t_segz += time.perf_counter() - t
         n_seg.append(len(segs))
     m = max(1, min(a.cbs_samples, a.batch))
+    # the same stage for the WHOLE batch, samples striped over --streams contexts (own streams)
+    ctxs = [ctx] + [_lib.Context(0) for _ in range(a.streams - 1)]
+    for c in ctxs[1:]:
+        pt.attach_null_matrix([nr_full[off[c2]:off[c2 + 1]] for c2 in range(len(off) - 1)], c)
+
+    def post(i):
+        res = {"results_r": r[i], "results_z": z[i] - mz[i], "results_w": w / np.nanmean(w)}
+        for kk in res:
+            res[kk] = pt.get_post_processed_result(args, res[kk], n[i], rem)
+        res["results_nr"] = pt.ATTACHED
+        pt.log_trans(res, mlr[i])
+        return res
+    t = time.perf_counter()
+    all_segs = pt.segment_batch(list(range(a.batch)), rem, ctxs, post=post)
+    t_batch = time.perf_counter() - t
     print(json.dumps({
         "workload": "predict batch: {} samples, {} kb bins, B={}, k=300".format(a.batch, a.binsize // 1000, cum[-1]),
         "newref_host_api_s": t_newref, "host_prep_per_sample_ms": 1e3 * t_host_prep / a.batch,
@@ -78,7 +94,10 @@ def main():
         "normalize_batch_s": t_norm, "normalize_kernels_ms": norm_kernel_ms,
         "normalize_per_sample_ms": 1e3 * t_norm / a.batch,
         "postprocess_per_sample_ms": 1e3 * t_post / m, "cbs_per_sample_s": t_cbs / m,
-        "segment_z_per_sample_ms": 1e3 * t_segz / m, "segments": n_seg}))
+        "segment_z_per_sample_ms": 1e3 * t_segz / m, "segments": n_seg,
+        "streams": a.streams, "post_cbs_segz_whole_batch_s": t_batch,
+        "post_cbs_segz_per_sample_ms_threaded": 1e3 * t_batch / a.batch,
+        "batch_segments": int(sum(len(x) for x in all_segs))}))
 
 
 if __name__ == "__main__":

@@ -303,3 +303,30 @@ def exec_cbs(rem_input, results, ctx=None):
                         rem_input["binsize"], rem_input["args"].seed, ctx)
     segment_z = get_z_score(results_c, results, ctx)
     return [results_c[i][:3] + [segment_z[i]] + [results_c[i][3]] for i in range(len(results_c))]
+
+
+def segment_batch(results_list, rem_input, contexts, post=None):
+    """Config 5: CBS + segment z of a batch of samples, striped over `contexts`
+    (one per HIP stream / device; each needs its null matrix attached) from host threads -- ctypes
+    releases the GIL, so one sample's host post-processing overlaps another's kernels.
+    results_list[i] is either a finished results dict or the argument of `post(i)` -> dict.
+    Returns [results_c, ...] in input order."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def work(t):
+        ctx = contexts[t]
+        out = []
+        for i in range(t, len(results_list), len(contexts)):
+            res = post(i) if post is not None else results_list[i]
+            segs = run_cbs(res, rem_input["ref_gender"], rem_input["args"].alpha,
+                           rem_input["binsize"], rem_input["args"].seed, ctx)
+            zs = get_z_score(segs, res, ctx)
+            out.append((i, [[s[0], s[1], s[2], zs[j], s[3]] for j, s in enumerate(segs)]))
+        return out
+    results = [None] * len(results_list)
+    with ThreadPoolExecutor(max_workers=len(contexts)) as ex:
+        for part in ex.map(work, range(len(contexts))):
+            for i, rows in part:
+                results[i] = rows
+    return results
+
