@@ -242,3 +242,34 @@ def test_candidate_segments(nt, segments, monkeypatch):
     X[11] = np.nan
     _check_vs_c(nt, X, cum, 120, 0, cum[-1], 2)
     _check_vs_c(nt, X, cum, 120, 850, 1900, 2)
+
+
+def test_config2_full_size_15kb(nt):
+    """BASELINE config[2] shape (15 kb bins, ~180 k rows, S=100, k=300) on the MFMA screen path:
+    size-independent properties on ALL rows + bit-exact oracle agreement (indices, distances,
+    null ratios) on a row subsample spread over every chromosome."""
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd.synth import bins_per_chr, corrected_matrix
+    bpc = [int(b * 0.95) for b in bins_per_chr(15000)[:22]]
+    X, mbpc, cum = corrected_matrix(bpc, 100, seed=15)
+    B, k = cum[-1], 300
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, B, mode=2)
+    st = _lib.default_context().topk_stats()
+    assert st["rows"] == B and st["fallback_rows"] == 0
+    assert (np.diff(dist, axis=1) >= 0).all()                      # ascending
+    assert (idx >= 0).all()
+    own = np.repeat(np.array(mbpc), np.array(mbpc))
+    assert (idx < (B - own)[:, None]).all()                        # chr-excluded index space
+    Xs = np.ascontiguousarray(X.T)
+    rng = np.random.default_rng(1)
+    rows = np.concatenate([rng.integers(cum[c - 1] if c else 0, cum[c], 3) for c in range(22)])
+    for t in rows:
+        c = int(np.searchsorted(cum, t, side="right"))
+        cs = cum[c - 1] if c else 0
+        oi, od = CO.topk_rows(Xs, cs, cum[c], int(t), int(t) + 1, k)
+        assert np.array_equal(idx[t], oi[0]) and np.array_equal(dist[t], od[0])
+    ids = list(range(0, 100, 7))
+    r0 = int(cum[10]) - 40
+    nr = nt.get_null_ratios(X, idx[r0:r0 + 80], r0, r0 + 80, ids)
+    np.testing.assert_allclose(nr, O.null_ratios(X, idx[r0:r0 + 80], r0, r0 + 80, ids),
+                               rtol=1e-12, atol=1e-13)
