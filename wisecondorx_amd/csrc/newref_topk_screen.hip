@@ -5,26 +5,31 @@
 // Pipeline (all on one stream):
 //   k_col_stats    per-sample mean c_j and max |x - c_j|           (centring + fp16 scale)
 //   k_transpose    Xs [S][B] -> Xr [B][S]                           (rows contiguous for refine)
-//   k_screen_prep  a = 2^p (x - c) split into fp16 hi + lo, written in MFMA-fragment order;
-//                  per row: |a~|^2, representation error norms      (rigorous error budget)
-//   k_screen       -2 a~.b~ Gram tiles on the matrix cores: v_mfma_f32_32x32x16_f16 (hi plane;
-//                  optionally hi.hi + hi.lo + lo.hi), fp32 accumulate; targets stay in registers as the
-//                  B operand, candidates stream through LDS as the A operand; the epilogue
-//                  adds the squared norms and appends (screen distance, index) to the target's
-//                  shortlist whenever the pair could still be among the k nearest given the
-//                  error budget; shortlists are cut back by a wave-level bisection select.
+//   k_row_norm / k_row_hist / k_scan_cells / k_scatter / k_group_mask
+//                  best-first sweep order: counting sort by (norm bucket, chromosome)
+//   k_screen_prep  a~ = fp16(2^p (x - c)) in MFMA-fragment order + four augmented k-columns that
+//                  carry |a~|^2; per row: representation-error norm      (rigorous error budget)
+//   k_screen       -2 a~.b~ Gram tiles on the matrix cores: v_mfma_f32_32x32x16_f16, fp32
+//                  accumulate; targets stay in registers as the B operand (their augmented
+//                  columns carry the current threshold), candidates stream through LDS as the A
+//                  operand; the screen test is the SIGN BIT of the accumulator; passing pairs are
+//                  appended to the target's shortlist, which is cut back by a wave-level bitwise
+//                  bisection select whenever it nears capacity.
+//   k_merge_segments (row shards with few target blocks only) joins per-segment shortlists.
 //   k_refine       exact sequential fp64 distance (newref_tools.py:260 arithmetic) of every
 //                  shortlisted pair, sort by (distance, index), emit the first k.
 //   rows whose shortlist overflowed (never seen on real data) are redone by the exact kernel.
 //
-// Error budget (t = |b~|^2 - 2 g~, screen distance d~ = t + |a~|^2, all in scaled units):
+// Error budget (t = nb' - 2 g~, screen distance d~ = t + |a~|^2, all in scaled units):
 //   sqrt(d) in [sqrt(dh) - E, sqrt(dh) + E],  dh = |a~ - b~|^2,  E = e_a + e_max  (e = |a - a~|)
-//   |d~ - dh| <= Q = 2 L_a L_max + 2 gamma N_a N_max + 2^-21 (N_a^2 + N_max^2)
-//     (dropped lo.lo term; fp32 accumulation of 3*16*NK products, gamma = n 2^-23; fp32 roundings)
+//   |d~ - dh| <= Q  (fp32 accumulation of the 16 NK products incl. the augmented ones,
+//     gamma = n 2^-23; fp32 roundings; nb - nb'): see row_budget()
 //   T = (sqrt(d~_(k) + Q) + E)^2 bounds the true k-th distance; a pair can be among the k nearest
 //   only if d~ <= F = (sqrt(T) + E)^2 + Q.  Everything with d~ <= F is kept and refined exactly.
 //
-// Roofline: MFMA bound, 3 * 2*32*32*16 flop per instruction, dense f16 peak ~2.5 PFLOP/s.
+// Roofline: MFMA bound, 2*32*32*16 flop per instruction, dense f16 peak ~2.5 PFLOP/s.
+#include <cstdlib>
+
 #include "wave_sort.h"
 #include "wcx_common.h"
 #include "screen_common.h"
