@@ -1,0 +1,65 @@
+"""Seeded randomised parity sweep of the reference-bin search (MFMA screen + refine, and auto mode)
+against the C oracle: random shapes, row ranges, refsizes, and data pathologies (integer ties,
+duplicated rows, NaN / inf rows, rows scaled by orders of magnitude, constant rows)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from oracle import wcx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_chr = int(rng.integers(2, 9))
+    mb = rng.integers(150, 1400, n_chr)
+    while mb.sum() < 2100:                       # the screen path needs B >= 2048
+        mb = mb + 200
+    if seed % 5 == 0:
+        mb[int(rng.integers(0, n_chr))] = 0      # an empty chromosome
+        mb[int(np.argmax(mb))] += 1500
+    cum = np.cumsum(mb).tolist()
+    B = cum[-1]
+    S = int(rng.choice([3, 8, 12, 17, 31, 60, 100, 125, 190, 260]))
+    k = int(rng.choice([1, 5, 40, 64, 150, 300, 511]))
+    kind = seed % 4
+    if kind == 0:
+        X = rng.integers(0, 5, (B, S)).astype(np.float64)             # heavy exact ties
+    elif kind == 1:
+        X = 1.0 + 0.05 * rng.standard_normal((B, S))
+    elif kind == 2:
+        scale = rng.gamma(2.0, 0.5, B)[:, None]
+        X = 1.0 + 0.1 * scale * rng.standard_normal((B, S))           # wide spread of norms
+    else:
+        proto = rng.standard_normal((16, S))
+        X = 1.0 + 0.05 * (proto[rng.integers(0, 16, B)] + 0.3 * rng.standard_normal((B, S)))
+    X = np.asfortranarray(X)
+    for _ in range(int(rng.integers(0, 4))):
+        X[int(rng.integers(0, B)), int(rng.integers(0, S))] = rng.choice([np.nan, np.inf, -np.inf])
+    for _ in range(int(rng.integers(0, 3))):
+        X[int(rng.integers(0, B))] *= 10.0 ** float(rng.integers(-3, 4))
+    for _ in range(int(rng.integers(0, 3))):
+        X[int(rng.integers(0, B))] = X[int(rng.integers(0, B))]       # duplicated rows
+    if seed % 7 == 0:
+        X[int(rng.integers(0, B))] = 1.0                              # constant row
+    s = int(rng.integers(0, B - 200))
+    e = int(min(B, s + rng.integers(100, 900)))
+    return X, cum, k, s, e
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_search_fuzz(seed):
+    from wisecondorx_amd import newref_tools as nt
+    X, cum, k, s, e = _case(seed)
+    oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, s, e, k)
+    for mode in (2, 0):
+        idx, dist = nt.get_ref_for_rows(X, cum, k, s, e, mode=mode)
+        assert np.array_equal(idx, oi), "indices differ (seed {}, mode {})".format(seed, mode)
+        assert np.array_equal(dist, od), "distances differ (seed {}, mode {})".format(seed, mode)
+    if seed % 3 == 0:
+        ids = list(range(0, X.shape[1], max(1, X.shape[1] // 9)))
+        with np.errstate(all="ignore"):
+            want = O.null_ratios(X, oi, s, e, ids)
+        got = nt.get_null_ratios(X, idx, s, e, ids)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13, equal_nan=True)
