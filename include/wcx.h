@@ -67,6 +67,11 @@ double wcx_last_kernel_ms(wcx_ctx *ctx, const char *name);
  * [8..13] per-phase wave cycles of the screen kernel (only with wcx_debug_flags(4)), [14..15] 0. */
 int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[16]);
 
+/* Device transpose of a row-major double matrix: d_dst[c][r] = d_src[r][c] (rows < 2^21).  A
+ * multi-GPU build all-gathers row shards of the (bins x samples) matrix; this turns the result
+ * into the sample-major layout the search takes (the bytes of the reference's F-ordered array). */
+int wcx_transpose_dev(wcx_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, double *d_dst);
+
 /* ---- newref: reference-bin search ------------------------------------------------- */
 /* Replaces newref_tools.get_ref_for_bins (newref_tools.py:255-278) as driven by
  * newref_tools.get_reference (newref_tools.py:176-206) for target rows

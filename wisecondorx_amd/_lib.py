@@ -32,6 +32,7 @@ SIGNATURES = {
     "wcx_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "wcx_last_kernel_ms": (C.c_double, [vp, C.c_char_p]),
     "wcx_last_topk_stats": (C.c_int, [vp, c_i64p]),
+    "wcx_transpose_dev": (C.c_int, [vp, vp, c_i64, c_i64, vp]),
     "wcx_newref_topk": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64p, C.c_int, c_i64, c_i64,
                                   C.c_int, C.c_int, vp, vp]),
     "wcx_newref_topk_dev": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64p, C.c_int, c_i64, c_i64,

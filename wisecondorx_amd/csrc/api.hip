@@ -183,6 +183,14 @@ double wcx_last_kernel_ms(wcx_ctx *ctx, const char *name) {
   return (double)ms;
 }
 
+int wcx_transpose_dev(wcx_ctx *ctx, const double *d_src, int64_t rows, int64_t cols,
+                      double *d_dst) {
+  WCX_ARG(ctx && d_src && d_dst, "NULL argument");
+  WCX_ARG(rows > 0 && cols > 0 && rows < (1ll << 31) && (rows + 31) / 32 < 65536, "bad sizes");
+  WCX_HIP(hipSetDevice(ctx->device));
+  return wcx_transpose_launch(ctx, d_src, rows, cols, d_dst);
+}
+
 int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[16]) {
   WCX_ARG(ctx && out, "NULL argument");
   unsigned long long h[16] = {0};

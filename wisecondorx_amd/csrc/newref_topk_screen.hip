@@ -771,6 +771,15 @@ __global__ __launch_bounds__(NT) void k_merge_segments(
 }  // namespace
 
 // Host side --------------------------------------------------------------------------------
+// dst[c][r] = src[r][c] for a row-major double matrix (rows x cols), on the context's stream.
+int wcx_transpose_launch(wcx_ctx *ctx, const double *src, int64_t rows, int64_t cols, double *dst) {
+  // k_transpose reads "Xs" [S'][B'] and writes "Xr" [B'][Sp]: S' = rows, B' = cols, Sp = rows
+  k_transpose<<<dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), 256, 0,
+                ctx->stream>>>(src, cols, (int)rows, (int)rows, dst);
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
 int wcx_debug_value = 0;   // diagnostics only (wcx_debug_flags): ablation switches for profiling
 bool wcx_screen_supported(int64_t B, int S, int k) {
   return S <= 508 && k <= 512 && k <= LIM && B >= 2048;

@@ -72,6 +72,7 @@ struct wcx_ref {
 int wcx_scratch(wcx_ctx *ctx, size_t bytes, void **out);
 int wcx_scratch2(wcx_ctx *ctx, size_t bytes, void **out);
 int wcx_upload_small(wcx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int wcx_transpose_launch(wcx_ctx *ctx, const double *src, int64_t rows, int64_t cols, double *dst);
 int wcx_timer_begin(wcx_ctx *ctx, const char *name);
 int wcx_timer_end(wcx_ctx *ctx, const char *name);
 

@@ -86,6 +86,7 @@ class _GpuPredictMixin:
 
 
 class GpuBackend(_GpuPredictMixin):
+    # (see transpose() below: sample-major copy of the gathered row-major matrix)
     """Compute on this rank's MI355X through the C-ABI (device pointers).  The orchestration in this
     module interleaves torch ops (clones, all-gathers) with library calls on the same buffers, so
     the context MUST have been created on torch's current stream:
@@ -93,6 +94,16 @@ class GpuBackend(_GpuPredictMixin):
 
     def __init__(self, ctx):
         self.ctx = ctx
+
+    def transpose(self, full):
+        """[B][S] row-major -> [S][B] (tiled HIP kernel; torch's generic .t().contiguous() is 4x
+        slower on this shape)."""
+        import torch
+        from . import _lib
+        B, S = full.shape
+        out = torch.empty((S, B), dtype=full.dtype, device=full.device)
+        _lib.check(self.ctx.lib.wcx_transpose_dev(self.ctx.h, full.data_ptr(), B, S, out.data_ptr()))
+        return out
 
     def search(self, d_Xs, B, S, chr_cum, row_begin, row_end, k, sample_ids, d_idx, d_dist, d_nr,
                mode=0):
@@ -116,7 +127,9 @@ def newref_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, wo
     rows, plus the gathered sample-major matrix it was computed from."""
     import torch
     full = allgather_rows(local_rows, n_rows, world)            # the ONE exchange
-    Xs = full.t().contiguous()                                   # sample-major [S][B]
+    full = full.contiguous()
+    Xs = backend.transpose(full) if hasattr(backend, "transpose") else full.t().contiguous()
+    # ^ sample-major [S][B]
     S = Xs.shape[0]
     b, e = row_shard(rank, world, n_rows)
     n = e - b
