@@ -112,6 +112,7 @@ int wcx_ctx_create(int device, void *stream, wcx_ctx **out) {
   }
   WCX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 128));
   WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, ctx->stream));
+  WCX_HIP(hipMalloc(&ctx->d_small, 8192));
   *out = ctx;
   return WCX_OK;
 }
@@ -127,6 +128,7 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->scratch2) hipFree(ctx->scratch2);
   if (ctx->d_stats) hipFree(ctx->d_stats);
+  if (ctx->d_small) hipFree(ctx->d_small);
   if (ctx->d_nullm) hipFree(ctx->d_nullm);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -282,6 +282,95 @@ __global__ __launch_bounds__(NTM) void k_nanmedian(const double *__restrict__ a0
   }
 }
 
+// ---- nanmedian of ONE long vector pair with the whole chip ---------------------------------------
+// The single-workgroup k_nanmedian above is fine for a batch (one workgroup per sample) but for a
+// single sample it leaves one CU walking 2 x 182 k doubles nine times (0.5 ms).  Here every pass is
+// spread over many workgroups: LDS-private digit histograms -> global histogram -> a one-wave
+// "decide" kernel that advances the two rank prefixes.  state[a] = {prefix0, prefix1, rank0, rank1,
+// himask, nvalid} (as 64-bit words), hist[a][2][256].
+struct NmState { unsigned long long prefix[2]; long long rank[2]; unsigned long long himask; long long nvalid; };
+
+__global__ __launch_bounds__(256) void k_nm_count(const double *__restrict__ a0,
+                                                  const double *__restrict__ a1, int64_t n,
+                                                  NmState *__restrict__ st) {
+  const double *a = blockIdx.y ? a1 : a0;
+  long long loc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double x = a[i];
+    loc += (x == x);
+  }
+  loc = (long long)wcx::wave_sum_i((int)loc);
+  if ((threadIdx.x & 63) == 0 && loc) atomicAdd((unsigned long long *)&st[blockIdx.y].nvalid, (unsigned long long)loc);
+}
+
+__global__ void k_nm_init(NmState *__restrict__ st, unsigned int *__restrict__ hist) {
+  const int a = blockIdx.x;
+  if (threadIdx.x == 0) {
+    const long long nv = st[a].nvalid;
+    st[a].rank[0] = nv > 0 ? (nv - 1) / 2 : 0;
+    st[a].rank[1] = nv / 2;
+    st[a].prefix[0] = st[a].prefix[1] = 0;
+    st[a].himask = 0;
+  }
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[a * 512 + i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_nm_hist(const double *__restrict__ a0,
+                                                 const double *__restrict__ a1, int64_t n, int shift,
+                                                 const NmState *__restrict__ st,
+                                                 unsigned int *__restrict__ hist) {
+  const int arr = blockIdx.y;
+  const double *a = arr ? a1 : a0;
+  __shared__ unsigned int lh[2][256];
+  lh[0][threadIdx.x] = 0;
+  lh[1][threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned long long p0 = st[arr].prefix[0], p1 = st[arr].prefix[1], himask = st[arr].himask;
+  const bool two = p1 != p0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double x = a[i];
+    if (x == x) {
+      const unsigned long long kx = f64_key(x);
+      const unsigned int dg = (unsigned int)((kx >> shift) & 255ull);
+      if ((kx & himask) == p0) atomicAdd(&lh[0][dg], 1u);
+      if (two && (kx & himask) == p1) atomicAdd(&lh[1][dg], 1u);
+    }
+  }
+  __syncthreads();
+  if (lh[0][threadIdx.x]) atomicAdd(&hist[arr * 512 + threadIdx.x], lh[0][threadIdx.x]);
+  if (two && lh[1][threadIdx.x]) atomicAdd(&hist[arr * 512 + 256 + threadIdx.x], lh[1][threadIdx.x]);
+}
+
+__global__ void k_nm_decide(NmState *__restrict__ st, unsigned int *__restrict__ hist, int shift,
+                            double *__restrict__ out0, double *__restrict__ out1) {
+  const int a = blockIdx.x;
+  const bool two = st[a].prefix[1] != st[a].prefix[0];
+  if (threadIdx.x < 2) {
+    const int t = threadIdx.x;
+    const unsigned int *h = hist + a * 512 + ((t == 1 && two) ? 256 : 0);
+    long long rk = st[a].rank[t];
+    int dg = 0;
+    for (; dg < 256; ++dg) {
+      const long long c = h[dg];
+      if (rk < c) break;
+      rk -= c;
+    }
+    st[a].rank[t] = rk;
+    st[a].prefix[t] |= ((unsigned long long)dg) << shift;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[a * 512 + i] = 0;
+  if (threadIdx.x == 0) {
+    st[a].himask |= 255ull << shift;
+    if (shift == 0) {
+      double *out = a ? out1 : out0;
+      const long long nv = st[a].nvalid;
+      const double lo = key_f64(st[a].prefix[0]), hi = key_f64(st[a].prefix[1]);
+      out[0] = nv == 0 ? __builtin_nan("") : ((nv & 1) ? lo : (lo + hi) / 2.0);
+    }
+  }
+}
+
 __global__ void k_copy2(const double *__restrict__ src, double *__restrict__ a,
                         double *__restrict__ b, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -289,6 +378,25 @@ __global__ void k_copy2(const double *__restrict__ src, double *__restrict__ a,
 }
 
 }  // namespace
+
+// nanmedian of two vectors of n doubles (one sample): the multi-workgroup radix select
+static int launch_nanmedian_wide(wcx_ctx *ctx, const double *a0, const double *a1, int64_t n,
+                                 double *out0, double *out1) {
+  void *scr = ctx->d_small;
+  NmState *st = reinterpret_cast<NmState *>(scr);
+  unsigned int *hist = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(scr) + 256);
+  hipStream_t s = ctx->stream;
+  WCX_HIP(hipMemsetAsync(st, 0, 2 * sizeof(NmState), s));
+  const unsigned g = (unsigned)std::min<int64_t>(256, (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
+  k_nm_count<<<dim3(g, 2), 256, 0, s>>>(a0, a1, n, st);
+  k_nm_init<<<2, 256, 0, s>>>(st, hist);
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    k_nm_hist<<<dim3(g, 2), 256, 0, s>>>(a0, a1, n, shift, st, hist);
+    k_nm_decide<<<2, 256, 0, s>>>(st, hist, shift, out0, out1);
+  }
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
 
 extern "C" {
 
@@ -509,8 +617,13 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
     if (rc) return rc;
   }
   // m_lr = nanmedian(log2 r), m_z = nanmedian(z)   (predict_tools.py:105-106)
-  k_nanmedian<<<dim3((unsigned)n_samples, 2), NTM, 0, ctx->stream>>>(lr, d_out_z, Bp, Bp, d_out_mlr,
-                                                                      d_out_mz);
+  if (n_samples == 1) {
+    rc = launch_nanmedian_wide(ctx, lr, d_out_z, Bp, d_out_mlr, d_out_mz);
+    if (rc) return rc;
+  } else {
+    k_nanmedian<<<dim3((unsigned)n_samples, 2), NTM, 0, ctx->stream>>>(lr, d_out_z, Bp, Bp,
+                                                                        d_out_mlr, d_out_mz);
+  }
   WCX_HIP(hipGetLastError());
   return wcx_timer_end(ctx, "normalize");
 }
@@ -577,9 +690,7 @@ int wcx_nanmedian2_dev(wcx_ctx *ctx, const double *d_a0, const double *d_a1, int
                        double *d_out0, double *d_out1) {
   WCX_ARG(ctx && d_a0 && d_a1 && d_out0 && d_out1 && n >= 0, "bad argument");
   WCX_HIP(hipSetDevice(ctx->device));
-  k_nanmedian<<<dim3(1, 2), NTM, 0, ctx->stream>>>(d_a0, d_a1, n, n, d_out0, d_out1);
-  WCX_HIP(hipGetLastError());
-  return WCX_OK;
+  return launch_nanmedian_wide(ctx, d_a0, d_a1, n, d_out0, d_out1);
 }
 
 int wcx_predict_normalize(wcx_ctx *ctx, const wcx_ref *ref, const double *x, int n_samples,

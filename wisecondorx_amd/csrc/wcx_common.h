@@ -42,7 +42,8 @@ struct wcx_ctx {
   bool own_stream = false;
   std::map<std::string, KernelTimer> timers;
   int64_t topk_stats[4] = {0, 0, 0, 0};
-  unsigned long long *d_stats = nullptr;  // 4 device counters
+  unsigned long long *d_stats = nullptr;  // 16 device counters
+  void *d_small = nullptr;                // 8 KB of persistent device workspace (radix-select state)
   // growable device scratch owned by the context
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
