@@ -341,26 +341,35 @@ __global__ __launch_bounds__(256) void k_nm_hist(const double *__restrict__ a0,
   if (two && lh[1][threadIdx.x]) atomicAdd(&hist[arr * 512 + 256 + threadIdx.x], lh[1][threadIdx.x]);
 }
 
-__global__ void k_nm_decide(NmState *__restrict__ st, unsigned int *__restrict__ hist, int shift,
-                            double *__restrict__ out0, double *__restrict__ out1) {
+__global__ __launch_bounds__(512) void k_nm_decide(NmState *__restrict__ st,
+                                                    unsigned int *__restrict__ hist, int shift,
+                                                    double *__restrict__ out0,
+                                                    double *__restrict__ out1) {
+  // 512 threads: half t = 0/1 scans the histogram of rank t's prefix (a shared one if equal)
   const int a = blockIdx.x;
+  const int t = threadIdx.x >> 8, d = threadIdx.x & 255;
   const bool two = st[a].prefix[1] != st[a].prefix[0];
-  if (threadIdx.x < 2) {
-    const int t = threadIdx.x;
-    const unsigned int *h = hist + a * 512 + ((t == 1 && two) ? 256 : 0);
-    long long rk = st[a].rank[t];
-    int dg = 0;
-    for (; dg < 256; ++dg) {
-      const long long c = h[dg];
-      if (rk < c) break;
-      rk -= c;
-    }
-    st[a].rank[t] = rk;
-    st[a].prefix[t] |= ((unsigned long long)dg) << shift;
-  }
+  __shared__ long long cum[2][256];
+  const long long rk = st[a].rank[t];
+  const long long mine = hist[a * 512 + ((t == 1 && two) ? 256 : 0) + d];
+  cum[t][d] = mine;
   __syncthreads();
-  for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[a * 512 + i] = 0;
+  for (int off = 1; off < 256; off <<= 1) {
+    const long long v = d >= off ? cum[t][d - off] : 0;
+    __syncthreads();
+    cum[t][d] += v;
+    __syncthreads();
+  }
+  const long long incl = cum[t][d], excl = incl - mine;
+  __syncthreads();
+  if (rk >= excl && rk < incl) {          // exactly one digit per half (rank < total count)
+    st[a].rank[t] = rk - excl;
+    st[a].prefix[t] |= ((unsigned long long)d) << shift;
+  }
+  hist[a * 512 + threadIdx.x] = 0;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    __threadfence();
     st[a].himask |= 255ull << shift;
     if (shift == 0) {
       double *out = a ? out1 : out0;
@@ -392,7 +401,7 @@ static int launch_nanmedian_wide(wcx_ctx *ctx, const double *a0, const double *a
   k_nm_init<<<2, 256, 0, s>>>(st, hist);
   for (int shift = 56; shift >= 0; shift -= 8) {
     k_nm_hist<<<dim3(g, 2), 256, 0, s>>>(a0, a1, n, shift, st, hist);
-    k_nm_decide<<<2, 256, 0, s>>>(st, hist, shift, out0, out1);
+    k_nm_decide<<<2, 512, 0, s>>>(st, hist, shift, out0, out1);
   }
   WCX_HIP(hipGetLastError());
   return WCX_OK;
