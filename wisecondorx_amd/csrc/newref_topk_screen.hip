@@ -54,39 +54,54 @@ __device__ __forceinline__ float up(float v) {  // a float strictly above v (v >
 constexpr int CSPLIT = 16;   // workgroups per sample column
 
 // per-sample mean over finite entries: partial sums, fp64 atomics
+__device__ __forceinline__ unsigned long long dord(double x) {   // order-preserving image
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dord_inv(unsigned long long k) {
+  return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
+// ONE sweep of X: per-sample sum, count, min and max over finite entries (max |x - mean| follows
+// from min and max: it is attained at one of them, with the same rounding as fabs(x - mean)).
 __global__ __launch_bounds__(NT) void k_col_sum(const double *__restrict__ Xs, int64_t B,
                                                 double *__restrict__ csum,
-                                                double *__restrict__ ccnt) {
+                                                double *__restrict__ ccnt,
+                                                unsigned long long *__restrict__ cmin,
+                                                unsigned long long *__restrict__ cmax) {
   const double *x = Xs + (int64_t)blockIdx.x * B;
-  double s = 0.0, c = 0.0;
+  double s = 0.0, c = 0.0, mn = HUGE_VAL, mx = -HUGE_VAL;
   for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < B; i += (int64_t)NT * CSPLIT) {
     const double v = x[i];
-    if (fabs(v) < HUGE_VAL) { s += v; c += 1.0; }  // finite only
+    if (fabs(v) < HUGE_VAL) { s += v; c += 1.0; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }  // finite only
   }
   s = wcx::wave_sum(s);
   c = wcx::wave_sum(c);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&csum[blockIdx.x], s); atomicAdd(&ccnt[blockIdx.x], c); }
+  mn = wcx::wave_min_f64(mn);
+  mx = wcx::wave_max_f64(mx);
+  if ((threadIdx.x & 63) == 0 && c > 0.0) {
+    atomicAdd(&csum[blockIdx.x], s);
+    atomicAdd(&ccnt[blockIdx.x], c);
+    atomicMin(&cmin[blockIdx.x], dord(mn));
+    atomicMax(&cmax[blockIdx.x], dord(mx));
+  }
 }
 
 // cmean[j] = csum/ccnt; global max |x - mean| over finite entries
-__global__ __launch_bounds__(NT) void k_col_stats(const double *__restrict__ Xs, int64_t B,
-                                                  const double *__restrict__ csum,
-                                                  const double *__restrict__ ccnt,
-                                                  double *__restrict__ cmean,
-                                                  ScreenGlobals *__restrict__ glob) {
-  const double *x = Xs + (int64_t)blockIdx.x * B;
-  const double cc = ccnt[blockIdx.x];
-  const double m = cc > 0 ? csum[blockIdx.x] / cc : 0.0;
-  if (blockIdx.y == 0 && threadIdx.x == 0) cmean[blockIdx.x] = m;
-  double mx = 0.0;
-  for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < B; i += (int64_t)NT * CSPLIT) {
-    const double a = fabs(x[i] - m);
-    if (a < HUGE_VAL && a > mx) mx = a;
+__global__ void k_col_stats(int S, const double *__restrict__ csum, const double *__restrict__ ccnt,
+                            const unsigned long long *__restrict__ cmin,
+                            const unsigned long long *__restrict__ cmax,
+                            double *__restrict__ cmean, ScreenGlobals *__restrict__ glob) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= S) return;
+  const double cc = ccnt[j];
+  const double m = cc > 0 ? csum[j] / cc : 0.0;
+  cmean[j] = m;
+  if (cc > 0) {
+    const double a0 = fabs(dord_inv(cmax[j]) - m), a1 = fabs(dord_inv(cmin[j]) - m);
+    const double mx = a0 > a1 ? a0 : a1;
+    if (mx < HUGE_VAL) atomicMax(&glob->amax_bits, (unsigned long long)__double_as_longlong(mx));
   }
-#pragma unroll
-  for (int k = 32; k >= 1; k >>= 1) { const double o = wcx::shfl_xor_f64(mx, k); mx = o > mx ? o : mx; }
-  if ((threadIdx.x & 63) == 0)
-    atomicMax(&glob->amax_bits, (unsigned long long)__double_as_longlong(mx));
 }
 
 __global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S, int Sp,
@@ -123,7 +138,7 @@ __global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S, int
 constexpr int NBUCKET = 128;            // norm buckets: float bits >> 20 (12.5 % steps)
 constexpr int NCELL = NBUCKET * 32;     // (bucket, chromosome) cells
 
-__global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xr, int64_t B, int S,
+__global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xs, int64_t B, int S,
                                                  int Sp, const double *__restrict__ cmean,
                                                  ChrTab chr, ScreenGlobals *__restrict__ glob,
                                                  unsigned int *__restrict__ rbits,
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xr, 
   if (b >= B) return;
   float s = 0.f;
   for (int j = 0; j < S; ++j) {
-    const float a = (float)(Xr[b * Sp + j] - cmean[j]);
+    const float a = (float)(Xs[(int64_t)j * B + b] - cmean[j]);   // sample-major: coalesced
     s += a * a;
   }
   int c = 0;
@@ -834,7 +849,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_glob = carve(sizeof(ScreenGlobals));
-  const size_t o_mean = carve((size_t)S * 8 * 3);   // mean | sum | count
+  const size_t o_mean = carve((size_t)S * 8 * 5);   // mean | sum | count | min | max
   const int Sp = (S + 3) & ~3;
   const size_t o_xr = carve((size_t)B * Sp * 8 + 256);   // + slack: refine loads whole 128-B chunks
   const size_t o_F = carve((size_t)Bpad * NK * 32);  // Bpad/32 tiles * NK * 1 KiB
@@ -892,9 +907,14 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   if (rc) return rc;
   rc = wcx_timer_begin(ctx, "topk_prep");
   if (rc) return rc;
+  unsigned long long *cmin = reinterpret_cast<unsigned long long *>(cmean + 3 * S);
+  unsigned long long *cmax = cmin + S;
   WCX_HIP(hipMemsetAsync(cmean + S, 0, (size_t)S * 16, st));
-  k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, cmean + S, cmean + 2 * S);
-  k_col_stats<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, cmean + S, cmean + 2 * S, cmean, glob);
+  WCX_HIP(hipMemsetAsync(cmin, 0xff, (size_t)S * 8, st));
+  WCX_HIP(hipMemsetAsync(cmax, 0, (size_t)S * 8, st));
+  k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, cmean + S, cmean + 2 * S, cmin, cmax);
+  k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, cmean + S, cmean + 2 * S, cmin, cmax, cmean,
+                                                         glob);
   k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
   {
     ChrTab tab0;
@@ -903,7 +923,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     const unsigned gb = (unsigned)((B + NT - 1) / NT);
     WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)NCELL * 4, st));
     WCX_HIP(hipMemsetAsync(perm, 0xff, (size_t)Bpad * 4, st));
-    k_row_norm<<<gb, NT, 0, st>>>(Xr, B, S, Sp, cmean, tab0, glob, rbits, rchr);
+    k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab0, glob, rbits, rchr);
     k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt);
     k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor);
     k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
