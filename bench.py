@@ -202,8 +202,10 @@ def main():
                     "executed_tflops": nprod * 2.0 * kpad * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
                     "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
                     "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
-                    "fallback_rows": stats["fallback_rows"], "compactions": stats["compactions"], "appends": stats["appends"],
-                    "phase_cycles": stats["phase_cycles"]}
+                    "fallback_rows": stats["fallback_rows"], "compactions": stats["compactions"],
+                    "appends": stats["appends"]}
+        if any(stats["phase_cycles"]):          # only with --debug-flags 4
+            roofline["phase_cycles"] = stats["phase_cycles"]
     else:
         flops = 3.0 * S * stats["pairs"]         # exact path: sub, mul, add per (pair, sample)
         achieved = flops / (k_ms * 1e-3) / 1e12
@@ -215,8 +217,8 @@ def main():
     # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (bench.py cannot read
     # counters itself): profiles/r01/screen_traffic.json, recorded on this exact default workload
     tpath = os.path.join(ROOT, "profiles", "r01", "screen_traffic.json")
-    if screen_ms >= 0 and (args.binsize, args.samples, args.refsize) == (15000, 100, 300) \
-            and os.path.exists(tpath):
+    if screen_ms >= 0 and world == 1 and os.path.exists(tpath) \
+            and (args.binsize, args.samples, args.refsize) == (15000, 100, 300):
         tj = json.load(open(tpath))
         roofline["traffic"] = tj["fetch_bytes_per_sweep_corrected_x2"] + tj["write_bytes_per_sweep"]
         roofline["traffic_source"] = "profiles/r01/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \

@@ -14,7 +14,7 @@ for f in ("gpurun_out/${TAG}.json","gpurun_out/${TAG}_f8.json","gpurun_out/${TAG
 try:
     d=json.loads(open("gpurun_out/${TAG}_prof.json").read().strip().split("\n")[-1]); r=d["roofline"]
     print("prof run: kernel_ms", r["kernel_ms"])
-    pc=r["phase_cycles"]; tot=sum(pc)
+    pc=r.get("phase_cycles",[0]); tot=sum(pc)
     names=["issue loads+MFMA","wait loads+ds_write","barrier","MFMA done+sign+OR","appends","maintenance"]
     for n,c in zip(names,pc): print("%-24s %6.1f%%  %.3g"%(n,100*c/tot,c))
 except Exception as e: print("prof ERR", e)
