@@ -170,8 +170,8 @@ def main():
     # Untimed spin-up (setup, not one of the contract's warm-up steps): the first process on an
     # idle box can otherwise measure the clock ramp (51 ms/step observed in the first 0.1 s of
     # load against 31.8 ms/step for every later process on the same box).
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < float(os.environ.get("WCX_BENCH_SPINUP_S", "1.0")):
+    # A FIXED number of steps: every rank must issue the same collectives.
+    for _ in range(int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "30"))):
         step(False)
     for _ in range(args.warmup):
         step(False)
