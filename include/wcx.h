@@ -48,8 +48,11 @@ int wcx_debug_flags(int flags);
 const char *wcx_last_error(void); /* thread-local, never NULL */
 
 /* ---- context / memory ------------------------------------------------------------- */
-/* stream == NULL: the context creates (and owns) its own HIP stream; otherwise the caller's
- * hipStream_t is used (e.g. torch.cuda.current_stream().cuda_stream). */
+/* stream == NULL: the context creates (and owns) its own non-blocking HIP stream; otherwise the
+ * caller's hipStream_t is used.  The default (null) stream's handle IS 0, so it is named by
+ * WCX_STREAM_DEFAULT: a caller that shares PyTorch's current stream passes
+ * torch.cuda.current_stream().cuda_stream, or WCX_STREAM_DEFAULT when that value is 0. */
+#define WCX_STREAM_DEFAULT ((void *)1)
 int wcx_ctx_create(int device, void *stream, wcx_ctx **out);
 int wcx_ctx_destroy(wcx_ctx *ctx);
 int wcx_sync(wcx_ctx *ctx);

@@ -1,0 +1,82 @@
+"""GPU, world_size 2 over gloo with BOTH ranks on cuda:0: the multi-GPU orchestration of dist.py
+(row shards, the all-gather of X, sharded cut-off and normalisation) driving the real HIP library
+(GpuBackend), compared with the oracle.  RCCL itself needs one device per rank and is exercised
+by bench.py on the multi-GPU node; everything around the collectives is covered here."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, X, cum, k, ids, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd import dist as wd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx)
+    B = X.shape[0]
+    b, e = wd.row_shard(rank, world, B)
+    pad = wd.max_shard_rows(world, B)
+    local = torch.zeros((pad, X.shape[1]), dtype=torch.float64, device=dev)
+    local[:e - b] = torch.from_numpy(np.ascontiguousarray(X[b:e])).to(dev)
+    idx, dd, nr, Xs = wd.newref_sharded(local, B, cum, k, ids, be, rank, world)
+    h = be.wrap_rows(idx, dd, B, k, cum, b, e - b)
+    cutoff = wd.cutoff_sharded(be, h, 5, world)
+    xt = torch.from_numpy(np.ascontiguousarray(X[:, 0]) * (1 + 0.2 * np.sin(np.arange(B)))).to(dev)
+    z, r, n, mlr, mz = wd.normalize_sharded(be, h, xt, B, 0, cutoff, rank, world)
+    ctx.sync()
+    be.free_ref(h)
+    q.put((rank, idx.cpu().numpy().copy(), dd.cpu().numpy().copy(), nr.cpu().numpy().copy(),
+           (cutoff, z.cpu().numpy().copy(), r.cpu().numpy().copy(), n.cpu().numpy().copy(), mlr, mz)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_device_real_kernels():
+    import torch.multiprocessing as mp
+    from oracle import c_oracle as CO
+    from oracle import wcx_oracle as O
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([900, 800, 700, 600, 500], 40, seed=23)
+    X = np.asfortranarray(X)
+    B, k, ids = cum[-1], 64, [3, 1, 7, 0, 22, 39]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, X, cum, k, ids, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ei, ed = CO.get_reference_rows(np.ascontiguousarray(X.T), cum, 0, B, k)
+    assert np.array_equal(np.concatenate([r[1] for r in res]), ei)
+    assert np.array_equal(np.concatenate([r[2] for r in res]), ed)
+    with np.errstate(all="ignore"):
+        enr = O.null_ratios(X, ei, 0, B, ids)
+    np.testing.assert_allclose(np.concatenate([r[3] for r in res]), enr, rtol=1e-12, atol=1e-13)
+    x = np.ascontiguousarray(X[:, 0]) * (1 + 0.2 * np.sin(np.arange(B)))
+    ecut = O.get_optimal_cutoff(ed, 5)
+    ez, er, en, emlr, emz = O.normalize_repeat(x, mbpc, cum, ei, ed, ecut, 0, 0)
+    for r in res:
+        cutoff, z, rr, n, mlr, mz = r[4]
+        np.testing.assert_allclose(cutoff, ecut, rtol=1e-12)
+        np.testing.assert_allclose(z, ez, rtol=1e-9, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(rr, er, rtol=1e-12, equal_nan=True)
+        assert np.array_equal(n, en)
+        np.testing.assert_allclose([mlr, mz], [emlr, emz], rtol=1e-9, atol=1e-12)

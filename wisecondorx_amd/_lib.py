@@ -123,12 +123,19 @@ def i32_array(v):
 
 class Context:
     """One per (process, GPU).  `stream` may be a raw hipStream_t (int), e.g.
-    torch.cuda.current_stream().cuda_stream, so launches order with the caller's work."""
+    torch.cuda.current_stream().cuda_stream, so launches order with the caller's work (0 = the
+    default stream, which is what PyTorch uses unless told otherwise); None = a private stream."""
 
     def __init__(self, device=0, stream=None):
         self.lib = load()
         h = vp()
-        check(self.lib.wcx_ctx_create(int(device), vp(stream) if stream else None, C.byref(h)))
+        if stream is None:
+            arg = None                      # the library creates its own stream
+        elif int(stream) == 0:
+            arg = vp(1)                     # WCX_STREAM_DEFAULT: the null stream's handle is 0
+        else:
+            arg = vp(int(stream))
+        check(self.lib.wcx_ctx_create(int(device), arg, C.byref(h)))
         self.h = h
         self.device = int(device)
 

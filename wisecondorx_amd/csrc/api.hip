@@ -103,7 +103,10 @@ int wcx_ctx_create(int device, void *stream, wcx_ctx **out) {
   WCX_HIP(hipSetDevice(device));
   wcx_ctx *ctx = new wcx_ctx();
   ctx->device = device;
-  if (stream) {
+  if (stream == WCX_STREAM_DEFAULT) {          // the device's default (null) stream
+    ctx->stream = nullptr;
+    ctx->own_stream = false;
+  } else if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     ctx->own_stream = false;
   } else {

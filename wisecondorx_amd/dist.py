@@ -34,9 +34,15 @@ def allgather_rows(local_rows, n_rows, world, group=None):
     if world == 1:
         return local_rows[:n_rows]
     pad = local_rows.shape[0]
-    gathered = torch.empty((world * pad,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype,
-                           device=local_rows.device)
-    dist.all_gather_into_tensor(gathered, local_rows.contiguous(), group=group)
+    if dist.get_backend(group) == "gloo" and local_rows.is_cuda:
+        # testing only (two ranks sharing one device): gloo gathers through host memory
+        host = torch.empty((world * pad,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype)
+        dist.all_gather_into_tensor(host, local_rows.contiguous().cpu(), group=group)
+        gathered = host.to(local_rows.device)
+    else:
+        gathered = torch.empty((world * pad,) + tuple(local_rows.shape[1:]),
+                               dtype=local_rows.dtype, device=local_rows.device)
+        dist.all_gather_into_tensor(gathered, local_rows.contiguous(), group=group)
     parts = []
     for r in range(world):
         b, e = row_shard(r, world, n_rows)
