@@ -90,11 +90,18 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # WCX_DIST_BACKEND=gloo is for tests only (several ranks sharing one device; RCCL needs one
+    # device per rank)
+    backend_name = os.environ.get("WCX_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend_name != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend_name)
 
     from wisecondorx_amd import _lib, predict_tools
     from wisecondorx_amd import dist as wd
@@ -124,7 +131,7 @@ def main():
     m = len(null_ids)
 
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = _lib.Context(local_rank, stream)
+    ctx = _lib.Context(dev_index, stream)
     lib = ctx.lib
     if args.debug_flags:
         lib.wcx_debug_flags(args.debug_flags)
@@ -182,7 +189,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend_name == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

@@ -80,3 +80,25 @@ def test_two_ranks_one_device_real_kernels():
         np.testing.assert_allclose(rr, er, rtol=1e-12, equal_nan=True)
         assert np.array_equal(n, en)
         np.testing.assert_allclose([mlr, mz], [emlr, emz], rtol=1e-9, atol=1e-12)
+
+
+def test_bench_two_ranks_smoke():
+    """bench.py's N > 1 code path end to end (launcher contract, sharding, collectives, JSON line)
+    with two gloo ranks on one device and a small problem."""
+    import json
+    import subprocess
+    env = dict(os.environ, WCX_DIST_BACKEND="gloo", WCX_BENCH_SPINUP_STEPS="1", MASTER_ADDR="127.0.0.1")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--binsize", "100000", "--samples", "40",
+           "--refsize", "100"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["roofline"]["frac"] > 0
