@@ -273,3 +273,20 @@ def test_config2_full_size_15kb(nt):
     nr = nt.get_null_ratios(X, idx[r0:r0 + 80], r0, r0 + 80, ids)
     np.testing.assert_allclose(nr, O.null_ratios(X, idx[r0:r0 + 80], r0, r0 + 80, ids),
                                rtol=1e-12, atol=1e-13)
+
+
+def test_reference_parts_from_threads(nt):
+    """The CLI's --gpus path: row parts driven from host threads, one context per thread (here two
+    contexts on the same device), five parts."""
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([800, 700, 600, 500], 30, seed=31)
+    k, ids = 50, [0, 5, 9, 17, 29]
+    ctxs = [_lib.Context(0), _lib.Context(0)]
+    parts = nt.get_reference_parts(X, cum, k, 5, ids, ctxs, mode=2)
+    idx = np.concatenate([p[0] for p in parts])
+    dist = np.concatenate([p[1] for p in parts])
+    nr = np.concatenate([p[2] for p in parts])
+    oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, 0, cum[-1], k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    np.testing.assert_allclose(nr, O.null_ratios(X, oi, 0, cum[-1], ids), rtol=1e-12, atol=1e-13)

@@ -116,8 +116,7 @@ def get_reference_parts(pca_corrected_data, masked_bins_per_chr_cum, ref_size, n
     contexts = contexts or [_lib.default_context()]
     bincount = masked_bins_per_chr_cum[-1]
 
-    def work(p):
-        ctx = contexts[p % len(contexts)]
+    def work(p, ctx):
         s, e = _get_part(p, n_parts, bincount)
         idx, dist = get_ref_for_rows(pca_corrected_data, masked_bins_per_chr_cum, ref_size, s, e,
                                      ctx, mode)
@@ -125,6 +124,13 @@ def get_reference_parts(pca_corrected_data, masked_bins_per_chr_cum, ref_size, n
         return idx, dist, nr
 
     if n_parts == 1:
-        return [work(0)]
+        return [work(0, contexts[0])]
+
+    def worker(t):          # a context is only ever used by ONE thread: parts t, t + T, ...
+        return [(p, work(p, contexts[t])) for p in range(t, n_parts, len(contexts))]
+    out = [None] * n_parts
     with ThreadPoolExecutor(max_workers=len(contexts)) as ex:
-        return list(ex.map(work, range(n_parts)))
+        for part in ex.map(worker, range(len(contexts))):
+            for p, res in part:
+                out[p] = res
+    return out
