@@ -290,3 +290,30 @@ def test_reference_parts_from_threads(nt):
     oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, 0, cum[-1], k)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
     np.testing.assert_allclose(nr, O.null_ratios(X, oi, 0, cum[-1], ids), rtol=1e-12, atol=1e-13)
+
+
+def test_large_bin_count_5kb(nt):
+    """5 kb bins (~590 k rows): index arithmetic beyond 2^19 rows / 2^32 bytes -- properties on all
+    rows, oracle agreement on sampled rows, null ratios on a block."""
+    from wisecondorx_amd.synth import bins_per_chr, corrected_matrix
+    bpc = [int(b * 0.95) for b in bins_per_chr(5000)[:22]]
+    S, k = 24, 60
+    X, mbpc, cum = corrected_matrix(bpc, S, seed=5)
+    B = cum[-1]
+    assert B > 520000
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, B, mode=2)
+    assert (np.diff(dist, axis=1) >= 0).all() and (idx >= 0).all()
+    own = np.repeat(np.array(mbpc), np.array(mbpc))
+    assert (idx < (B - own)[:, None]).all()
+    Xs = np.ascontiguousarray(np.asarray(X).T)
+    rng = np.random.default_rng(2)
+    rows = np.concatenate([[0, B - 1], rng.integers(0, B, 30)])
+    for t in rows:
+        c = int(np.searchsorted(cum, t, side="right"))
+        cs = cum[c - 1] if c else 0
+        oi, od = CO.topk_rows(Xs, cs, cum[c], int(t), int(t) + 1, k)
+        assert np.array_equal(idx[t], oi[0]) and np.array_equal(dist[t], od[0])
+    r0 = B - 64
+    ids = [0, 7, 23]
+    nr = nt.get_null_ratios(X, idx[r0:], r0, B, ids)
+    np.testing.assert_allclose(nr, O.null_ratios(X, idx[r0:], r0, B, ids), rtol=1e-12, atol=1e-13)
