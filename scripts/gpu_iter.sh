@@ -2,11 +2,11 @@
 # dev helper: bash scripts/gpu_iter.sh <tag> [extra bench variants...] -- runs parity + benches on the GPU box
 TAG=$1
 cd /root/repo
-/usr/local/graft/bin/gpurun --timeout 1500 -- "python -m pytest tests/test_gpu_newref.py -x -q 2>&1 | tail -3; python bench.py --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/${TAG}.json; python bench.py --no-cpu-baseline --debug-flags 8 2>&1 | tail -1 | tee gpurun_out/${TAG}_f8.json; python bench.py --no-cpu-baseline --samples 500 2>&1 | tail -1 | tee gpurun_out/${TAG}_500.json; python bench.py --no-cpu-baseline --debug-flags 4 2>&1 | tail -1 | tee gpurun_out/${TAG}_prof.json" > gpurun_out/run_${TAG}.log 2>&1
+/usr/local/graft/bin/gpurun --timeout 1500 -- "python -m pytest tests/test_gpu_newref.py -x -q 2>&1 | tail -3; python bench.py --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/${TAG}.json; python bench.py --no-cpu-baseline --samples 500 2>&1 | tail -1 | tee gpurun_out/${TAG}_500.json; python bench.py --no-cpu-baseline --debug-flags 4 2>&1 | tail -1 | tee gpurun_out/${TAG}_prof.json" > gpurun_out/run_${TAG}.log 2>&1
 grep -h "passed\|failed\|rror" gpurun_out/run_${TAG}.log | head
 python - <<PY
 import json
-for f in ("gpurun_out/${TAG}.json","gpurun_out/${TAG}_f8.json","gpurun_out/${TAG}_500.json"):
+for f in ("gpurun_out/${TAG}.json","gpurun_out/${TAG}_500.json"):
     try:
         d=json.loads(open(f).read().strip().split("\n")[-1]); r=d["roofline"]
         print(f, "%.2f"%d["ms_per_step"], {k:(round(r[k],3) if isinstance(r[k],float) else r[k]) for k in ("kernel_ms","frac","prep_ms","refine_ms","compactions","appends","null_ratios_ms")})
