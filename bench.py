@@ -253,6 +253,9 @@ def main():
                    "bins": int(B), "samples": int(S), "refsize": int(k),
                    "pairs": pairs_total, "bin_samples_per_s": B * S / (ms_per_step * 1e-3),
                    "mode": args.mode,
+                   "precision": "indices and distances bit-identical to the reference's fp64 path; the "
+                                "fp16 MFMA product is only a rigorously bounded pre-filter, every "
+                                "kept pair is re-evaluated in sequential fp64",
                    "partition": "target rows x{} (_get_part): one all-gather(X) for the search; "
                                 "predict row-sharded (all-reduce of cut-off moments, all-gather "
                                 "of B-vectors between passes)".format(world)},
