@@ -246,6 +246,59 @@ def golden_pipeline():
     save("pipeline.npz", **out)
 
 
+# --------------------------------------------------------------------------- a1/a3 prep pins
+def golden_prep_filter():
+    """A cohort in which the PCA-distance bin filter (newref_control.py:38-54) fires in the A
+    pass AND again in the F pass on an autosomal bin: the shared mask is mutated in place after
+    the A pass saved its copy, so mask.F/.M hold one autosomal bin fewer than mask (SURVEY.md
+    "latent A/F/M mask skew").  Captured: the reference's prep outputs of the three passes."""
+    import wisecondorx.newref_control as ref_nc
+    binsize = 4000000
+    co = Cohort(binsize, struct_seed=21, female_y=0.1)
+    samples, genders = co.cohort(28, seed0=700, reads=4e6)
+    rng = np.random.default_rng(9)
+    sd = 1.6
+    spec = [(2, 10, "FM"), (5, 7, "F"), (6, 7, "F"), (7, 9, "F"), (8, 3, "F"), (9, 3, "M"),
+            (10, 3, "M"), (11, 5, "M"), (12, 5, "M"), (3, 5, "F"), (4, 5, "F"), (13, 5, "F"),
+            (24, 4, "M"), (23, 11, "F")]
+    for c, b, who in spec:          # per-sample heavy multiplicative noise on single bins
+        for i, s in enumerate(samples):
+            if genders[i] in who:
+                s[str(c)][b] = int(s[str(c)][b] * np.exp(rng.normal(0, sd)))
+    out = {"cohort_counts": np.stack([np.concatenate([s[str(c)] for c in range(1, 25)])
+                                      for s in samples]),
+           "cohort_genders": np.array(genders), "cohort_bpc": np.array(co.bpc)}
+    samples = np.array([ref_ot.gender_correct(s, g) for s, g in zip(samples, genders)])
+    g = np.array(genders)
+    total_mask, bpc = ref_nt.get_mask(samples)                       # main.py:82-88
+    total_mask = total_mask & ref_nt.get_mask(samples[g == "F"])[0] \
+        & ref_nt.get_mask(samples[g == "M"])[0]
+    out["total_mask_in"] = total_mask.copy()
+    tmp = tempfile.mkdtemp(prefix="wcx_golden_prep_")
+    for gender, sub in (("A", samples), ("F", samples[g == "F"]), ("M", samples[g == "M"])):
+        args = argparse.Namespace(prepdatafile=os.path.join(tmp, "d.npy"),
+                                  prepfile=os.path.join(tmp, "p.npz"), binsize=binsize)
+        np.random.seed(3)
+        before = total_mask.copy()
+        ref_nc.tool_newref_prep(args, sub, gender, total_mask, bpc)
+        p = np.load(args.prepfile)
+        for key in ("mask", "bins_per_chr", "masked_bins_per_chr", "masked_bins_per_chr_cum",
+                    "pca_mean"):
+            out["{}_{}".format(gender, key)] = p[key]
+        out[gender + "_removed"] = np.where(before & ~total_mask)[0]
+        print(gender, "filter removed bins", out[gender + "_removed"])
+    n_aut = int(np.sum(bpc[:22]))
+    assert len(out["A_removed"]) > 0 and len(out["F_removed"]) > 0
+    assert out["F_removed"].max() < n_aut, "the F pass must drop an AUTOSOMAL bin"
+    assert out["A_mask"][:n_aut].sum() != out["F_mask"][:n_aut].sum()
+    save("prep_filter.npz", **out)
+
+
 if __name__ == "__main__":
-    golden_newref_search()
-    golden_pipeline()
+    which = sys.argv[1:] or ["search", "pipeline", "prep_filter"]
+    if "search" in which:
+        golden_newref_search()
+    if "pipeline" in which:
+        golden_pipeline()
+    if "prep_filter" in which:
+        golden_prep_filter()

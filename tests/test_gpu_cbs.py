@@ -27,7 +27,8 @@ def test_post_processing_and_segment_z_golden(pt, g_pipe, name, tmp_path):
     ap = "." + gender
     resA = [g["{}_A_{}".format(name, k)] for k in ("r", "z", "w", "n", "mlr", "mz")]
     resG = [g["{}_G_{}".format(name, k)] for k in ("r", "z", "w", "n", "mlr", "mz")]
-    r, z, w, n = pt.merge_autosomes_gonosomes(resA, resG)
+    r, z, w, n, weights_ok = pt.merge_autosomes_gonosomes(resA, resG)
+    assert weights_ok
     args = argparse.Namespace(minrefbins=20)
     rem = {"args": args, "mask": ref["mask" + ap], "bins_per_chr": ref["bins_per_chr" + ap],
            "binsize": int(ref["binsize"])}

@@ -1,4 +1,6 @@
 """CPU: host-side glue (bin rescaling, PCA, partition helpers, CLI surface, .npz formats)."""
+import os
+
 import numpy as np
 
 from oracle import wcx_oracle as O
@@ -145,3 +147,66 @@ def test_convert_filters_match_reference_loop(monkeypatch):
             assert bins[k].dtype == np.int32 and np.array_equal(bins[k], exp[k])
         assert (q["filter_rmdup"], q["filter_mapq"], q["pair_fail"], q["pre_retro"]) == (dup, mq, pf, seen)
         assert q["post_retro"] == sum(int(v.sum()) for v in exp.values())
+
+
+def _golden_cohort(g):
+    from conftest import sample_from_counts
+    from wisecondorx_amd.overall_tools import gender_correct
+    bpc = g["cohort_bpc"]
+    genders = np.array([str(x) for x in g["cohort_genders"]])
+    samples = np.array([gender_correct(sample_from_counts(c, bpc), gd)
+                        for c, gd in zip(g["cohort_counts"], genders)])
+    return samples, genders
+
+
+def test_prepare_matches_reference_outputs(g_pipe):
+    """a1/a3 pin: prep.get_mask + prep.prepare on the golden cohort reproduce what the REFERENCE's
+    tool_newref wrote (mask, masked_bins_per_chr(_cum), bins_per_chr, pca_mean) for the A, F and
+    M passes (tests/golden/pipeline.npz, keys ref__*).  pca_components are not compared: the
+    reference's randomized SVD is unseeded."""
+    from conftest import ref_dict_from_golden
+    from wisecondorx_amd import prep
+    ref = ref_dict_from_golden(g_pipe)
+    samples, g = _golden_cohort(g_pipe)
+    total_mask, bins_per_chr = prep.get_mask(samples)                 # main.py:82-88
+    total_mask = total_mask & prep.get_mask(samples[g == "F"])[0] & prep.get_mask(samples[g == "M"])[0]
+    for gender, sub, ap in (("A", samples, ""), ("F", samples[g == "F"], ".F"),
+                            ("M", samples[g == "M"], ".M")):
+        p = prep.prepare(sub, gender, total_mask, bins_per_chr)
+        assert np.array_equal(p["mask"], ref["mask" + ap]), gender
+        assert np.array_equal(p["bins_per_chr"], ref["bins_per_chr" + ap]), gender
+        assert np.array_equal(p["masked_bins_per_chr"], ref["masked_bins_per_chr" + ap]), gender
+        assert np.array_equal(p["masked_bins_per_chr_cum"], ref["masked_bins_per_chr_cum" + ap])
+        np.testing.assert_allclose(p["pca_mean"], ref["pca_mean" + ap], rtol=1e-13, atol=0)
+        assert p["pca_components"].shape == ref["pca_components" + ap].shape
+
+
+def test_pca_distance_filter_fires_and_skews_masks():
+    """a3 pin (tests/golden/prep_filter.npz, captured from the reference's tool_newref_prep): the
+    PCA-distance filter removes nine bins in the A pass and ONE MORE autosomal bin in the F pass;
+    because the shared mask is mutated in place (newref_control.py:51-54) after the A pass kept
+    its copy, mask.F / mask.M end up with one autosomal bin fewer than mask -- reproduced, not
+    fixed."""
+    from conftest import GOLDEN, sample_from_counts
+    from wisecondorx_amd import prep
+    from wisecondorx_amd.overall_tools import gender_correct
+    g = np.load(os.path.join(GOLDEN, "prep_filter.npz"), allow_pickle=False)
+    bpc = g["cohort_bpc"]
+    genders = np.array([str(x) for x in g["cohort_genders"]])
+    samples = np.array([gender_correct(sample_from_counts(c, bpc), gd)
+                        for c, gd in zip(g["cohort_counts"], genders)])
+    total_mask, bins_per_chr = prep.get_mask(samples)
+    total_mask = total_mask & prep.get_mask(samples[genders == "F"])[0] \
+        & prep.get_mask(samples[genders == "M"])[0]
+    assert np.array_equal(total_mask, g["total_mask_in"])
+    n_aut = int(np.sum(bins_per_chr[:22]))
+    for gender, sub in (("A", samples), ("F", samples[genders == "F"]),
+                        ("M", samples[genders == "M"])):
+        before = total_mask.copy()
+        p = prep.prepare(sub, gender, total_mask, bins_per_chr)
+        assert np.array_equal(np.where(before & ~total_mask)[0], g[gender + "_removed"]), gender
+        for key in ("mask", "bins_per_chr", "masked_bins_per_chr", "masked_bins_per_chr_cum"):
+            assert np.array_equal(p[key], g["{}_{}".format(gender, key)]), (gender, key)
+        np.testing.assert_allclose(p["pca_mean"], g[gender + "_pca_mean"], rtol=1e-13, atol=0)
+    assert len(g["A_removed"]) == 9 and len(g["F_removed"]) == 1
+    assert g["A_mask"][:n_aut].sum() == g["F_mask"][:n_aut].sum() + 1      # the skew

@@ -103,3 +103,31 @@ def test_partition_helpers():
     assert O.get_part(0, 3, 10) == (0, 3) and O.get_part(2, 3, 10) == (6, 10)
     assert O.split_by_chr(0, 10, [4, 4, 10]) == [[0, 0, 4], [1, 4, 4], [2, 4, 10]]  # empty chr -> empty region
     assert O.split_by_chr(2, 7, [4, 6, 10]) == [[0, 2, 4], [1, 4, 6], [2, 6, 7]]
+
+
+# ---- the C restatement (oracle/wcx_oracle.c): pinned against the same reference outputs -------
+@pytest.mark.parametrize("tag", ["A", "A1", "F", "M", "M2"])
+def test_c_oracle_get_reference(g_search, tag):
+    """oracle/wcx_oracle.c + the gonosomal dummy rule of c_oracle.get_reference_rows vs the
+    reference's get_reference output (bit-exact indices and distances)."""
+    from oracle import c_oracle as CO
+    from oracle.wcx_oracle import get_part
+    g = g_search
+    mb = g[tag + "_mb"].tolist()
+    cum = np.cumsum(mb).tolist()
+    part, parts = g[tag + "_part"].tolist()
+    Xs = np.ascontiguousarray(g["Xs"][:, :cum[-1]])
+    s, e = get_part(part - 1, parts, cum[-1])
+    idx, dist = CO.get_reference_rows(Xs, cum, s, e, 40)
+    assert np.array_equal(idx, g[tag + "_idx"])
+    assert np.array_equal(dist, g[tag + "_dist"])
+
+
+@pytest.mark.parametrize("tag,cs,ce,k", [("tie", 20, 50, 25), ("few", 10, 18, 40),
+                                         ("nan", 20, 30, 45)])
+def test_c_oracle_edge_cases(g_search, tag, cs, ce, k):
+    """ties (stable by index), fewer than k candidates, NaN/inf/>=1e10 never admitted."""
+    from oracle import c_oracle as CO
+    idx, dist = CO.topk_rows(g_search[tag + "_Xs"], cs, ce, cs, ce, k)
+    assert np.array_equal(idx, g_search[tag + "_idx"])
+    assert np.array_equal(dist, g_search[tag + "_dist"])

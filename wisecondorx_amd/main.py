@@ -33,35 +33,52 @@ def tool_convert(args):
 
 
 # --------------------------------------------------------------------------- newref
+def _y_fractions(samples):
+    """Share of the reads of each sample that fall on chrY (key "24")."""
+    tot = np.array([float(sum(np.sum(v) for v in s.values())) for s in samples])
+    y = np.array([float(np.sum(s["24"])) for s in samples])
+    return y / tot
+
+
+def _plot_yfrac(path, y_fractions, grid, density):
+    import matplotlib
+    matplotlib.use("Agg")
+    from matplotlib import pyplot
+    figure = pyplot.figure(figsize=(16, 6))
+    axes = figure.add_subplot(111)
+    axes.hist(y_fractions, bins=100, density=True)
+    axes.plot(grid, density, "r-", label="Gaussian mixture fit")
+    axes.set_xlim(grid[0], grid[-1])
+    axes.legend(loc="best")
+    figure.savefig(path)
+
+
 def train_gender_model(args, samples):
-    """Two-component Gaussian mixture on the Y-read fractions; cut-off = first local minimum of
-    the mixture density on [0, 0.02] unless --yfrac is given (newref_tools.py:21-68)."""
-    y_fractions = np.array([
-        float(np.sum(s["24"])) / float(np.sum([np.sum(s[x]) for x in s.keys()])) for s in samples])
-    if args.yfrac is not None:
-        cut_off = args.yfrac
-    else:
+    """Gender of every reference sample from its Y-read fraction (newref_tools.py:21-68): with
+    --yfrac the cut-off is given; otherwise a two-component Gaussian mixture is fitted and the
+    cut-off is the first local minimum of its density on [0, 0.02] (same mixture settings and
+    grid as the reference, so the same cut-off)."""
+    y_fractions = _y_fractions(samples)
+    cut_off = args.yfrac
+    if cut_off is None:
         from scipy.signal import argrelextrema
         from sklearn.mixture import GaussianMixture
-        gmm = GaussianMixture(n_components=2, covariance_type="full", reg_covar=1e-99,
-                              max_iter=10000, tol=1e-99)
-        gmm.fit(X=y_fractions.reshape(-1, 1))
-        gmm_x = np.linspace(0, 0.02, 5000)
-        gmm_y = np.exp(gmm.score_samples(gmm_x.reshape(-1, 1)))
+        mixture = GaussianMixture(n_components=2, covariance_type="full", reg_covar=1e-99,
+                                  max_iter=10000, tol=1e-99).fit(y_fractions[:, None])
+        grid = np.linspace(0, 0.02, 5000)
+        density = np.exp(mixture.score_samples(grid[:, None]))
         if getattr(args, "plotyfrac", None) is not None:
-            import matplotlib.pyplot as plt
-            fig, ax = plt.subplots(figsize=(16, 6))
-            ax.hist(y_fractions, bins=100, density=True)
-            ax.plot(gmm_x, gmm_y, "r-", label="Gaussian mixture fit")
-            ax.set_xlim([0, 0.02])
-            ax.legend(loc="best")
-            plt.savefig(args.plotyfrac)
+            _plot_yfrac(args.plotyfrac, y_fractions, grid, density)
             logging.info("Image written to {}, now quitting ...".format(args.plotyfrac))
             sys.exit()
-        local_min = argrelextrema(gmm_y, np.less)
-        cut_off = gmm_x[local_min][0]
+        minima = argrelextrema(density, np.less)[0]
+        if not len(minima):
+            logging.critical("No local minimum in the Y-fraction mixture density: the genders "
+                             "cannot be separated automatically, pass --yfrac")
+            sys.exit()
+        cut_off = grid[minima[0]]
         logging.info("Determined --yfrac cutoff: {}".format(str(round(cut_off, 4))))
-    genders = np.empty(len(samples), dtype="object")
+    genders = np.full(len(samples), None, dtype=object)
     genders[y_fractions > cut_off] = "M"
     genders[y_fractions < cut_off] = "F"
     return genders.tolist(), cut_off
@@ -129,7 +146,7 @@ def tool_newref(args):
         sys.exit()
     if genders.count("F") > 4:
         logging.info("Starting female gonosomal reference creation ...")
-        sub = build_sub_reference(args, samples[g == "F"], "F", total_mask, bins_per_chr, contexts[:1])
+        sub = build_sub_reference(args, samples[g == "F"], "F", total_mask, bins_per_chr, contexts)
         final_ref["has_female"] = True
         final_ref.update({k + ".F": v for k, v in sub.items() if k != "gender"})
     else:
@@ -137,13 +154,24 @@ def tool_newref(args):
     if not args.nipt:
         if genders.count("M") > 4:
             logging.info("Starting male gonosomal reference creation ...")
-            sub = build_sub_reference(args, samples[g == "M"], "M", total_mask, bins_per_chr, contexts[:1])
+            sub = build_sub_reference(args, samples[g == "M"], "M", total_mask, bins_per_chr, contexts)
             final_ref["has_male"] = True
             final_ref.update({k + ".M": v for k, v in sub.items() if k != "gender"})
         else:
             logging.warning("Provide at least 5 male samples to enable normalization of male gonosomes.")
     final_ref["is_nipt"] = args.nipt
     final_ref["trained_cutoff"] = trained_cutoff
+    n_aut = int(np.sum(final_ref["bins_per_chr"]))
+    for ap in (".F", ".M"):
+        if "mask" + ap in final_ref and not np.array_equal(final_ref["mask" + ap][:n_aut],
+                                                           final_ref["mask"]):
+            # the reference has the same latent skew (newref_control.py:51-54 mutates the shared
+            # mask after the A pass kept its copy) and misaligns silently at predict time
+            logging.warning("The PCA-distance filter of the {} pass dropped {} autosomal bin(s) "
+                            "the autosomal reference still holds: predict cannot align the two "
+                            "(rebuild without the offending samples/bins)".format(
+                                ap[1:], int(np.sum(final_ref["mask"]) -
+                                            np.sum(final_ref["mask" + ap][:n_aut]))))
     npz_io.save_npz(args.outfile, final_ref)
     logging.info("Finished creating reference")
 
@@ -169,6 +197,10 @@ def tool_test(args):
         sys.exit()
     if args.alpha <= 0 or args.alpha > 1:
         logging.critical("Parameter --alpha should be a strictly positive number lower than or equal to 1")
+        sys.exit()
+    if args.plot and not args.bed:
+        logging.critical("--plot needs R (include/plotter.R of the reference), which is outside the "
+                         "MI355X hot path: no output would be written. Add --bed.")
         sys.exit()
     from . import predict_tools as pt
     from .predict_output import generate_output_tables
@@ -216,9 +248,18 @@ def tool_test(args):
         "masked_bins_per_chr_cum": ref_file["masked_bins_per_chr_cum" + ap],
     }
     m_lr = res_a[4]
-    r, z, w, ref_sizes = pt.merge_autosomes_gonosomes(res_a, res_g)
-    if not np.isfinite(w).all():
-        logging.warning("Non-numeric values found in weights -- reference too small.")
+    n_aut_masked = int(np.sum(ref_file["mask"]))
+    n_aut = int(np.sum(ref_file["bins_per_chr"]))
+    if int(np.sum(ref_file["mask" + ap][:n_aut])) != n_aut_masked:
+        logging.critical("Reference mask{} holds {} autosomal bins but the autosomal reference {}: "
+                         "the reference was built with a PCA-distance filter skew "
+                         "(newref_control.py:51-54) and cannot be aligned".format(
+                             ap, int(np.sum(ref_file["mask" + ap][:n_aut])), n_aut_masked))
+        sys.exit()
+    r, z, w, ref_sizes, weights_ok = pt.merge_autosomes_gonosomes(res_a, res_g)
+    if not weights_ok:       # main.py:252-256
+        logging.warning("Non-numeric values found in weights -- reference too small. "
+                        "Circular binary segmentation and z-scoring will be unweighted")
     m = max(nr_aut.shape[1], nr_gon.shape[1])
     nr = np.full((len(nr_aut) + len(nr_gon), m), np.nan)      # ragged rows padded with NaN
     nr[:len(nr_aut), :nr_aut.shape[1]] = nr_aut

@@ -46,17 +46,18 @@ def _dev(ref_file, ap, cache):
 
 
 def coverage_normalize_and_mask(sample, ref_file, ap):
-    """predict_tools.py:32-48 (O(B) host glue)."""
-    bpc = ref_file["bins_per_chr{}".format(ap)]
-    by_chr = []
-    for c in range(1, len(bpc) + 1):
-        this_chr = np.zeros(bpc[c - 1], dtype=float)
-        min_len = min(bpc[c - 1], len(sample[str(c)]))
-        this_chr[:min_len] = sample[str(c)][:min_len]
-        by_chr.append(this_chr)
-    all_data = np.concatenate(by_chr, axis=0)
-    all_data = all_data / np.sum(all_data)
-    return all_data[ref_file["mask{}".format(ap)]]
+    """The sample as one vector over the reference's bins (predict_tools.py:32-48): each
+    chromosome truncated or zero-padded to the reference's bin count, divided by the total read
+    count, masked bins dropped.  One preallocated vector, filled through the chromosome offsets."""
+    bpc = np.asarray(ref_file["bins_per_chr{}".format(ap)], dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(bpc)))
+    depth = np.zeros(int(starts[-1]), dtype=np.float64)
+    for c, n_ref in enumerate(bpc):
+        counts = sample[str(c + 1)]
+        n = min(int(n_ref), len(counts))
+        depth[starts[c]:starts[c] + n] = counts[:n]
+    depth /= depth.sum()
+    return depth[ref_file["mask{}".format(ap)]]
 
 
 def project_pc(sample_data, ref_file, ap):
@@ -131,7 +132,8 @@ def normalize(args, sample, ref_file, ref_gender, cache=None):
 # --------------------------------------------------------------------------- a14-a17 (host glue)
 def merge_autosomes_gonosomes(res_a, res_g):
     """main.py:242-257: append gonosomal to autosomal results, centre z, cross-scale and
-    renormalise the weights (all-ones fallback when not finite)."""
+    renormalise the weights (all-ones fallback when not finite; the last return value tells the
+    caller whether the weights were usable, main.py:252-256)."""
     results_r, results_z, results_w, ref_sizes, m_lr, m_z = res_a
     results_r_2, results_z_2, results_w_2, ref_sizes_2, _, _ = res_g
     with np.errstate(all="ignore"):
@@ -139,9 +141,10 @@ def merge_autosomes_gonosomes(res_a, res_g):
         z = np.append(results_z, results_z_2) - m_z
         w = np.append(results_w * np.nanmean(results_w_2), results_w_2 * np.nanmean(results_w))
         w = w / np.nanmean(w)
-    if np.isnan(w).any() or np.isinf(w).any():
+    weights_ok = bool(np.isfinite(w).all())
+    if not weights_ok:
         w = np.ones(len(w))
-    return r, z, w, np.append(ref_sizes, ref_sizes_2)
+    return r, z, w, np.append(ref_sizes, ref_sizes_2), weights_ok
 
 
 def inflate_results(results, rem_input):
@@ -179,36 +182,34 @@ def log_trans(results, log_r_median):
         results["results_r"][c], results["results_z"][c], results["results_w"][c] = r, z, w
 
 
-def _import_bed(rem_input):
-    """predict_tools.py:217-233."""
-    bed = {}
-    for line in open(rem_input["args"].blacklist):
-        chr_name, s, e = line.strip().split("\t")
-        if chr_name[:3] == "chr":
-            chr_name = chr_name[3:]
-        if chr_name == "X":
-            chr_name = "23"
-        if chr_name == "Y":
-            chr_name = "24"
-        c = int(chr_name) - 1
-        bed.setdefault(c, []).append(
-            [int(int(s) / rem_input["binsize"]), int(int(e) / rem_input["binsize"]) + 1])
-    return bed
+_BED_CHR = {"X": 23, "Y": 24}
+
+
+def _blacklist_spans(path, binsize):
+    """(chromosome index, first bin, one-past-last bin) of every blacklist row
+    (predict_tools.py:217-233: `chr` prefix optional, X/Y = 23/24, end bin inclusive)."""
+    spans = []
+    with open(path) as fh:
+        for row in fh:
+            name, start, end = row.strip().split("\t")
+            name = name[3:] if name.startswith("chr") else name
+            c = _BED_CHR.get(name) or int(name)
+            spans.append((c - 1, int(int(start) / binsize), int(int(end) / binsize) + 1))
+    return spans
 
 
 def apply_blacklist(rem_input, results):
-    """predict_tools.py:202-214."""
-    for c, spans in _import_bed(rem_input).items():
-        if len(results["results_r"]) < 24 and c == 23:
+    """predict_tools.py:202-214: zero ratio, z and weight of the blacklisted bins (slice
+    assignment per span; chrY rows are ignored when the result holds 23 chromosomes)."""
+    n_chr = len(results["results_r"])
+    for c, first, last in _blacklist_spans(rem_input["args"].blacklist, rem_input["binsize"]):
+        if c >= n_chr or (n_chr < 24 and c == 23):
             continue
-        if c >= len(results["results_r"]):
+        lo, hi = max(first, 0), min(last, len(results["results_r"][c]))
+        if lo >= hi:
             continue
-        n = len(results["results_r"][c])
-        for s, e in spans:
-            s, e = max(s, 0), min(e, n)
-            if s < e:
-                for key in ("results_r", "results_z", "results_w"):
-                    results[key][c][s:e] = 0
+        for key in ("results_r", "results_z", "results_w"):
+            results[key][c][lo:hi] = 0
 
 
 def _flatten(results, key):
