@@ -76,6 +76,26 @@ def topk_stable(d, ref_size):
     return idx, dist
 
 
+def topk_scan(d, ref_size):
+    """newref_tools.py:261-275 as the reference executes it: one pass over ALL candidates in
+    Python, keeping an ascending list of the ref_size best (a candidate enters only if strictly
+    below the current worst; it goes after equal values, the worst drops out).  Same result as
+    topk_stable(); kept because THIS loop is most of the reference's run time, so
+    bench.py's cpu_baseline times it."""
+    from bisect import bisect_right
+    best_d = [1e10] * ref_size
+    best_i = [-1] * ref_size
+    worst = 1e10
+    for cand, val in enumerate(d):
+        if val < worst:
+            at = bisect_right(best_d, val)
+            best_d[at:at] = [val]
+            best_i[at:at] = [cand]
+            del best_d[-1], best_i[-1]
+            worst = best_d[-1]
+    return np.array(best_i, dtype=np.int32), np.array(best_d, dtype=np.float64)
+
+
 def get_ref_for_bins(ref_size, start, end, X, chr_data):
     """newref_tools.py:255-278."""
     ref_indexes = np.zeros((end - start, ref_size), dtype=np.int32)

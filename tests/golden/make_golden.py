@@ -294,8 +294,80 @@ def golden_prep_filter():
     save("prep_filter.npz", **out)
 
 
+# --------------------------------------------------------------------------- BASELINE config 1
+def golden_config1():
+    """BASELINE.json configs[0]: predict one synthetic sample at 1 Mb bins (~3.1 k bins) against
+    a 50-sample reference, refsize 300 -- the reference's own CPU path end to end
+    (tool_newref, then predict_control.normalize for the autosomes and the gonosomes).
+
+    To keep the fixture small, the 2 x (B x 300) indexes/distances are stored as SHA-256 digests
+    next to the reference's PCA-corrected matrices (the bytes np.save wrote, newref_control.py:68):
+    a parity test first rebuilds the neighbour tables from those matrices, proves them identical
+    to the reference's through the digests, then runs predict on them and compares with the
+    reference's outputs."""
+    import hashlib
+    import wisecondorx.newref_control as ref_nc
+    binsize = 1000000
+    co = Cohort(binsize, struct_seed=41, female_y=0.1)
+    samples, genders = co.cohort(50, seed0=4100, reads=1e7)
+    tmp = tempfile.mkdtemp(prefix="wcx_golden_c1_")
+    infiles = []
+    for i, s in enumerate(samples):
+        p = os.path.join(tmp, "s{}.npz".format(i))
+        write_sample(p, s, binsize)
+        infiles.append(p)
+    # capture the PCA-corrected matrix of every pass as the reference saves it
+    captured = {}
+    real_prep = ref_nc.tool_newref_prep
+
+    def spy_prep(args, samples_, gender, mask, bins_per_chr):
+        real_prep(args, samples_, gender, mask, bins_per_chr)
+        captured[gender] = np.load(args.prepdatafile)
+    ref_main.tool_newref_prep = spy_prep
+    args = argparse.Namespace(infiles=infiles, outfile=os.path.join(tmp, "ref.npz"),
+                              nipt=False, yfrac=0.004, plotyfrac=None, refsize=300,
+                              binsize=binsize, cpus=1)
+    np.random.seed(41)
+    random.seed(41)
+    try:
+        ref_main.tool_newref(args)
+    except NameError as e:          # main.py:135 qc_reference never imported
+        print("expected reference bug:", e)
+    finally:
+        ref_main.tool_newref_prep = real_prep
+    ref = np.load(args.outfile, encoding="latin1", allow_pickle=True)
+    test = co.sample(4999, "M", reads=1e7, cnv=[(4, 40, 70, 1.5), (23, 20, 60, 0.5)])
+    gender = ref_pt.predict_gender(test, ref["trained_cutoff"])
+    assert gender == "M"
+    sample = ref_ot.gender_correct({k: v.copy() for k, v in test.items()}, gender)
+    pargs = argparse.Namespace(maskrepeats=5, minrefbins=150)
+    out = {"test_counts": np.concatenate([test[str(c)] for c in range(1, 25)]),
+           "test_gender": np.array(gender), "cohort_bpc": np.array(co.bpc)}
+    sha = lambda a: np.array(hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest())
+    for tag, ap, rg in (("A", "", "A"), ("G", "." + gender, gender)):
+        X = captured[rg]
+        assert X.flags["F_CONTIGUOUS"] and X.shape[0] == ref["indexes" + ap].shape[0]
+        out[tag + "_Xs"] = np.ascontiguousarray(X.T)          # the bytes of the F-ordered (B,S)
+        for key in ("mask", "bins_per_chr", "masked_bins_per_chr", "masked_bins_per_chr_cum",
+                    "pca_components", "pca_mean"):
+            out["ref__" + key + ap] = ref[key + ap]
+        idx, dist = ref["indexes" + ap], ref["distances" + ap]
+        out[tag + "_idx_sha"], out[tag + "_dist_sha"] = sha(idx), sha(dist)
+        out[tag + "_idx_rows"] = idx[::97]                     # a few rows in clear, for debugging
+        out[tag + "_dist_rows"] = dist[::97]
+        res = ref_pc.normalize(pargs, sample, ref, rg)
+        for nm, v in zip(("r", "z", "w", "n", "mlr", "mz"), res):
+            out["{}_{}".format(tag, nm)] = np.asarray(v)
+    out["ref__binsize"] = ref["binsize"]
+    out["ref__trained_cutoff"] = ref["trained_cutoff"]
+    out["cutoff"] = np.array(ref_pt.get_optimal_cutoff(ref, 5))
+    save("config1.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["search", "pipeline", "prep_filter"]
+    which = sys.argv[1:] or ["search", "pipeline", "prep_filter", "config1"]
+    if "config1" in which:
+        golden_config1()
     if "search" in which:
         golden_newref_search()
     if "pipeline" in which:

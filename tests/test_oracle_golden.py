@@ -131,3 +131,66 @@ def test_c_oracle_edge_cases(g_search, tag, cs, ce, k):
     idx, dist = CO.topk_rows(g_search[tag + "_Xs"], cs, ce, cs, ce, k)
     assert np.array_equal(idx, g_search[tag + "_idx"])
     assert np.array_equal(dist, g_search[tag + "_dist"])
+
+
+# ---- BASELINE config 1: predict one sample at 1 Mb bins vs a 50-sample reference ------------
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def config1_reference(g, search):
+    """Reference dict of tests/golden/config1.npz with indexes/distances REBUILT by `search`
+    (X, masked_bins_per_chr, cum, k) -> (idx, dist) from the reference's PCA-corrected matrices and
+    proven identical to the reference's own tables through their SHA-256 digests."""
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("ref__")}
+    gender = str(g["test_gender"])
+    for tag, ap in (("A", ""), ("G", "." + gender)):
+        X = g[tag + "_Xs"].T                                  # (B,S) Fortran-ordered view
+        mb = ref["masked_bins_per_chr" + ap].tolist()
+        idx, dist = search(X, mb, np.cumsum(mb).tolist(), 300)
+        assert np.array_equal(idx[::97], g[tag + "_idx_rows"]), tag
+        assert np.array_equal(dist[::97], g[tag + "_dist_rows"]), tag
+        assert _sha(idx) == str(g[tag + "_idx_sha"]), tag + ": indexes differ from the reference"
+        assert _sha(dist) == str(g[tag + "_dist_sha"]), tag + ": distances differ from the reference"
+        ref["indexes" + ap], ref["distances" + ap] = idx, dist
+    return ref, gender
+
+
+def config1_sample(g, gender):
+    sample = sample_from_counts(g["test_counts"], g["cohort_bpc"])
+    if gender == "M":       # overall_tools.py:48-53
+        sample["23"] = sample["23"] * 2
+        sample["24"] = sample["24"] * 2
+    return sample
+
+
+def test_config1_predict_1mb_vs_50_sample_reference():
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "config1.npz"), allow_pickle=False)
+
+    def search(X, mb, cum, k):
+        i, d, _ = O.get_reference(X, mb, cum, k, 1, 1, [0])
+        return i, d
+    ref, gender = config1_reference(g, search)
+    sample = config1_sample(g, gender)
+    np.testing.assert_allclose(O.get_optimal_cutoff(ref["distances"], 5), g["cutoff"], rtol=1e-14)
+    for tag, rg in (("A", "A"), ("G", gender)):
+        res = O.normalize(sample, ref, rg, 5)
+        for nm, v in zip(("r", "z", "w", "n", "mlr", "mz"), res):
+            np.testing.assert_allclose(np.asarray(v), g["{}_{}".format(tag, nm)], rtol=1e-12,
+                                       atol=1e-12, equal_nan=True, err_msg=tag + nm)
+
+
+@pytest.mark.parametrize("tag,cs,ce,k", [("tie", 20, 50, 25), ("few", 10, 18, 40),
+                                         ("nan", 20, 30, 45)])
+def test_scan_restatement_matches_reference(g_search, tag, cs, ce, k):
+    """O.topk_scan (the per-candidate Python loop bench.py times as cpu_baseline) on the
+    reference's edge-case fixtures."""
+    X = _X(g_search, tag + "_Xs")
+    chr_data = np.concatenate((X[:cs], X[ce:]))
+    for t in range(cs, ce):
+        i, d = O.topk_scan(O.sq_distances(chr_data, X[t, :]), k)
+        assert np.array_equal(i, g_search[tag + "_idx"][t - cs])
+        assert np.array_equal(d, g_search[tag + "_dist"][t - cs])
