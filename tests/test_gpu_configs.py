@@ -120,7 +120,7 @@ def test_config5_predict_batch_of_96_at_15kb(ref15):
     for i in range(n_batch):
         c = i % 22
         cs = cum[c - 1] if c else 0
-        a = cs + 500 + 37 * i
+        a = cs + 100 + (37 * i) % (mb[c] - 2200)      # the 2000-bin CNV stays inside chromosome c
         f = 1.5 if i % 2 == 0 else 0.5
         xs[i, a:a + 2000] *= f
         planted.append((c, a - cs, a - cs + 2000, f))
