@@ -134,7 +134,7 @@ def main():
     ctx = _lib.Context(dev_index, stream)
     lib = ctx.lib
     if args.debug_flags:
-        lib.wcx_debug_flags(args.debug_flags)
+        lib.wcx_debug_flags(ctx.h, args.debug_flags)
     d_idx = torch.empty((max(n_rows, 1), k), dtype=torch.int32, device=dev)
     d_dist = torch.empty((max(n_rows, 1), k), dtype=torch.float64, device=dev)
     d_nr = torch.empty((max(n_rows, 1), m), dtype=torch.float64, device=dev)
@@ -144,7 +144,7 @@ def main():
     d_med = torch.empty(2, dtype=torch.float64, device=dev)
     cum_p = cum.ctypes.data_as(_lib.c_i64p)
     ids_p = null_ids.ctypes.data_as(_lib.c_i32p)
-    topk_ms, nr_ms, norm_ms = [], [], []
+    topk_ms, nr_ms, norm_ms, fb_rows = [], [], [], []
 
     backend = wd.GpuBackend(ctx)
     out_bufs = (d_idx, d_dist, d_nr)
@@ -158,15 +158,19 @@ def main():
         # rows it just built; cut-off = 5 x 2 local moment sweeps + tiny all-reduces, then three
         # masked passes over the local rows with an all-gather of the updated copy vector
         # (B doubles) between passes, and of z / r / n / log2 r at the end.
-        h = backend.wrap_rows(idx_l, dist_l, B, k, cum, row_begin, n_rows)
-        cut = wd.cutoff_sharded(backend, h, 5, world)
-        wd.normalize_sharded(backend, h, d_x, B, 0, cut, rank, world)
-        lib.wcx_sync(ctx.h)
-        backend.free_ref(h)
+        if not (args.debug_flags & 3):          # (ablations leave garbage neighbour tables)
+            h = backend.wrap_rows(idx_l, dist_l, B, k, cum, row_begin, n_rows)
+            cut = wd.cutoff_sharded(backend, h, 5, world)
+            wd.normalize_sharded(backend, h, d_x, B, 0, cut, rank, world)
+            lib.wcx_sync(ctx.h)
+            backend.free_ref(h)
+        else:
+            lib.wcx_sync(ctx.h)
         if record:
             topk_ms.append(ctx.kernel_ms("topk"))
             nr_ms.append(ctx.kernel_ms("null_ratios"))
             norm_ms.append(ctx.kernel_ms("normalize"))
+            fb_rows.append(ctx.topk_stats()["fallback_rows"])
 
     def barrier():
         torch.cuda.synchronize()
@@ -215,7 +219,8 @@ def main():
                     "executed_tflops": nprod * 2.0 * kpad * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
                     "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
                     "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
-                    "fallback_rows": stats["fallback_rows"], "compactions": stats["compactions"],
+                    "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": fb_rows,
+                    "compactions": stats["compactions"],
                     "appends": stats["appends"]}
         if any(stats["phase_cycles"]):          # only with --debug-flags 4
             roofline["phase_cycles"] = stats["phase_cycles"]

@@ -40,11 +40,6 @@ typedef struct wcx_ctx wcx_ctx; /* one per (process, GPU): device id, stream, sc
 typedef struct wcx_ref wcx_ref; /* a reference (indexes/distances) resident in HBM    */
 
 int wcx_version(void);
-/* Diagnostics only: switches used by the profiling scripts (0 = normal operation).  4 = per-phase
- * cycle accounting of the screen kernel (results stay valid, ~20 % slower); 1 (no shortlist
- * appends), 16 / 64 (null ratios without gathers / without selection) are ablations whose results
- * are INVALID; bits 8.. = compaction trigger level.  Returns the previous value. */
-int wcx_debug_flags(int flags);
 const char *wcx_last_error(void); /* thread-local, never NULL */
 
 /* ---- context / memory ------------------------------------------------------------- */
@@ -55,6 +50,11 @@ const char *wcx_last_error(void); /* thread-local, never NULL */
 #define WCX_STREAM_DEFAULT ((void *)1)
 int wcx_ctx_create(int device, void *stream, wcx_ctx **out);
 int wcx_ctx_destroy(wcx_ctx *ctx);
+/* Diagnostics only, per context: switches used by the profiling scripts (0 = normal operation).
+ * 4 = per-phase cycle accounting of the screen kernel (results stay valid, ~20 % slower); 1 (no
+ * shortlist appends), 16 / 64 (null ratios without gathers / without selection) are ablations whose
+ * results are INVALID; bits 8.. = compaction trigger level.  Returns the previous value. */
+int wcx_debug_flags(wcx_ctx *ctx, int flags);
 int wcx_sync(wcx_ctx *ctx);
 int wcx_malloc(wcx_ctx *ctx, size_t bytes, void **dptr);
 int wcx_free(wcx_ctx *ctx, void *dptr);

@@ -21,7 +21,7 @@ vp = C.c_void_p
 # name -> (restype, argtypes): every symbol include/wcx.h declares.
 SIGNATURES = {
     "wcx_version": (C.c_int, []),
-    "wcx_debug_flags": (C.c_int, [C.c_int]),
+    "wcx_debug_flags": (C.c_int, [vp, C.c_int]),
     "wcx_last_error": (C.c_char_p, []),
     "wcx_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
     "wcx_ctx_destroy": (C.c_int, [vp]),

@@ -81,10 +81,10 @@ extern "C" {
 
 int wcx_version(void) { return 100; }
 
-extern int wcx_debug_value;
-int wcx_debug_flags(int flags) {
-  const int old = wcx_debug_value;
-  wcx_debug_value = flags;
+int wcx_debug_flags(wcx_ctx *ctx, int flags) {
+  if (!ctx) return 0;
+  const int old = ctx->debug_flags;
+  ctx->debug_flags = flags;
   return old;
 }
 

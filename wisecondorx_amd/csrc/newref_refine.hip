@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
       if (wcx::lane_id() == 0) atomicAdd(&glob->n_overflow, 1u);
       continue;
     }
-    const int n = cnt_out[r];
+    const int n = cnt_out[r] & 0x3fffffff;
     if (n > 512) continue;     // k_refine_big
     const int64_t row = row_begin + r;
     int64_t cs = 0, ce = chr.cum[0];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr
   __shared__ int si[CAP];
   for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
     if (!searched[r] || flags[r]) continue;
-    const int n = cnt_out[r];
+    const int n = cnt_out[r] & 0x3fffffff;
     if (n <= 512) continue;
     const int64_t row = row_begin + r;
     int64_t cs = 0, ce = chr.cum[0];

@@ -50,8 +50,13 @@ __device__ void bitonic_sort_lds(double *sd, int *si, int n) {
   __syncthreads();
 }
 
+// n_blocks_dev == nullptr: one workgroup per entry of `blocks` (grid = number of blocks), shortlist
+// scratch row = output row.  Otherwise (device-driven redo of rows the screen flagged): the
+// number of blocks is read from the device, the fixed grid strides over them and the scratch rows
+// are per workgroup (TM rows each).
 __global__ __launch_bounds__(NT) void k_topk_exact(
     const double *__restrict__ Xs, int64_t B, int S, const TopkBlock *__restrict__ blocks,
+    const unsigned int *__restrict__ n_blocks_dev,
     int k, int C, double *__restrict__ scr_d, int *__restrict__ scr_i, int64_t row_begin,
     int32_t *__restrict__ out_idx, double *__restrict__ out_dist,
     unsigned long long *__restrict__ stats) {
@@ -64,17 +69,20 @@ __global__ __launch_bounds__(NT) void k_topk_exact(
   double *sd = reinterpret_cast<double *>(smem + HDR);        // [C]   (aliases the tiles)
   int *si = reinterpret_cast<int *>(smem + HDR + (size_t)C * 8);  // [C]
 
-  const TopkBlock blk = blocks[blockIdx.x];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
-  const int64_t srow0 = blk.row0 - row_begin;  // scratch/output row of local row 0
+  const unsigned int n_blk = n_blocks_dev ? *n_blocks_dev : gridDim.x;
+  const int lim = C - TN;  // a row may receive at most TN appends per tile
+  unsigned long long n_compact = 0;
+  for (unsigned int bi = blockIdx.x; bi < n_blk; bi += gridDim.x) {
+  const TopkBlock blk = blocks[bi];
+  const int64_t orow0 = blk.row0 - row_begin;                       // output row of local row 0
+  const int64_t srow0 = n_blocks_dev ? (int64_t)blockIdx.x * TM : orow0;   // scratch row
 
+  __syncthreads();
   if (tid < TM) { tau[tid] = 1e10; cnt[tid] = 0; }
   if (tid == 0) *flag = 0;
   __syncthreads();
-
-  const int lim = C - TN;  // a row may receive at most TN appends per tile
-  unsigned long long n_compact = 0;
 
   auto compact_row = [&](int r, bool final_pass) {
     const int n = cnt[r];
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(NT) void k_topk_exact(
       for (int t = tid; t < keep; t += NT) { scr_d[base + t] = sd[t]; scr_i[base + t] = si[t]; }
       if (tid == 0) { cnt[r] = keep; tau[r] = (n >= k) ? sd[k - 1] : 1e10; }
     } else {
-      const int64_t ob = (srow0 + r) * (int64_t)k;
+      const int64_t ob = (orow0 + r) * (int64_t)k;
       for (int t = tid; t < k; t += NT) {
         out_idx[ob + t] = t < keep ? si[t] : -1;
         out_dist[ob + t] = t < keep ? sd[t] : 1e10;
@@ -174,7 +182,8 @@ __global__ __launch_bounds__(NT) void k_topk_exact(
     }
   }
   for (int r = 0; r < blk.nrows; ++r) compact_row(r, true);
-  if (tid == 0 && stats) atomicAdd(&stats[2], n_compact);
+  }
+  if (tid == 0 && stats && n_compact) atomicAdd(&stats[2], n_compact);
 }
 
 __global__ void k_fill_dummy(int32_t *idx, double *dist, int64_t n) {
@@ -228,9 +237,38 @@ int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   rc = wcx_timer_begin(ctx, "topk");
   if (rc) return rc;
   k_topk_exact<<<(unsigned)blocks.size(), NT, lds, ctx->stream>>>(
-      dXs, B, S, d_blocks, k, C, scr_d, scr_i, row_begin, d_out_idx, d_out_dist, d_stats);
+      dXs, B, S, d_blocks, nullptr, k, C, scr_d, scr_i, row_begin, d_out_idx, d_out_dist, d_stats);
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk");
   if (rc) return rc;
+  return WCX_OK;
+}
+
+// Device-driven redo (no host round trip): `d_blocks[0 .. *d_count)` was written by the screen's
+// k_collect_redo; a fixed grid of WCX_REDO_GRID workgroups strides over it (normally *d_count = 0
+// and the launch returns at once).  `scratch` must hold wcx_topk_redo_scratch_bytes(k) bytes.
+size_t wcx_topk_redo_scratch_bytes(int k) {
+  int C = 1024;
+  while (C < k + TN) C <<= 1;
+  return (size_t)WCX_REDO_GRID * TM * C * 12;
+}
+
+int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                               const TopkBlock *d_blocks, const unsigned int *d_count, void *scratch,
+                               int64_t row_begin, int k, int32_t *d_out_idx, double *d_out_dist) {
+  int C = 1024;
+  while (C < k + TN) C <<= 1;
+  const size_t tile_bytes = (size_t)JC * (TM + TN) * 8;
+  const size_t sort_bytes = (size_t)C * 12;
+  const size_t lds = HDR + (tile_bytes > sort_bytes ? tile_bytes : sort_bytes);
+  double *scr_d = reinterpret_cast<double *>(scratch);
+  int *scr_i = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) +
+                                       (size_t)WCX_REDO_GRID * TM * C * 8);
+  WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_topk_exact),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_topk_exact<<<WCX_REDO_GRID, NT, lds, ctx->stream>>>(dXs, B, S, d_blocks, d_count, k, C, scr_d,
+                                                        scr_i, row_begin, d_out_idx, d_out_dist,
+                                                        nullptr);
+  WCX_HIP(hipGetLastError());
   return WCX_OK;
 }

@@ -9,12 +9,18 @@
 //                  best-first sweep order: counting sort by (norm bucket, chromosome)
 //   k_screen_prep  a~ = fp16(2^p (x - c)) in MFMA-fragment order + four augmented k-columns that
 //                  carry |a~|^2; per row: representation-error norm      (rigorous error budget)
-//   k_screen       -2 a~.b~ Gram tiles on the matrix cores: v_mfma_f32_32x32x16_f16, fp32
-//                  accumulate; targets stay in registers as the B operand (their augmented
-//                  columns carry the current threshold), candidates stream through LDS as the A
-//                  operand; the screen test is the SIGN BIT of the accumulator; passing pairs are
-//                  appended to the target's shortlist, which is cut back by a wave-level bitwise
-//                  bisection select whenever it nears capacity.
+//   k_screen       (screen_kernel.h) -2 a~.b~ Gram tiles on the matrix cores:
+//                  v_mfma_f32_32x32x16_f16, fp32 accumulate; targets stay in registers as the B
+//                  operands (their augmented columns carry the current threshold), candidates
+//                  stream through LDS as the A operand; the screen test is the SIGN BIT of the
+//                  accumulator; passing pairs are appended to the target's shortlist, which is cut
+//                  back by a wave-level bitwise bisection select whenever it nears capacity.
+//                  The sweep starts with a SAMPLED PRE-PASS (every SF-th candidate group): the
+//                  r-th smallest value of the sample, r ~ k/SF + 6 sigma, is an estimate of the
+//                  final threshold that is tight enough to cut the appends of the main pass to
+//                  ~2 k per row and loose enough to hold the k nearest with overwhelming
+//                  probability; the final cut PROVES it (k values below it, their filter bound not
+//                  above it) or hands the row to the exact kernel -- results never depend on it.
 //   k_merge_segments (row shards with few target blocks only) joins per-segment shortlists.
 //   k_refine       exact sequential fp64 distance (newref_tools.py:260 arithmetic) of every
 //                  shortlisted pair, sort by (distance, index), emit the first k.
@@ -28,27 +34,12 @@
 //   only if d~ <= F = (sqrt(T) + E)^2 + Q.  Everything with d~ <= F is kept and refined exactly.
 //
 // Roofline: MFMA bound, 2*32*32*16 flop per instruction, dense f16 peak ~2.5 PFLOP/s.
+#include <cmath>
 #include <cstdlib>
 
-#include "wave_sort.h"
-#include "wcx_common.h"
-#include "screen_common.h"
-
-#pragma clang fp contract(off)
+#include "screen_kernel.h"
 
 namespace {
-
-__device__ __forceinline__ unsigned int f32_key(float t) {
-  const unsigned int u = __float_as_uint(t);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_f32(unsigned int kx) {
-  const unsigned int u = (kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx;
-  return __uint_as_float(u);
-}
-__device__ __forceinline__ float up(float v) {  // a float strictly above v (v >= 0, finite)
-  return v * 1.0000005f + 1e-37f;
-}
 
 // ------------------------------------------------------------------------------------------
 constexpr int CSPLIT = 16;   // workgroups per sample column
@@ -163,12 +154,16 @@ __global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xs, 
 
 // Cell histogram with workgroup-private LDS counters (the rows pile into a few dozen cells: global
 // atomics straight from every row serialise).
+// Rows b with b % SF == 0 (SF > 0) form the SAMPLE region at the head of the sweep (cells
+// [0, NCELL): one cell per chromosome), all other rows the main region (cells [NCELL, 2 NCELL),
+// best-first order).
 __global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict__ rbits,
-                                                 const int *__restrict__ rchr, int64_t B,
+                                                 const int *__restrict__ rchr, int64_t B, int SF,
+                                                 int fair_sample,
                                                  const ScreenGlobals *__restrict__ glob,
                                                  int *__restrict__ rkey, int *__restrict__ cellcnt) {
-  __shared__ int lh[NCELL];
-  for (int i = threadIdx.x; i < NCELL; i += NT) lh[i] = 0;
+  __shared__ int lh[2 * NCELL];
+  for (int i = threadIdx.x; i < 2 * NCELL; i += NT) lh[i] = 0;
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
   if (b < B) {
@@ -176,20 +171,28 @@ __global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict_
     const unsigned int u = rbits[b];
     unsigned int bucket = NBUCKET - 1;
     if (u != 0xffffffffu && u >= umin && u - umin < NBUCKET - 1) bucket = u - umin;
-    const int key = (int)bucket * 32 + rchr[b];
+    const bool sample = SF > 0 && (b % SF) == 0;
+    // sample rows of a SEGMENTED sweep: by chromosome only (bucket 0), i.e. in random order with
+    // respect to the norm, so that the split of the sample's groups over the candidate segments
+    // gives every segment a fair subsample (best-first order would hand the few groups that hold
+    // most of the nearest rows to one or two segments, whose estimates then come out too tight)
+    const int key = sample ? (fair_sample ? 0 : (int)bucket * 32) + rchr[b]
+                           : NCELL + (int)bucket * 32 + rchr[b];
     rkey[b] = key;
     atomicAdd(&lh[key], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NCELL; i += NT)
+  for (int i = threadIdx.x; i < 2 * NCELL; i += NT)
     if (lh[i]) atomicAdd(&cellcnt[i], lh[i]);
 }
 
+// Exclusive scan of the cell counts -> first sweep position of every cell; the main region starts
+// `pad` positions later so that the sample region ends on a group boundary.
 __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cellcnt,
-                                                     int *__restrict__ cursor) {
+                                                     int *__restrict__ cursor, int pad) {
   __shared__ int part[1024];
   const int t = threadIdx.x;
-  constexpr int PER = NCELL / 1024;
+  constexpr int PER = 2 * NCELL / 1024;
   int loc[PER], s = 0;
 #pragma unroll
   for (int i = 0; i < PER; ++i) { loc[i] = s; s += cellcnt[t * PER + i]; }
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cel
     part[t] += v;
     __syncthreads();
   }
-  const int base = part[t] - s;
+  const int base = part[t] - s + (t * PER >= NCELL ? pad : 0);
 #pragma unroll
   for (int i = 0; i < PER; ++i) cursor[t * PER + i] = base + loc[i];
 }
@@ -210,14 +213,14 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cel
 __global__ __launch_bounds__(NT) void k_scatter(const int *__restrict__ rkey, int64_t B,
                                                 int *__restrict__ cursor, int *__restrict__ perm,
                                                 int *__restrict__ rowpos) {
-  __shared__ int lh[NCELL];
-  for (int i = threadIdx.x; i < NCELL; i += NT) lh[i] = 0;
+  __shared__ int lh[2 * NCELL];
+  for (int i = threadIdx.x; i < 2 * NCELL; i += NT) lh[i] = 0;
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
   int key = 0, local = 0;
   if (b < B) { key = rkey[b]; local = atomicAdd(&lh[key], 1); }
   __syncthreads();
-  for (int i = threadIdx.x; i < NCELL; i += NT)
+  for (int i = threadIdx.x; i < 2 * NCELL; i += NT)
     if (lh[i]) lh[i] = atomicAdd(&cursor[i], lh[i]);        // count -> base of this workgroup's range
   __syncthreads();
   if (b < B) {
@@ -239,26 +242,6 @@ __global__ __launch_bounds__(NT) void k_group_mask(const int *__restrict__ perm,
   }
   gmask[g] = m;
 }
-
-// Two fp16 values h1 + h2 bracketing x from below (up = false) or above (up = true), with
-// sum = h1 + h2 EXACT in fp32 and no fp16 subnormals (quantum >= 2^-14; the matrix pipe may
-// flush them).  |x| <= 65000.  Error |x - sum| < max(2^-21 |x|, 2^-14).
-__device__ __forceinline__ void split16(float x, bool up, _Float16 &h1, _Float16 &h2, float &sum) {
-  h1 = (_Float16)x;                       // round to nearest
-  const float f1 = (float)h1;
-  const float r = x - f1;                 // exact (Sterbenz)
-  int eb = (int)((__float_as_uint(f1) >> 23) & 0xffu) - 21;
-  if (eb < 113) eb = 113;
-  const float q = __uint_as_float((unsigned int)eb << 23);
-  const float m = up ? ceilf(r / q) : floorf(r / q);   // |m| <= 1024
-  const float f2 = m * q;
-  h2 = (_Float16)f2;                      // exact
-  sum = f1 + f2;                          // exact: a multiple of q below 2^(e+1)
-}
-
-constexpr float AUG = 32768.f;            // the constant factor of the augmented products
-constexpr float GMAX = 4.0e9f;            // thresholds at or above this count as "none yet"
-constexpr float SLOW_OFF = 3.75e9f;       // slow-path pass offset: real rows pass, padding fails
 
 // One thread per sweep POSITION p (the row it holds is perm[p], -1 = padding): fp16 image of the
 // centred, scaled row in MFMA-fragment order + the augmented columns.
@@ -337,426 +320,51 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
   }
 }
 
+
 // ------------------------------------------------------------------------------------------
-struct ScreenBlock {
-  int64_t row0;
-  int32_t nrows;  // <= TGT
-  int32_t chr;    // chromosome index of the target rows
-  int64_t cs, ce;
-};
-
-// Error budget of one target row (see the file header): na = |a~|^2 as encoded, E, Q.
-// |computed t - exact hi-plane t| <= Q: fp32 accumulation of the 16 NK products (data columns
-// + the nb'/2 and G'/2 columns: sum |x y| <= N_a N_max + (N_a + N_max)^2), the rounding of
-// t = G' - 2 acc, and nb - nb' < 2^-21 nb + 4.  gamma = (16 NK + 8) 2^-23.
-__device__ __forceinline__ void row_budget(const RowInfo &ti, float e_max, float N_max, float gamma,
-                                           float &na, float &E, float &Q) {
-  na = ti.nb;
-  E = up(ti.e + e_max);
-  const float nsum = ti.N + N_max;
-  Q = up(2.f * gamma * ti.N * N_max + 4.8e-7f * (ti.N * ti.N + 2.f * N_max * N_max) +
-         2.2f * gamma * nsum * nsum + 4.f);
-}
-constexpr float G_INIT = 3.0e38f;   // "no threshold yet" (finite on purpose)
-
-// Wave-level shortlist compaction of one target of this wave, in two halves so that a burst of
-// compactions can have the NEXT target's 8 KB in flight while the current one is processed.
-// Shortlist entries are (float bits of t, sweep position).
-//
-// All CAP slots exist in memory: load unconditionally (16 independent loads in flight; a load
-// under `if (e < n)` made the compiler wait for each one in turn -- 16 serial round trips to HBM,
-// ~40k cycles per compaction) and mask afterwards.
-__device__ __forceinline__ void load_shortlist(const uint2 *__restrict__ sl_row, uint2 (&raw)[CAP / 64]) {
-  const int lane = wcx::lane_id();
-#pragma unroll
-  for (int q = 0; q < CAP / 64; ++q) raw[q] = sl_row[q * 64 + lane];
-}
-
-// Returns the new threshold G (t-space) and the new count (n_out; 0 + overflow flag when the list
-// cannot be cut below LIM).  exact: resolve the k-th key to the last bit (final cut), else to
-// 2^-11 relative -- the resolution of the fp16 screen itself -- rounded up (in-sweep cuts: a tight
-// threshold matters, every later candidate passes with probability ~ rank/n).
-__device__ __forceinline__ float compact_loaded(const uint2 (&raw)[CAP / 64], int n,
-                                                uint2 *__restrict__ sl_row, int k, float na, float E,
-                                                float Q, float G_old, unsigned int *overflow_flag,
-                                                bool exact, int &n_out) {
-  const int lane = wcx::lane_id();
-  unsigned int key[CAP / 64], idx[CAP / 64];
-#pragma unroll
-  for (int q = 0; q < CAP / 64; ++q) {
-    const bool in = q * 64 + lane < n;
-    key[q] = in ? f32_key(__uint_as_float(raw[q].x)) : 0xffffffffu;
-    idx[q] = in ? raw[q].y : 0u;
-  }
-  float G = G_old;
-  if (n >= k) {
-    // k-th smallest key by bitwise bisection (ballot counts): largest v with #(key < v) < k.
-    // The keys share their leading bits (sign, exponent, ...): start below the common prefix.
-    const unsigned int kref = (unsigned int)__builtin_amdgcn_readfirstlane((int)key[0]);
-    unsigned int x = 0;
-#pragma unroll
-    for (int q = 0; q < CAP / 64; ++q) x |= (q * 64 + lane < n) ? (key[q] ^ kref) : 0u;
-    x = wcx::wave_or_u32(x);
-    const int hb = 31 - __builtin_clz(x | 1u);              // highest differing bit (0 if none)
-    unsigned int prefix = kref & ~((2u << hb) - 1u);
-    const int low = exact ? 0 : 12;
-    for (int bit = hb; bit >= low; --bit) {
-      const unsigned int trial = prefix | (1u << bit);
-      int c = 0;
-#pragma unroll
-      for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] < trial));
-      if (c < k) prefix = trial;
-    }
-    if (!exact && hb >= 12) prefix |= 0xfffu;
-    if (!exact && hb < 12) prefix |= (2u << hb) - 1u;       // all keys within the low bits: upper end
-    const float tk = key_f32(prefix);
-    // T-space -> distance space -> filter bound F -> back to t-space, rounded outwards
-    float dk = tk + na;
-    dk = dk > 0.f ? dk : 0.f;
-    const float rt = sqrtf(up(dk + Q)) * 1.0000005f + 2.f * E;
-    const float Fb = up(up(rt * rt) + Q);
-    const float Gn = (Fb - na) + 4e-7f * (Fb + na);
-    if (tk < HUGE_VALF && Gn < G_old) G = Gn;   // (NaN / inf bound: keep the old threshold)
-  }
-  // keep entries with t <= G
-  const unsigned int gkey = f32_key(G);
-  int base = 0;
-#pragma unroll
-  for (int q = 0; q < CAP / 64; ++q) {
-    const bool keep = (q * 64 + lane < n) && (key[q] <= gkey);
-    const unsigned long long m = __ballot(keep);
-    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (keep) sl_row[pos] = make_uint2(__float_as_uint(key_f32(key[q])), idx[q]);
-    base += __popcll(m);
-  }
-  if (base > LIM) {   // cannot make room: hand the row to the exact kernel
-    if (lane == 0) *overflow_flag = 1u;
-    n_out = 0;
-    return -HUGE_VALF;
-  }
-  n_out = base;
-  return G;
-}
-
-// Threshold -> the two fp16 values of the target's augmented columns and the value G' they encode.
-__device__ __forceinline__ void encode_threshold(float G, _Float16 &w1, _Float16 &w2, float &Gp) {
-  if (G < -GMAX) {            // nothing may pass (unused target lane, overflowed row)
-    w1 = (_Float16)-65504.f; w2 = (_Float16)-65504.f; Gp = -131008.f * 65536.f;
-  } else if (G < GMAX) {
-    float s;
-    split16(G * (1.f / 65536.f), true, w1, w2, s);
-    Gp = s * 65536.f;
-  } else {                    // no threshold yet: columns off, the slow path passes every real row
-    w1 = (_Float16)0; w2 = (_Float16)0; Gp = 0.f;
-  }
-}
-
-// NK = k-steps of 16 (K = 16 NK >= S + 4), CTG = candidate sub-tiles of 32 rows per iteration.
-// PROF = per-phase s_memtime accounting into stats[8..13] (diagnostics, debug flag 4).
-template <int NK, int CTG, bool PROF = false>
-__global__ __launch_bounds__(NT, (NK <= 8 ? 3 : 2)) void k_screen(
-    const half8 *__restrict__ F, const RowInfo *__restrict__ info,
-    const ScreenGlobals *__restrict__ glob,
-    const int *__restrict__ perm, const int *__restrict__ rowpos,
-    const unsigned int *__restrict__ gmask,
-    const ScreenBlock *__restrict__ blocks, int k, int64_t row_begin,
-    uint2 *__restrict__ sl, int *__restrict__ cnt_out, unsigned int *__restrict__ flags,
-    float *__restrict__ g_state, int64_t gi_begin, int64_t gi_end, int first, int last,
-    unsigned long long *__restrict__ stats, int dbg, int n_seg, int64_t n_rows_all) {
-  // The candidate sweep is cut into chunks [gi_begin,gi_end) of groups, one launch per chunk:
-  // every workgroup of a launch streams the SAME few MB of candidate fragments, which therefore
-  // come out of the XCD L2s instead of HBM/MALL.  Per-target state (threshold G, shortlist
-  // count) lives in g_state/cnt_out between launches; the shortlists are in HBM anyway.
-  constexpr int GR = CTG * 32;                      // candidate rows per iteration
-  constexpr int TILE_H8 = CTG * NK * 64;            // half8 elements per staged candidate group
-  constexpr int NPT = (TILE_H8 + NT - 1) / NT;      // 16-byte pieces per thread
-  constexpr int NOUT = CTG * 16;                    // screen outputs per lane per iteration
-  extern __shared__ __align__(16) unsigned char smem[];
-  half8 *sbuf = reinterpret_cast<half8 *>(smem);                       // [2][TILE_H8]
-  int *glist = reinterpret_cast<int *>(smem + 2 * TILE_H8 * 16);       // [groups of the chunk]
-  __shared__ int s_nlist;
-
-  // Candidate segments: with few target blocks (a row shard of a multi-GPU build) every block is
-  // issued n_seg times; copy `seg` sweeps the candidate groups g = seg (mod n_seg) into its own
-  // shortlists / thresholds (arrays offset by seg * n_rows_all); k_merge_segments joins them.
-  const int n_blocks = (int)gridDim.x / n_seg;
-  const int seg = (int)blockIdx.x / n_blocks;
-  const ScreenBlock blk = blocks[(int)blockIdx.x - seg * n_blocks];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int tl = wave * 32 + (lane & 31);        // local target of this lane
-  const int hf = lane >> 5;
-  const bool tvalid = tl < blk.nrows;
-  const int64_t trow = tvalid ? blk.row0 + tl : blk.row0;
-  const int64_t soff = (int64_t)seg * n_rows_all;
-  const int64_t srow = trow - row_begin + soff;
-  const int64_t wg_srow = blk.row0 - row_begin + soff;
-  uint2 *wg_sl = sl + wg_srow * (int64_t)CAP;    // this workgroup's TGT shortlists (uniform base)
-
-  // Visit list of this launch's chunk, built once per workgroup in LDS: groups holding only
-  // own-chromosome rows are skipped (gmask = chromosomes present per 64 rows); bit 31 marks groups
-  // that also contain own-chromosome rows.
-  const unsigned int blkbit = 1u << blk.chr;
-  if (wave == 0) {
-    int count = 0;
-    for (int64_t g0 = gi_begin; g0 < gi_end; g0 += 64) {
-      const int64_t g = g0 + lane;
-      unsigned int m = blkbit;
-      if (g < gi_end) m = gmask[(g * GR) >> 6];
-      const bool keep = (g < gi_end) && m != blkbit && ((int)g & (n_seg - 1)) == seg;
-      const unsigned long long bal = __ballot(keep);
-      if (keep) glist[count + __popcll(bal & ((1ull << lane) - 1ull))] =
-          (int)g | ((m & blkbit) ? (int)0x80000000 : 0);
-      count += __popcll(bal);
-    }
-    if (lane == 0) s_nlist = count;
-  }
-
-  // target operand (B operand of the MFMA) stays in registers for the whole sweep
-  const RowInfo ti = info[rowpos[trow]];
-  half8 th[NK];
-  {
-    const int64_t tpos = rowpos[trow];        // sweep position of the target row
-    const int64_t ttile = tpos >> 5;
-    const int trl = (int)(tpos & 31);
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) th[ks] = F[(ttile * NK + ks) * 64 + trl + 32 * hf];
-  }
-  const float e_max = __uint_as_float(glob->e_max), N_max = __uint_as_float(glob->N_max);
-  float na, E, Q;
-  row_budget(ti, e_max, N_max, (float)(16 * NK + 8) * 1.1920929e-7f, na, E, Q);
-  float G = tvalid ? (first ? G_INIT : g_state[srow]) : -HUGE_VALF;
-  float Gp;
-  {
-    _Float16 w1, w2;
-    encode_threshold(G, w1, w2, Gp);
-    if (hf) { th[NK - 1][4] = (_Float16)AUG; th[NK - 1][5] = (_Float16)AUG;
-              th[NK - 1][6] = w1; th[NK - 1][7] = w2; }
-  }
-  int n_compact = 0, n_app = 0;
-  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0;
-  auto stamp = [&](int ph) {
-    if (PROF) {
-      const unsigned long long now = __builtin_amdgcn_s_memtime();
-      pt[ph] += now - tp;
-      tp = now;
-    }
-  };
-
-  half8 pre[NPT];
-  auto fetch = [&](int gix) {
-    const half8 *src = F + (int64_t)gix * TILE_H8;
-#pragma unroll
-    for (int p = 0; p < NPT; ++p)
-      if ((p + 1) * NT <= TILE_H8 || p * NT + tid < TILE_H8) pre[p] = src[p * NT + tid];
-  };
-  int buf = 0;
-  __syncthreads();
-  const int n_list = s_nlist;
-  int cur = n_list > 0 ? glist[0] : 0;
-  if (n_list > 0) {
-    fetch(cur & 0x7fffffff);
-#pragma unroll
-    for (int p = 0; p < NPT; ++p)
-      if ((p + 1) * NT <= TILE_H8 || p * NT + tid < TILE_H8) sbuf[p * NT + tid] = pre[p];
-  }
-  // shortlist count of my target, kept in a register (identical in the target's two lanes)
-  int cntr = (first || !tvalid) ? 0 : cnt_out[srow];
-  __syncthreads();
-  bool fast = false;
-  // A burst of compactions (targets of this wave flagged in `need`): the next target's shortlist
-  // is loaded while the current one is selected and written back.
-  auto run_compactions = [&](unsigned int need, bool exact) {
-    const float G_before = G;
-    // this wave's appends must be visible before they are re-read
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    int c = __ffs((int)need) - 1;
-    need &= need - 1;
-    uint2 raw[CAP / 64];
-    load_shortlist(sl + (wg_srow + wave * 32 + c) * (int64_t)CAP, raw);
-    for (;;) {
-      const int cn = need ? __ffs((int)need) - 1 : -1;
-      need &= need - 1;
-      uint2 rawn[CAP / 64];
-      if (NK <= 8 && cn >= 0) load_shortlist(sl + (wg_srow + wave * 32 + cn) * (int64_t)CAP, rawn);
-      const int64_t crow_s = wg_srow + wave * 32 + c;
-      const float na_c = __shfl(na, c, 64), E_c = __shfl(E, c, 64), Q_c = __shfl(Q, c, 64),
-                  G_c = __shfl(G, c, 64);
-      const int n_c = __builtin_amdgcn_readlane(cntr, c);
-      int n_new;
-      const float Gn = compact_loaded(raw, n_c, sl + crow_s * (int64_t)CAP, k, na_c, E_c, Q_c, G_c,
-                                      &flags[crow_s], exact, n_new);
-      if ((lane & 31) == c) { G = Gn; cntr = n_new; }
-      ++n_compact;
-      if (cn < 0) break;
-      c = cn;
-      if (NK <= 8) {
-#pragma unroll
-        for (int q = 0; q < CAP / 64; ++q) raw[q] = rawn[q];
-      } else {                       // large K: no registers to spare for the look-ahead
-        load_shortlist(sl + (wg_srow + wave * 32 + c) * (int64_t)CAP, raw);
-      }
-    }
-    if (G != G_before) {
-      _Float16 w1, w2;
-      encode_threshold(G, w1, w2, Gp);
-      if (hf) { th[NK - 1][6] = w1; th[NK - 1][7] = w2; }
-    }
-  };
-  for (int j = 0; j < n_list; ++j) {
-    // Order inside an iteration: issue the next group's global loads, run the MFMA block on the
-    // current LDS buffer, park the loaded group in the other buffer, barrier, THEN do the
-    // shortlist appends.  The appends' stores share the vmcnt counter with the loads; in this order
-    // nobody waits for a store until a whole MFMA block later.
-    const int nxt = (j + 1 < n_list) ? glist[j + 1] : 0;
-    half8 *sb = sbuf + buf * TILE_H8;
-    const int gix = cur & 0x7fffffff;
-    const bool mixed = cur < 0;                  // some own-chromosome rows in this group
-    if (PROF) tp = __builtin_amdgcn_s_memtime();
-    if (j + 1 < n_list) fetch(nxt & 0x7fffffff);
-
-    // acc = g~ - nb'/2 + G'/2 straight out of the matrix pipe (see k_screen_prep); A fragments
-    // are read lane-linearly (conflict-free ds_read_b128), a few reads ahead of their MFMA.
-    f32x16 acc[CTG];
-#pragma unroll
-    for (int sub = 0; sub < CTG; ++sub)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[sub][r] = 0.f;
-    {
-      half8 a[NK][CTG];
-#pragma unroll
-      for (int ks = 0; ks < NK; ++ks)
-#pragma unroll
-        for (int sub = 0; sub < CTG; ++sub) a[ks][sub] = sb[(sub * NK + ks) * 64 + lane];
-#pragma unroll
-      for (int ks = 0; ks < NK; ++ks)
-#pragma unroll
-        for (int sub = 0; sub < CTG; ++sub)
-          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][sub], th[ks], acc[sub], 0, 0, 0);
-      // schedule: PRE reads up front, then one read per MFMA, the last PRE MFMAs back to back
-      constexpr int NM = NK * CTG, PRE = NM < 6 ? NM : 6;
-      __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
-#pragma unroll
-      for (int i = 0; i < NM - PRE; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, PRE, 0);
-    }
-    stamp(0);                                    // loads issued + MFMA block issued
-    if (j + 1 < n_list) {
-      half8 *so = sbuf + (buf ^ 1) * TILE_H8;
-#pragma unroll
-      for (int p = 0; p < NPT; ++p)
-        if ((p + 1) * NT <= TILE_H8 || p * NT + tid < TILE_H8) so[p * NT + tid] = pre[p];
-    }
-    stamp(1);                                    // wait for the loads + LDS writes
-    __syncthreads();
-    stamp(2);                                    // barrier
-    // C[row = candidate][col = target]; output rr = sub*16 + r is candidate row
-    // loc(rr) = sub*32 + 8*(r>>2) + 4*(lane>>5) + (r&3) of this group.  Bit (31-rr) of pmask.
-    if (!fast) fast = __all(G < GMAX);           // G only ever decreases
-    unsigned int negs[CTG];                      // one dependent chain per sub-tile
-    if (fast) {
-#pragma unroll
-      for (int sub = 0; sub < CTG; ++sub) {
-        negs[sub] = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          negs[sub] = __builtin_amdgcn_alignbit(negs[sub], __float_as_uint(acc[sub][r]), 31);
-      }
-    } else {
-      asm volatile("; slow path" ::: "memory");
-      const float off = (G < GMAX) ? 0.f : SLOW_OFF;   // lanes without a threshold: pass real rows
-#pragma unroll
-      for (int sub = 0; sub < CTG; ++sub) {
-        negs[sub] = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          negs[sub] = __builtin_amdgcn_alignbit(negs[sub], __float_as_uint(acc[sub][r] + off), 31);
-      }
-    }
-    unsigned int neg = negs[0];
-    if (CTG == 2) neg = (negs[0] << 16) | (negs[CTG - 1] & 0xffffu);
-    unsigned int pmask = (~neg) << (32 - NOUT);
-    if (mixed) {   // rare: mask the own-chromosome rows of a mixed group
-      asm volatile("; mixed group" ::: "memory");   // keep this a branch (no if-conversion)
-      const int cs32 = (int)blk.cs, ce32 = (int)blk.ce;
-#pragma unroll 1
-      for (int rr = 0; rr < NOUT; ++rr) {
-        const int loc = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + 4 * hf + (rr & 3);
-        const int g = perm[(int64_t)gix * GR + loc];
-        if (g >= cs32 && g < ce32) pmask &= ~(0x80000000u >> rr);
-      }
-    }
-    if (dbg & 1) pmask = 0;
-    const unsigned int anym = wcx::wave_or_u32(pmask);       // wave-uniform
-    stamp(3);                                    // MFMA completion + sign bits + OR
-    if (anym) {
-      // slot reservation without LDS: the target's two lanes (l, l+32) swap their pass counts
-      // (appends staged in LDS and flushed as whole 128-byte lines were measured: no gain)
-      const unsigned int pc = (unsigned int)__popc(pmask);
-      const auto pcs = __builtin_amdgcn_permlane32_swap(pc, pc, false, false);   // {low, high} lane's
-      unsigned int ofs = (unsigned int)(tl * CAP + cntr + (hf ? (int)pcs[0] : 0));
-      cntr += (int)(pcs[0] + pcs[1]);
-      n_app += (int)pc;
-      // cntr <= LIM + CT = CAP: the slots exist (counts are cut back to <= LIM below)
-      const unsigned int pbase = (unsigned int)(gix * GR + 4 * hf);
-#pragma unroll
-      for (int rr = 0; rr < NOUT; ++rr) {
-        if (anym & (0x80000000u >> rr)) {                    // scalar branch: skip empty outputs
-          asm volatile("" ::: "memory");                     // (keeps the two tests separate)
-          if (pmask & (0x80000000u >> rr)) {
-            const int loc0 = (rr >> 4) * 32 + 8 * ((rr >> 2) & 3) + (rr & 3);
-            const float t = fmaf(-2.f, acc[rr >> 4][rr & 15], Gp);
-            wg_sl[ofs] = make_uint2(__float_as_uint(t), pbase + loc0);
-            ++ofs;
-          }
-        }
-      }
-      stamp(4);                                  // appends
-      // shortlist maintenance: wave-private (this wave's 32 targets); counts only change here
-      const int trig = (dbg >> 8) ? (dbg >> 8) : LIM;         // (diagnostics: earlier cuts)
-      const unsigned int need = (unsigned int)__ballot(tvalid && cntr > trig);   // low half = targets
-      if (need) run_compactions(need, false);
-    }
-    stamp(5);                                    // maintenance (compactions)
-    buf ^= 1;
-    cur = nxt;
-  }
-  if (last) {
-    // final cut of every target's shortlist with its final threshold (exact k-th key)
-    const int nv = blk.nrows - wave * 32;
-    if (nv > 0) run_compactions(nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u), true);
-  } else if (tvalid && hf == 0) {
-    g_state[srow] = G;
-  }
-  if (tvalid && hf == 0) cnt_out[srow] = cntr;
-  if (stats) {
-    const int tot_c = wcx::wave_sum_i(n_compact), tot_a = wcx::wave_sum_i(n_app);
-    if (lane == 0) {
-      atomicAdd(&stats[2], (unsigned long long)(tot_c / 64));
-      atomicAdd(&stats[4], (unsigned long long)tot_a);
-      if (PROF)
-        for (int i = 0; i < 6; ++i) atomicAdd(&stats[8 + i], pt[i]);
-    }
-  }
-}
-
 __global__ void k_mark(unsigned char *searched, const ScreenBlock *__restrict__ blocks,
                        int64_t row_begin) {
   const ScreenBlock b = blocks[blockIdx.x];
-  if ((int)threadIdx.x < b.nrows) searched[b.row0 - row_begin + threadIdx.x] = 1;
+  for (int i = threadIdx.x; i < b.nrows; i += blockDim.x) searched[b.row0 - row_begin + i] = 1;
 }
 
-// Joins the shortlists of candidate segments s0 and s1 of every row into s0's: exact cut of the
-// union at its k-th smallest screen value (every row's true neighbours are in the union of the
-// segments' own top lists).  One wave per row.
+// min over the candidate segments of a row's threshold, with the estimate bit of the winner
+// (a tie is rigorous if either is)
+__device__ __forceinline__ void min_threshold(float G0, int e0, float G1, int e1, float &G, int &e) {
+  if (G0 < G1) { G = G0; e = e0; }
+  else if (G1 < G0) { G = G1; e = e1; }
+  else { G = G0; e = e0 & e1; }
+}
+
+// After the sampled pre-pass of a segmented sweep: every segment of a row continues with the
+// tightest of the segments' estimates (each is an estimate of the same final threshold).
+__global__ __launch_bounds__(NT) void k_share_thresholds(int64_t n_rows, int n_seg,
+                                                         const unsigned char *__restrict__ searched,
+                                                         float *__restrict__ g_state,
+                                                         int *__restrict__ cnt) {
+  const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (r >= n_rows || !searched[r]) return;
+  float G = g_state[r];
+  int e = (cnt[r] >> 30) & 1;
+  for (int s = 1; s < n_seg; ++s)
+    min_threshold(G, e, g_state[(int64_t)s * n_rows + r], (cnt[(int64_t)s * n_rows + r] >> 30) & 1, G, e);
+  for (int s = 0; s < n_seg; ++s) {
+    const int64_t i = (int64_t)s * n_rows + r;
+    g_state[i] = G;
+    cnt[i] = (cnt[i] & CNT_MASK) | (e << 30);
+  }
+}
+
+// Joins the shortlists of candidate segments s0 and s1 of every row into s0's: cut of the union
+// at its k-th smallest screen value.  State (G, est) of the union: everything of both segments
+// with t <= min(G0, G1) is in it.  is_root: the last merge -- a still unproven estimate hands the
+// row to the exact kernel.  One wave per row.
 __global__ __launch_bounds__(NT) void k_merge_segments(
     const RowInfo *__restrict__ info, const ScreenGlobals *__restrict__ glob,
     const int *__restrict__ rowpos, int64_t row_begin, int64_t n_rows,
     const unsigned char *__restrict__ searched, uint2 *__restrict__ sl, int *__restrict__ cnt,
-    unsigned int *__restrict__ flags, int s0, int s1, int k, float gamma) {
+    unsigned int *__restrict__ flags, float *__restrict__ g_state, int s0, int s1, int k,
+    float gamma, int is_root) {
   const int lane = wcx::lane_id();
   const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
@@ -764,9 +372,10 @@ __global__ __launch_bounds__(NT) void k_merge_segments(
   for (int64_t r = w0; r < n_rows; r += nw) {
     if (!searched[r]) continue;
     const int64_t i0 = (int64_t)s0 * n_rows + r, i1 = (int64_t)s1 * n_rows + r;
-    const int n0 = cnt[i0], n1 = cnt[i1];
+    const int c0 = cnt[i0], c1 = cnt[i1];
+    const int n0 = c0 & CNT_MASK, n1 = c1 & CNT_MASK;
     if (flags[i0] | flags[i1] | (unsigned int)(n0 + n1 > CAP)) {   // -> exact fallback
-      if (lane == 0) flags[i0] = 1u;
+      if (lane == 0) { flags[i0] = 1u; cnt[i0] = 0; }
       continue;
     }
     uint2 raw[CAP / 64];
@@ -775,12 +384,35 @@ __global__ __launch_bounds__(NT) void k_merge_segments(
       const int e = q * 64 + lane;
       raw[q] = e < n0 ? sl[i0 * CAP + e] : sl[i1 * CAP + (e - n0 < CAP ? e - n0 : 0)];
     }
-    float na, E, Q;
+    float na, E, Q, Gm;
+    int em;
     row_budget(info[rowpos[row_begin + r]], e_max, N_max, gamma, na, E, Q);
-    int n_new;
-    (void)compact_loaded(raw, n0 + n1, sl + i0 * CAP, k, na, E, Q, G_INIT, &flags[i0], true, n_new);
-    if (lane == 0) cnt[i0] = n_new;
+    min_threshold(g_state[i0], (c0 >> 30) & 1, g_state[i1], (c1 >> 30) & 1, Gm, em);
+    int n_new, e_new;
+    const float Gn = compact_loaded(raw, n0 + n1, sl + i0 * CAP, k, na, E, Q, Gm, em, 2, is_root != 0,
+                                    &flags[i0], n_new, e_new);
+    if (lane == 0) { cnt[i0] = n_new | (e_new << 30); g_state[i0] = Gn; }
   }
+}
+
+// Rows the screen could not finish (shortlist overflow, unproven estimate) -> redo list for the
+// exact kernel, built on the device: no host round trip.
+__global__ __launch_bounds__(NT) void k_collect_redo(int64_t row_begin, int64_t n_rows,
+                                                     const unsigned char *__restrict__ searched,
+                                                     const unsigned int *__restrict__ flags,
+                                                     ChrTab chr, TopkBlock *__restrict__ redo,
+                                                     unsigned int *__restrict__ n_redo,
+                                                     unsigned long long *__restrict__ stats) {
+  const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (r >= n_rows || !searched[r] || !flags[r]) return;
+  const int64_t row = row_begin + r;
+  int64_t cs = 0, ce = chr.cum[0];
+  for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+  const unsigned int slot = atomicAdd(n_redo, 1u);
+  TopkBlock b;
+  b.row0 = row; b.nrows = 1; b.pad = 0; b.cs = cs; b.ce = ce;
+  redo[slot] = b;
+  atomicAdd(&stats[3], 1ull);
 }
 
 }  // namespace
@@ -795,9 +427,24 @@ int wcx_transpose_launch(wcx_ctx *ctx, const double *src, int64_t rows, int64_t 
   return WCX_OK;
 }
 
-int wcx_debug_value = 0;   // diagnostics only (wcx_debug_flags): ablation switches for profiling
 bool wcx_screen_supported(int64_t B, int S, int k) {
   return S <= 508 && k <= 512 && k <= LIM && B >= 2048;
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+
+static int screen_dispatch(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds,
+                           hipStream_t st) {
+  int rc = wcx_screen_launch_k1(c, a, grid, lds, st);
+  if (rc < 0) rc = wcx_screen_launch_k2(c, a, grid, lds, st);
+  if (rc < 0) rc = wcx_screen_launch_k3(c, a, grid, lds, st);
+  if (rc < 0) rc = wcx_screen_launch_k4(c, a, grid, lds, st);
+  if (rc < 0) rc = wcx_screen_launch_k5(c, a, grid, lds, st);
+  if (rc < 0) rc = wcx_screen_launch_k6(c, a, grid, lds, st);
+  return rc;
 }
 
 int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
@@ -813,9 +460,34 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   int NK = 32;
   for (int v : nk_list)
     if (16 * v >= S + 4) { NK = v; break; }
-  const int CTG = NK <= 16 ? 2 : 1;
-  const int64_t Bpad = (B + CT - 1) / CT * CT;
-  // regroup the searched row ranges into workgroups of <= 128 rows (same chromosome)
+  // Kernel configuration: small K keeps TWO target tiles per wave in registers (every candidate
+  // fragment read from LDS feeds two MFMAs, one barrier per 4 NK MFMAs); large K uses eight
+  // waves per workgroup so that 256 targets share every staged candidate group.
+  ScreenCfg cfg;
+  cfg.nk = NK;
+  cfg.prof = (ctx->debug_flags & 4) && (NK == 7 || NK == 32) ? 1 : 0;
+  // Kernel configuration (measured on MI355X): 128 targets per workgroup; small K:
+  // 64 candidates per iteration, 3 waves per SIMD, LDS-DMA ring of 3; large K: 2 waves per SIMD
+  // (the targets' fragments alone take 4 NK registers), LDS-DMA double buffer.
+  if (NK <= 8) { cfg.ctg = 2; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 3; cfg.ring = 3; }
+  else { cfg.ctg = NK <= 16 ? 2 : 1; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 2; cfg.ring = 2; }
+  if (const char *e = getenv("WCX_SCREEN_TILE")) {     // testing / tuning: "ctg,tt,wpb,lb,ring"
+    int a = 0, b = 0, c = 0, d = 0, r = 0;
+    if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &r) == 5) {
+      cfg.ctg = a; cfg.tt = b; cfg.wpb = c; cfg.lb = d; cfg.ring = r;
+    }
+  }
+  const int CTG = cfg.ctg;
+  const int TGT_WG = 32 * cfg.tt * cfg.wpb;
+  const int GRr = CTG * 32;
+  // Sampled pre-pass: the rows b = 0 (mod SF) are swept first (own region of the sweep order).
+  int SF = (B >= 32768) ? 16 : 0;
+  SF = env_int("WCX_SCREEN_SAMPLE", SF);
+  if (SF < 2 || SF > 64) SF = 0;
+  const int64_t n_s = SF ? (B + SF - 1) / SF : 0;             // rows in the sample
+  const int64_t P_s = (n_s + CT - 1) / CT * CT;               // positions of the sample region
+  const int64_t Bpad = P_s + ((B - n_s) + CT - 1) / CT * CT;
+  // regroup the searched row ranges into workgroups of <= TGT_WG rows (same chromosome)
   std::vector<ScreenBlock> blocks;
   {
     size_t i = 0;
@@ -830,7 +502,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       sb.ce = exact_blocks[i].ce;
       size_t j = i + 1;
       while (j < exact_blocks.size() && exact_blocks[j].cs == sb.cs &&
-             exact_blocks[j].row0 == sb.row0 + sb.nrows && sb.nrows + exact_blocks[j].nrows <= TGT) {
+             exact_blocks[j].row0 == sb.row0 + sb.nrows && sb.nrows + exact_blocks[j].nrows <= TGT_WG) {
         sb.nrows += exact_blocks[j].nrows;
         ++j;
       }
@@ -838,12 +510,34 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       i = j;
     }
   }
-  // candidate segments: fill the chip when a row shard has few target blocks (multi-GPU builds)
+  const int64_t n_iter_groups = Bpad / GRr;
+  // Candidate segments fill the chip when a row shard has few target blocks (multi-GPU builds)
+  // and even out the last round of workgroups: work items = blocks x segments.
+  int hw_cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+      hw_cus = prop.multiProcessorCount;
+  }
+  const int wg_per_cu = cfg.lb * 4 / cfg.wpb > 0 ? cfg.lb * 4 / cfg.wpb : 1;
+  const int slots = hw_cus * wg_per_cu;
   int n_seg = 1;
-  if (blocks.size() < 512) n_seg = 2;      // measured: 2 helps below ~500 blocks, 4 never does
-  if (const char *e = getenv("WCX_SCREEN_SEGMENTS")) {   // testing / tuning: 1, 2 or 4
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) n_seg = v;
+  if ((int)blocks.size() < slots) {
+    n_seg = (int)((2 * slots + blocks.size() - 1) / blocks.size());   // >= 2 rounds of work items
+    if (n_seg > 8) n_seg = 8;
+  }
+  n_seg = env_int("WCX_SCREEN_SEGMENTS", n_seg);
+  if (n_seg < 1) n_seg = 1;
+  if (n_seg > 8) n_seg = 8;
+  // r = a rank in the sample that the k-th nearest of all candidates stays below with
+  // overwhelming probability (mean k/SF of the k nearest fall into the sample; + 10 % for the
+  // uneven share of the own chromosome, + 6 sigma): the estimate admits ~r SF candidates.
+  int cut_r = 0;
+  if (SF) {
+    const double kf = (double)k / ((double)SF * n_seg);
+    cut_r = (int)ceil(1.1 * kf + 6.0 * sqrt(kf)) + 1;
+    // the sample must hold several times cut_r candidates and cut_r must be well below k
+    if (cut_r * 2 > k || P_s / n_seg < 16 * (int64_t)cut_r) cut_r = 0;
   }
   // scratch layout
   size_t off = 0;
@@ -860,8 +554,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_rbit = carve((size_t)B * 4);
   const size_t o_rchr = carve((size_t)B * 4);
   const size_t o_rkey = carve((size_t)B * 4);
-  const size_t o_cell = carve((size_t)NCELL * 4);
-  const size_t o_curs = carve((size_t)NCELL * 4);
+  const size_t o_cell = carve((size_t)2 * NCELL * 4);
+  const size_t o_curs = carve((size_t)2 * NCELL * 4);
   const size_t o_gmsk = carve((size_t)n_groups * 4);
   const size_t o_sl = carve((size_t)n_seg * n_rows * CAP * 8);
   const size_t o_cnt = carve((size_t)n_seg * n_rows * 4);
@@ -869,6 +563,9 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_flag = carve((size_t)n_seg * n_rows * 4);
   const size_t o_srch = carve((size_t)n_rows);
   const size_t o_blk = carve(blocks.size() * sizeof(ScreenBlock));
+  const size_t o_redo = carve((size_t)n_rows * sizeof(TopkBlock));
+  const size_t o_nredo = carve(256);
+  const size_t o_rscr = carve(wcx_topk_redo_scratch_bytes(k));
   void *scr = nullptr;
   int rc = wcx_scratch(ctx, off, &scr);
   if (rc) return rc;
@@ -892,16 +589,19 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   unsigned int *flags = reinterpret_cast<unsigned int *>(base + o_flag);
   unsigned char *searched = reinterpret_cast<unsigned char *>(base + o_srch);
   ScreenBlock *d_blocks = reinterpret_cast<ScreenBlock *>(base + o_blk);
+  TopkBlock *d_redo = reinterpret_cast<TopkBlock *>(base + o_redo);
+  unsigned int *d_nredo = reinterpret_cast<unsigned int *>(base + o_nredo);
 
   hipStream_t st = ctx->stream;
   WCX_HIP(hipMemsetAsync(glob, 0, sizeof(ScreenGlobals), st));
   WCX_HIP(hipMemsetAsync(cnt_out, 0, (size_t)n_seg * n_rows * 4, st));
   WCX_HIP(hipMemsetAsync(flags, 0, (size_t)n_seg * n_rows * 4, st));
   WCX_HIP(hipMemsetAsync(searched, 0, (size_t)n_rows, st));
+  WCX_HIP(hipMemsetAsync(d_nredo, 0, 256, st));
   WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, st));
   rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
   if (rc) return rc;
-  k_mark<<<(unsigned)blocks.size(), TGT, 0, st>>>(searched, d_blocks, row_begin);
+  k_mark<<<(unsigned)blocks.size(), 256, 0, st>>>(searched, d_blocks, row_begin);
 
   rc = wcx_timer_begin(ctx, "topk");
   if (rc) return rc;
@@ -916,119 +616,113 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, cmean + S, cmean + 2 * S, cmin, cmax, cmean,
                                                          glob);
   k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
+  ChrTab tab;
+  tab.n_chr = n_chr;
+  for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
   {
-    ChrTab tab0;
-    tab0.n_chr = n_chr;
-    for (int c = 0; c < 32; ++c) tab0.cum[c] = c < n_chr ? chr_cum[c] : B;
     const unsigned gb = (unsigned)((B + NT - 1) / NT);
-    WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)NCELL * 4, st));
+    WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
     WCX_HIP(hipMemsetAsync(perm, 0xff, (size_t)Bpad * 4, st));
-    k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab0, glob, rbits, rchr);
-    k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt);
-    k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor);
+    k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
+    k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, SF, n_seg > 1 ? 1 : 0, glob, rkey, cellcnt);
+    k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, (int)(P_s - n_s));
     k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
     k_group_mask<<<(unsigned)((n_groups + NT - 1) / NT), NT, 0, st>>>(perm, rchr, n_groups, gmask);
   }
   const unsigned gprep = (unsigned)((Bpad + NT - 1) / NT);
-  const int GRr = CTG * 32;
-  // candidate chunk per launch: ~3 MB of fragments (fits the 4 MB XCD L2)
-  const int64_t n_iter_groups = Bpad / GRr;
+  switch (NK) {
+#define WCX_PREP_CASE(N) case N: k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info); break;
+    WCX_PREP_CASE(1) WCX_PREP_CASE(2) WCX_PREP_CASE(3) WCX_PREP_CASE(4) WCX_PREP_CASE(5)
+    WCX_PREP_CASE(6) WCX_PREP_CASE(7) WCX_PREP_CASE(8) WCX_PREP_CASE(10) WCX_PREP_CASE(12)
+    WCX_PREP_CASE(14) WCX_PREP_CASE(16) WCX_PREP_CASE(20) WCX_PREP_CASE(24) WCX_PREP_CASE(28)
+    default: k_screen_prep<32><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info); break;
+#undef WCX_PREP_CASE
+  }
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "topk_prep");
+  if (rc) return rc;
+  rc = wcx_timer_begin(ctx, "topk_screen");
+  if (rc) return rc;
+
+  // candidate chunk per launch: a few MB of fragments (3 MB fits the 4 MB XCD L2)
   const int64_t group_bytes = (int64_t)GRr * NK * 32;
-  int64_t chunk_groups = (3 << 20) / group_bytes;
+  // (every launch costs ~30 us of prologue per round of workgroups -- target fragments, visit
+  // list --, so large K, whose groups are big, takes bigger chunks: L2 misses go to the MALL)
+  int64_t chunk_groups = ((int64_t)env_int("WCX_SCREEN_CHUNK_KB", NK > 16 ? 8192 : 3072) << 10) / group_bytes;
   if (chunk_groups < 16) chunk_groups = 16;
   if (chunk_groups > 4096) chunk_groups = 4096;
-  const size_t lds = 2 * (size_t)(CTG * NK * 64) * 16 +
+  const size_t lds = (size_t)(cfg.ring >= 2 ? cfg.ring : 2) * (size_t)(CTG * NK * 64) * 16 +
                      (size_t)(chunk_groups + 64) * 4;   // + the chunk's visit list
-#define WCX_SCREEN_CASE(N, G)                                                                  \
-  case N: {                                                                                    \
-    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);        \
-    rc = wcx_timer_end(ctx, "topk_prep");                                                      \
-    if (rc) return rc;                                                                         \
-    rc = wcx_timer_begin(ctx, "topk_screen");                                                  \
-    if (rc) return rc;                                                                         \
-    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<N, G>),                 \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
-    for (int64_t g0 = 0; g0 < n_iter_groups; g0 += chunk_groups) {                             \
-      const int64_t g1 = g0 + chunk_groups < n_iter_groups ? g0 + chunk_groups : n_iter_groups; \
-      k_screen<N, G><<<(unsigned)(blocks.size() * n_seg), NT, lds, st>>>(                                \
-          F, info, glob, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out, flags,      \
-          g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats, wcx_debug_value, n_seg,   \
-          n_rows);                                                                             \
-    }                                                                                          \
-  } break;
-  if ((wcx_debug_value & 4) && NK == 7) {
-    k_screen_prep<7><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info);
-    rc = wcx_timer_end(ctx, "topk_prep");
-    if (rc) return rc;
-    rc = wcx_timer_begin(ctx, "topk_screen");
-    if (rc) return rc;
-    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen<7, 2, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int64_t g0 = 0; g0 < n_iter_groups; g0 += chunk_groups) {
-      const int64_t g1 = g0 + chunk_groups < n_iter_groups ? g0 + chunk_groups : n_iter_groups;
-      k_screen<7, 2, true><<<(unsigned)(blocks.size() * n_seg), NT, lds, st>>>(
-          F, info, glob, perm, rowpos, gmask, d_blocks, k, row_begin, sl, cnt_out, flags,
-          g_state, g0, g1, g0 == 0, g1 == n_iter_groups, ctx->d_stats, wcx_debug_value, n_seg,
-          n_rows);
+  ScreenArgs a;
+  a.F = F; a.info = info; a.glob = glob; a.perm = perm; a.rowpos = rowpos; a.gmask = gmask;
+  a.blocks = d_blocks; a.sl = sl; a.cnt = cnt_out; a.flags = flags; a.g_state = g_state;
+  a.stats = ctx->d_stats; a.row_begin = row_begin; a.n_rows_all = n_rows;
+  a.k = k; a.dbg = ctx->debug_flags; a.n_seg = n_seg; a.n_blocks = (int)blocks.size();
+  const unsigned grid = (unsigned)(blocks.size() * n_seg);
+  bool first = true;
+  auto launch = [&](int64_t g0, int64_t g1, int cut_k, int cut_mode, int trig, int end_cut) {
+    a.g_start = g0; a.g_count = (int)(g1 - g0);
+    a.cut_k = cut_k; a.cut_mode = cut_mode; a.trig = trig; a.end_cut = end_cut;
+    a.first = first ? 1 : 0;
+    first = false;
+    const int e = screen_dispatch(cfg, a, grid, lds, st);
+    if (e < 0) {
+      wcx_set_error("screen kernel configuration nk=%d ctg=%d tt=%d wpb=%d lb=%d ring=%d is not instantiated",
+                    cfg.nk, cfg.ctg, cfg.tt, cfg.wpb, cfg.lb, cfg.ring);
+      return (int)WCX_ERR_UNSUPPORTED;
     }
-  } else
-  switch (NK) {
-    WCX_SCREEN_CASE(1, 2) WCX_SCREEN_CASE(2, 2) WCX_SCREEN_CASE(3, 2) WCX_SCREEN_CASE(4, 2)
-    WCX_SCREEN_CASE(5, 2) WCX_SCREEN_CASE(6, 2) WCX_SCREEN_CASE(7, 2) WCX_SCREEN_CASE(8, 2)
-    WCX_SCREEN_CASE(10, 2) WCX_SCREEN_CASE(12, 2) WCX_SCREEN_CASE(14, 2) WCX_SCREEN_CASE(16, 2)
-    WCX_SCREEN_CASE(20, 1) WCX_SCREEN_CASE(24, 1) WCX_SCREEN_CASE(28, 1)
-    default: WCX_SCREEN_CASE(32, 1)
+    if (e != 0) {
+      wcx_set_error("screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+      return (int)WCX_ERR_HIP;
+    }
+    return (int)WCX_OK;
+  };
+  const int trig_main = (ctx->debug_flags >> 8) ? (ctx->debug_flags >> 8) : LIM;   // (diagnostics)
+  int64_t g_main = 0;
+  if (cut_r) {   // sampled pre-pass: a streaming top-r over the sample region
+    g_main = P_s / GRr;
+    int trig_a = n_seg > 1 ? 2 * cut_r + 32 : 4 * cut_r + 64;   // (random order: cut more often)
+    if (trig_a > LIM) trig_a = LIM;
+    for (int64_t g0 = 0; g0 < g_main; g0 += chunk_groups) {
+      const int64_t g1 = g0 + chunk_groups < g_main ? g0 + chunk_groups : g_main;
+      rc = launch(g0, g1, cut_r, 1, trig_a, g1 == g_main ? 1 : 0);
+      if (rc) return rc;
+    }
+    if (n_seg > 1)
+      k_share_thresholds<<<(unsigned)((n_rows + NT - 1) / NT), NT, 0, st>>>(n_rows, n_seg, searched,
+                                                                            g_state, cnt_out);
   }
-#undef WCX_SCREEN_CASE
+  for (int64_t g0 = g_main; g0 < n_iter_groups; g0 += chunk_groups) {
+    const int64_t g1 = g0 + chunk_groups < n_iter_groups ? g0 + chunk_groups : n_iter_groups;
+    rc = launch(g0, g1, k, 0, trig_main, g1 == n_iter_groups ? 2 : 0);
+    if (rc) return rc;
+  }
   if (n_seg > 1) {
-    const float gamma = (float)(16 * NK + 8) * 1.1920929e-7f;
+    const float gamma = (float)(16 * NK + 12) * 1.1920929e-7f;
     const unsigned gm = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
     for (int step = 1; step < n_seg; step *= 2)
       for (int s0 = 0; s0 + step < n_seg; s0 += 2 * step)
         k_merge_segments<<<gm, NT, 0, st>>>(info, glob, rowpos, row_begin, n_rows, searched, sl,
-                                            cnt_out, flags, s0, s0 + step, k, gamma);
+                                            cnt_out, flags, g_state, s0, s0 + step, k, gamma,
+                                            step * 2 >= n_seg ? 1 : 0);
   }
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_screen");
   if (rc) return rc;
   rc = wcx_timer_begin(ctx, "topk_refine");
   if (rc) return rc;
-  ChrTab tab;
-  tab.n_chr = n_chr;
-  for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
   rc = wcx_refine_launch(ctx, Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out, flags, perm,
                          k, d_out_idx, d_out_dist, glob);
   if (rc) return rc;
   rc = wcx_timer_end(ctx, "topk_refine");
   if (rc) return rc;
-  rc = wcx_timer_end(ctx, "topk");
+  // rows the screen could not finish (none on all data seen) are redone exactly, device-driven:
+  // redo list and its length never leave the device
+  k_collect_redo<<<(unsigned)((n_rows + NT - 1) / NT), NT, 0, st>>>(row_begin, n_rows, searched, flags,
+                                                                   tab, d_redo, d_nredo, ctx->d_stats);
+  WCX_HIP(hipGetLastError());
+  rc = wcx_topk_exact_redo_launch(ctx, dXs, B, S, d_redo, d_nredo, base + o_rscr, row_begin, k,
+                                  d_out_idx, d_out_dist);
   if (rc) return rc;
-
-  // overflowed rows (if any) are redone exactly
-  ScreenGlobals hg;
-  WCX_HIP(hipMemcpyAsync(&hg, glob, sizeof(hg), hipMemcpyDeviceToHost, st));
-  WCX_HIP(hipStreamSynchronize(st));
-  ctx->stage.clear();
-  if (hg.n_overflow) {
-    std::vector<unsigned int> hflags((size_t)n_rows);
-    WCX_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)n_rows * 4, hipMemcpyDeviceToHost, st));
-    WCX_HIP(hipStreamSynchronize(st));
-    std::vector<TopkBlock> redo;
-    for (const TopkBlock &eb : exact_blocks)
-      for (int r = 0; r < eb.nrows; ++r)
-        if (hflags[(size_t)(eb.row0 + r - row_begin)]) {
-          TopkBlock one = eb;
-          one.row0 = eb.row0 + r;
-          one.nrows = 1;
-          redo.push_back(one);
-        }
-    // NOTE: wcx_topk_exact_launch re-uses ctx->scratch; the screen scratch is dead by now.
-    rc = wcx_topk_exact_launch(ctx, dXs, B, S, redo, row_begin, n_rows, k, d_out_idx, d_out_dist);
-    if (rc) return rc;
-    WCX_HIP(hipStreamSynchronize(st));
-    unsigned long long fb = redo.size();
-    WCX_HIP(hipMemcpyAsync(ctx->d_stats + 3, &fb, 8, hipMemcpyHostToDevice, st));
-    WCX_HIP(hipStreamSynchronize(st));
-  }
-  return WCX_OK;
+  return wcx_timer_end(ctx, "topk");
 }

@@ -23,7 +23,6 @@
 #include "wave_sort.h"
 #include "wcx_common.h"
 
-extern int wcx_debug_value;
 
 namespace {
 
@@ -314,7 +313,7 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)n_sg);
 #define WCX_NR_LAUNCH(IPL)                                                                      \
   k_null_ratios<IPL><<<grid, NT, 0, st>>>(Rg, V, d_nan, dXs, d_sids, B, d_idx, row_begin, n_rows, \
-                                          k, n_ids, d_out, wcx_debug_value)
+                                          k, n_ids, d_out, ctx->debug_flags)
   const int ipl = (k + 63) / 64;
   if (ipl <= 1) WCX_NR_LAUNCH(1);
   else if (ipl <= 2) WCX_NR_LAUNCH(2);

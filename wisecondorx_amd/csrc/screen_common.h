@@ -7,9 +7,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NT = 256;      // 4 waves per workgroup
-constexpr int TGT = 128;     // target rows per workgroup (32 per wave)
-constexpr int CT = 64;       // candidate rows per main-loop iteration (2 MFMA tiles)
+constexpr int NT = 256;      // threads of the helper kernels (prep, merge, refine)
+constexpr int CT = 64;       // sweep positions are padded to a multiple of this (gmask granule)
 constexpr int CAP = 1024;    // shortlist capacity per target
 constexpr int LIM = CAP - CT;
 
@@ -27,6 +26,51 @@ struct ScreenGlobals {
   unsigned int uinv;             // 0xffffffff - min(norm float bits >> 20) over finite rows
 };
 
+
+// One workgroup of the screen: consecutive target rows of one chromosome.
+struct ScreenBlock {
+  int64_t row0;
+  int32_t nrows;  // <= 32 TT WPB of the launched configuration
+  int32_t chr;    // chromosome index of the target rows
+  int64_t cs, ce;
+};
+
+struct ScreenArgs {
+  const half8 *F;
+  const RowInfo *info;
+  const ScreenGlobals *glob;
+  const int *perm, *rowpos;
+  const unsigned int *gmask;
+  const ScreenBlock *blocks;
+  uint2 *sl;
+  int *cnt;
+  unsigned int *flags;
+  float *g_state;
+  unsigned long long *stats;
+  int64_t row_begin, n_rows_all;
+  int64_t g_start;          // this launch visits the candidate groups [g_start, g_start + g_count)
+  int g_count;
+  int k;                    // refsize
+  int cut_k, cut_mode;      // in-sweep cuts: rank and mode (sampled pre-pass: r, 1; main pass: k, 0)
+  int trig;                 // shortlist length that triggers an in-sweep cut
+  int end_cut;              // cut of every target at the end of the launch: 0 none, 1 = end of the
+                            // sampled pre-pass (estimate from rank cut_k), 2 = final (exact k-th)
+  int first, dbg, n_seg, n_blocks;
+};
+
+// Screen kernel configuration: K = 16 nk, ctg candidate sub-tiles per iteration, tt target tiles
+// per wave, wpb waves per workgroup (targets per workgroup = 32 tt wpb), lb = waves per SIMD the
+// registers are budgeted for, ring = slots of the LDS-DMA staging ring (0 = register staging into a
+// double buffer); prof = phase accounting.
+struct ScreenCfg { int nk, ctg, tt, wpb, lb, ring, prof; };
+// Launchers of the instantiated configurations (newref_screen_k*.hip); return -1 if `c` is not
+// instantiated there, else a hipError_t.
+int wcx_screen_launch_k1(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_screen_launch_k2(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_screen_launch_k3(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_screen_launch_k4(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_screen_launch_k5(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_screen_launch_k6(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
 
 struct ChrTab {
   int n_chr;

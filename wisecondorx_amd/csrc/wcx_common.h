@@ -41,6 +41,7 @@ struct wcx_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::map<std::string, KernelTimer> timers;
+  int debug_flags = 0;                    // diagnostics (wcx_debug_flags): per context
   int64_t topk_stats[4] = {0, 0, 0, 0};
   unsigned long long *d_stats = nullptr;  // 16 device counters
   void *d_small = nullptr;                // 8 KB of persistent device workspace (radix-select state)
@@ -88,6 +89,11 @@ struct TopkBlock {
 int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                           const std::vector<TopkBlock> &blocks, int64_t row_begin,
                           int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist);
+constexpr int WCX_REDO_GRID = 64;   // workgroups of the device-driven exact redo
+size_t wcx_topk_redo_scratch_bytes(int k);
+int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                               const TopkBlock *d_blocks, const unsigned int *d_count, void *scratch,
+                               int64_t row_begin, int k, int32_t *d_out_idx, double *d_out_dist);
 bool wcx_screen_supported(int64_t B, int S, int k);
 int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                            const int64_t *chr_cum, int n_chr,
