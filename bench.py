@@ -5,16 +5,20 @@ Contract (see the task prompt): `python bench.py --gpus N --steps K --warmup W` 
 JSON line on rank 0.  A "step" = one pass of the hot path over one synthetic batch:
   newref   reference-bin search of every autosomal bin (all-pairs distance + top-k, k=300)
            + the null-ratio table, target rows split over the N ranks with the reference's
-           own _get_part formula (newref_tools.py:244-247) after an RCCL all-gather of the
-           row-sharded bin-feature matrix X;
-  predict  cut-off + three masked normalisation passes of one test sample against the rows
-           this rank just built.
-Default workload = BASELINE.json configs[2]: 15 kb bins (hg38, ~5 % of bins masked), 100
-reference samples, refsize 300.  Inputs are resident in HBM when the timed region starts.
-value = candidate bin pairs evaluated per second over the whole job ("bins x refs / s").
+           own _get_part formula (newref_tools.py:244-247) after ONE RCCL all-gather of the
+           row-sharded bin-feature matrix X; the finished row blocks are all-gathered so that
+           every rank holds the whole reference (what `newref` writes to disk);
+  predict  one test sample against that reference, complete: cut-off, weights, three masked
+           normalisation passes, post-processing, CBS segmentation, segment z-scores
+           (replicated on every rank: predict has no collective on its path).
+Default workload = north_star's headline problem, the size of BASELINE.json configs[3]:
+15 kb bins (hg38, ~5 % of bins masked) x 500 reference samples, refsize 300 -- it fits one
+GPU; with --gpus N the same problem is row-sharded (strong scaling).  Inputs are resident in
+HBM when the timed region starts.  value = candidate bin pairs evaluated per second over the
+whole job ("bins x refs / s").  A secondary block carries configs[2] (100 samples).
 """
 import argparse
-import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -27,8 +31,18 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 vector == matrix (not in the guide)
-F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix
-BF16_MFMA_PEAK_TFLOPS = 2500.0
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA
+SPINUP_STEPS = int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "10"))
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "screen_traffic.json")
+
+
+def screen_source_sha():
+    """Hash of the screen kernel's sources: roofline.traffic (PMC counters recorded by
+    scripts/measure_traffic.sh) is only reported while the kernel is the one that was profiled."""
+    h = hashlib.sha256()
+    for f in ("screen_kernel.h", "screen_common.h", "newref_topk_screen.hip"):
+        h.update(open(os.path.join(ROOT, "wisecondorx_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_workload(binsize, n_samples, seed=0):
@@ -43,29 +57,187 @@ def make_workload(binsize, n_samples, seed=0):
     return co, p, test
 
 
-def cpu_baseline(Xs, chr_cum, k, budget_s=12.0):
-    """The C oracle (port of newref_tools.py:255-278) on a bounded row sample, 1 core."""
+def cpu_baseline(Xs, chr_cum, k, budget_s=10.0):
+    """The reference's per-bin search on the host cores, single process (the reference is
+    single-threaded in effect: its --cpus threads are GIL-bound), on a bounded
+    sample of target rows, each against ALL its candidate rows:
+      value   the NumPy + Python-scan restatement (oracle.wcx_oracle.sq_distances + topk_scan:
+              what newref_tools.py:260-275 executes), the primary figure;
+      c_port  the plain-C port of the same loop (oracle/wcx_oracle.c)."""
     from oracle import c_oracle as CO
+    from oracle import wcx_oracle as O
     B = Xs.shape[1]
+    X = Xs.T                                      # (B, S) Fortran-ordered view
     rng = np.random.default_rng(0)
     rows = rng.choice(B, 4096, replace=False)
-    t0 = time.perf_counter()
-    pairs = 0
-    n = 0
-    for t in rows:
+
+    def own(t):
         c = int(np.searchsorted(chr_cum, t, side="right"))
-        cs = int(chr_cum[c - 1]) if c else 0
-        ce = int(chr_cum[c])
-        CO.topk_rows(Xs, cs, ce, int(t), int(t) + 1, k)
-        pairs += B - (ce - cs)
-        n += 1
+        return (int(chr_cum[c - 1]) if c else 0), int(chr_cum[c])
+    t0 = time.perf_counter()
+    pairs_py, n_py = 0, 0
+    for t in rows:
+        cs, ce = own(int(t))
+        chr_data = np.concatenate((X[:cs], X[ce:]))          # newref_tools.py:192-199
+        O.topk_scan(O.sq_distances(chr_data, X[int(t), :]), k)
+        pairs_py += B - (ce - cs)
+        n_py += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": pairs / dt, "unit": "bin-pairs/s", "cores": 1, "kind": "port",
-            "sample": "{} random target rows x all {} candidate rows, S={}, k={} "
-                      "(oracle/wcx_oracle.c, newref search only; {:.1f} s)".format(
-                          n, B, Xs.shape[0], k, dt)}
+    dt_py = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pairs_c, n_c = 0, 0
+    for t in rows:
+        cs, ce = own(int(t))
+        CO.topk_rows(Xs, cs, ce, int(t), int(t) + 1, k)
+        pairs_c += B - (ce - cs)
+        n_c += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt_c = time.perf_counter() - t0
+    mb = np.diff(np.concatenate(([0], chr_cum)))
+    return {"value": pairs_py / dt_py, "unit": "bin-pairs/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": "{} random target rows x all {} candidate rows, S={}, k={}: NumPy distance + "
+                      "Python scan restatement of newref_tools.py:260-275 ({:.1f} s); "
+                      "single-threaded like the reference".format(n_py, B, Xs.shape[0], k, dt_py),
+            "c_port": {"value": pairs_c / dt_c, "rows": n_c, "seconds": dt_c,
+                       "what": "oracle/wcx_oracle.c, the same loop in C, 1 core"},
+            "extrapolated_full_search_s": float(np.sum(mb * (B - mb))) / (pairs_py / dt_py)}
+
+
+class Workload:
+    """Device-resident inputs and the step of one problem size."""
+
+    def __init__(self, args, n_samples, torch, dev, dev_index, rank, world):
+        from wisecondorx_amd import _lib, predict_tools
+        from wisecondorx_amd import dist as wd
+        from wisecondorx_amd.newref_tools import _get_part
+        self.torch, self.wd, self.pt = torch, wd, predict_tools
+        self.rank, self.world, self.args = rank, world, args
+        co, p, test = make_workload(args.binsize, n_samples)
+        self.p = p
+        X = p["X"]                                   # (B, S) Fortran order
+        self.Xs_host = np.ascontiguousarray(X.T)     # [S][B]
+        self.S, self.B = self.Xs_host.shape
+        self.k = args.refsize
+        self.cum = np.asarray(p["masked_bins_per_chr_cum"], dtype=np.int64)
+        mb = np.asarray(p["masked_bins_per_chr"], dtype=np.int64)
+        self.pairs_total = int(np.sum(mb * (self.B - mb)))
+        self.row_begin, self.row_end = _get_part(rank, world, self.B)
+        n_rows = self.row_end - self.row_begin
+        shard_rows = wd.max_shard_rows(world, self.B)
+        # this rank's row shard of X (what it would have produced itself), resident in HBM
+        self.Xrow = torch.zeros((shard_rows, self.S), dtype=torch.float64, device=dev)
+        self.Xrow[:n_rows] = torch.from_numpy(
+            np.ascontiguousarray(X[self.row_begin:self.row_end])).to(dev)
+        x_test = predict_tools.project_pc(
+            predict_tools.coverage_normalize_and_mask(test, p, ""), p, "")
+        self.d_x = torch.from_numpy(np.ascontiguousarray(x_test)).to(dev)
+        self.null_ids = np.ascontiguousarray(
+            np.random.default_rng(5).permutation(self.S)[:min(self.S, 100)], dtype=np.int32)
+        m = len(self.null_ids)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.ctx = _lib.Context(dev_index, stream)
+        if args.debug_flags:
+            self.ctx.lib.wcx_debug_flags(self.ctx.h, args.debug_flags)
+        self.out_bufs = (torch.empty((shard_rows, self.k), dtype=torch.int32, device=dev),
+                         torch.empty((shard_rows, self.k), dtype=torch.float64, device=dev),
+                         torch.empty((shard_rows, m), dtype=torch.float64, device=dev))
+        self.backend = wd.GpuBackend(self.ctx)
+        self.pargs = argparse.Namespace(minrefbins=150, alpha=1e-4, seed=1, maskrepeats=5)
+        self.rem = {"args": self.pargs, "mask": p["mask"], "bins_per_chr": p["bins_per_chr"],
+                    "binsize": args.binsize, "ref_gender": "F"}
+        self.ms = {k_: [] for k_ in ("topk", "null_ratios", "normalize", "cbs", "segment_z",
+                                     "predict_full", "gather_ref")}
+        self.fb_rows = []
+        self.n_segments = 0
+
+    def step(self, record):
+        wd, ctx, torch = self.wd, self.ctx, self.torch
+        # (1) ONE exchange (all-gather of the row shards of X over RCCL/xGMI), then the search +
+        # null ratios of this rank's target rows
+        idx_l, dist_l, nr_l, _ = wd.newref_sharded(self.Xrow, self.B, self.cum, self.k,
+                                                   self.null_ids, self.backend, self.rank,
+                                                   self.world, out=self.out_bufs)
+        if self.args.debug_flags & 3:                # (ablations leave garbage neighbour tables)
+            ctx.sync()
+            if record:
+                self.ms["topk"].append(ctx.kernel_ms("topk"))
+            return
+        # (2) every rank gets the whole reference (rank 0 would write it to disk)
+        if record and self.world > 1:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx, dist_, nr = wd.gather_reference3(idx_l, dist_l, nr_l, self.B, self.world, self.backend)
+        if record and self.world > 1:
+            torch.cuda.synchronize()
+            self.ms["gather_ref"].append(1e3 * (time.perf_counter() - t0))
+        # (3) predict ONE sample, complete (replica on every rank)
+        t0 = time.perf_counter()
+        res = wd.predict_one_dev(self.backend, idx, dist_, nr, self.d_x, self.B, self.k, self.cum,
+                                 self.rem, self.pt)
+        self.n_segments = len(res)
+        if record:
+            self.ms["predict_full"].append(1e3 * (time.perf_counter() - t0))
+            for name in ("topk", "null_ratios", "normalize", "cbs", "segment_z"):
+                self.ms[name].append(ctx.kernel_ms(name))
+            self.fb_rows.append(ctx.topk_stats()["fallback_rows"])
+
+    def roofline(self):
+        ctx, S = self.ctx, self.S
+        stats = ctx.topk_stats()
+        k_ms = float(np.mean(self.ms["topk"])) if self.ms["topk"] else ctx.kernel_ms("topk")
+        screen_ms = ctx.kernel_ms("topk_screen")
+        if screen_ms >= 0:
+            # MFMA screen: algorithmic work = the -2 X^T X Gram GEMM, 2*S flop per candidate pair
+            # (SURVEY.md §8d).  The kernel executes one fp16 product over K = 16*NK >= S + 4 (four
+            # augmented columns carry the norm and the threshold), reported as executed_tflops.
+            nk_list = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32]
+            nk = next(v for v in nk_list if 16 * v >= S + 4)   # same rule as wcx_topk_screen_launch
+            flops = 2.0 * S * stats["pairs"]
+            achieved = flops / (screen_ms * 1e-3) / 1e12
+            r = {"kernel": "k_screen (v_mfma_f32_32x32x16_f16, fp16 hi plane, fp32 acc) + fused "
+                           "top-k filter", "bound": "mfma", "achieved": achieved,
+                 "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": screen_ms,
+                 "executed_tflops": 2.0 * nk * 16 * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
+                 "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
+                 "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
+                 "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": self.fb_rows,
+                 "compactions": stats["compactions"], "appends": stats["appends"],
+                 "attainable_note": "the dense-f16 peak is not attainable on random data: a bare "
+                                    "LDS-fed MFMA loop is power-limited to 1.27-1.48 PFLOP/s on this "
+                                    "chip (profiles/r02/ubench_mfma.txt)"}
+            if any(stats["phase_cycles"]):          # only with --debug-flags 4
+                r["phase_cycles"] = stats["phase_cycles"]
+        else:
+            flops = 3.0 * S * stats["pairs"]         # exact path: sub, mul, add per (pair, sample)
+            achieved = flops / (k_ms * 1e-3) / 1e12
+            r = {"kernel": "k_topk_exact (fp64 VALU, 3 flop per pair-sample)", "bound": "mfma",
+                 "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel_ms": k_ms,
+                 "pairs_per_launch": stats["pairs"], "compactions": stats["compactions"]}
+        for name in ("null_ratios", "normalize", "cbs", "segment_z", "predict_full", "gather_ref"):
+            if self.ms[name]:
+                r[name + "_ms"] = float(np.mean(self.ms[name]))
+        return r, screen_ms
+
+
+def run_steps(w, steps, warmup, spinup, barrier):
+    # Untimed spin-up (setup, not one of the contract's warm-up steps; reported in config): the
+    # first process on an idle box otherwise measures the clock ramp.  A FIXED number of steps:
+    # every rank must issue the same collectives.
+    for _ in range(spinup):
+        w.step(False)
+    for _ in range(warmup):
+        w.step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.step(True)
+    barrier()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -74,10 +246,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--binsize", type=int, default=15000)
-    ap.add_argument("--samples", type=int, default=100)
+    ap.add_argument("--samples", type=int, default=500)
     ap.add_argument("--refsize", type=int, default=300)
-    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact fp64, 2 MFMA screen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the S=100 block")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling ablations (invalid results)")
     args = ap.parse_args()
 
@@ -87,9 +259,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
     # WCX_DIST_BACKEND=gloo is for tests only (several ranks sharing one device; RCCL needs one
     # device per rank)
     backend_name = os.environ.get("WCX_DIST_BACKEND", "nccl")
@@ -103,171 +274,70 @@ def main():
         else:
             dist.init_process_group(backend_name)
 
-    from wisecondorx_amd import _lib, predict_tools
-    from wisecondorx_amd import dist as wd
-    from wisecondorx_amd.newref_tools import _get_part
-
-    # ---------------------------------------------------------------- inputs (untimed)
-    co, p, test = make_workload(args.binsize, args.samples)
-    X = p["X"]                                   # (B, S) Fortran order
-    Xs_host = np.ascontiguousarray(X.T)          # [S][B]
-    S, B = Xs_host.shape
-    k = args.refsize
-    cum = np.asarray(p["masked_bins_per_chr_cum"], dtype=np.int64)
-    mb = np.asarray(p["masked_bins_per_chr"], dtype=np.int64)
-    row_begin, row_end = _get_part(rank, world, B)
-    n_rows = row_end - row_begin
-    pairs_total = int(np.sum(mb * (B - mb)))
-    # this rank's row shard of X^T (what it would have produced itself), resident in HBM
-    sh0, sh1 = _get_part(rank, world, B)
-    shard_rows = max(_get_part(r, world, B)[1] - _get_part(r, world, B)[0] for r in range(world))
-    Xrow = torch.zeros((shard_rows, S), dtype=torch.float64, device=dev)   # row-major shard
-    Xrow[: sh1 - sh0] = torch.from_numpy(np.ascontiguousarray(X[sh0:sh1])).to(dev)
-    x_test = predict_tools.project_pc(
-        predict_tools.coverage_normalize_and_mask(test, p, ""), p, "")
-    d_x = torch.from_numpy(np.ascontiguousarray(x_test)).to(dev)
-    null_ids = np.ascontiguousarray(np.random.default_rng(5).permutation(S)[:min(S, 100)],
-                                    dtype=np.int32)
-    m = len(null_ids)
-
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = _lib.Context(dev_index, stream)
-    lib = ctx.lib
-    if args.debug_flags:
-        lib.wcx_debug_flags(ctx.h, args.debug_flags)
-    d_idx = torch.empty((max(n_rows, 1), k), dtype=torch.int32, device=dev)
-    d_dist = torch.empty((max(n_rows, 1), k), dtype=torch.float64, device=dev)
-    d_nr = torch.empty((max(n_rows, 1), m), dtype=torch.float64, device=dev)
-    d_z = torch.empty(B, dtype=torch.float64, device=dev)
-    d_r = torch.empty_like(d_z)
-    d_n = torch.empty_like(d_z)
-    d_med = torch.empty(2, dtype=torch.float64, device=dev)
-    cum_p = cum.ctypes.data_as(_lib.c_i64p)
-    ids_p = null_ids.ctypes.data_as(_lib.c_i32p)
-    topk_ms, nr_ms, norm_ms, fb_rows = [], [], [], []
-
-    backend = wd.GpuBackend(ctx)
-    out_bufs = (d_idx, d_dist, d_nr)
-
-    def step(record):
-        # (1)+(2) ONE exchange (all-gather of the row shards of X over RCCL/xGMI), then the
-        # search + null ratios of this rank's target rows
-        idx_l, dist_l, _, d_Xs = wd.newref_sharded(Xrow, B, cum, k, null_ids, backend, rank, world,
-                                                   out=out_bufs)
-        # (3) predict one sample, ROW-SHARDED like the reference build: every rank keeps only the
-        # rows it just built; cut-off = 5 x 2 local moment sweeps + tiny all-reduces, then three
-        # masked passes over the local rows with an all-gather of the updated copy vector
-        # (B doubles) between passes, and of z / r / n / log2 r at the end.
-        if not (args.debug_flags & 3):          # (ablations leave garbage neighbour tables)
-            h = backend.wrap_rows(idx_l, dist_l, B, k, cum, row_begin, n_rows)
-            cut = wd.cutoff_sharded(backend, h, 5, world)
-            wd.normalize_sharded(backend, h, d_x, B, 0, cut, rank, world)
-            lib.wcx_sync(ctx.h)
-            backend.free_ref(h)
-        else:
-            lib.wcx_sync(ctx.h)
-        if record:
-            topk_ms.append(ctx.kernel_ms("topk"))
-            nr_ms.append(ctx.kernel_ms("null_ratios"))
-            norm_ms.append(ctx.kernel_ms("normalize"))
-            fb_rows.append(ctx.topk_stats()["fallback_rows"])
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed spin-up (setup, not one of the contract's warm-up steps): the first process on an
-    # idle box can otherwise measure the clock ramp (51 ms/step observed in the first 0.1 s of
-    # load against 31.8 ms/step for every later process on the same box).
-    # A FIXED number of steps: every rank must issue the same collectives.
-    for _ in range(int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "30"))):
-        step(False)
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    dt = time.perf_counter() - t0
+    w = Workload(args, args.samples, torch, dev, dev_index, rank, world)
+    dt = run_steps(w, args.steps, args.warmup, SPINUP_STEPS, barrier)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend_name == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
+    roofline, screen_ms = w.roofline()
 
-    # ---------------------------------------------------------------- roofline (dominant kernel)
-    stats = ctx.topk_stats()
-    k_ms = float(np.mean(topk_ms))
-    screen_ms = ctx.kernel_ms("topk_screen")
-    if screen_ms >= 0:
-        # MFMA screen: algorithmic work = the -2 X^T X Gram GEMM, 2*S flop per candidate pair
-        # (SURVEY.md §8d).  The kernel executes one fp16 product over K = 16*NK >= S + 4 (four
-        # augmented columns carry the norm and the threshold), reported as executed_tflops.
-        nk_list = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32]
-        nk = next(v for v in nk_list if 16 * v >= S + 4)   # same rule as wcx_topk_screen_launch
-        kpad, nprod, form = nk * 16, 1, "fp16 hi plane"
-        flops = 2.0 * S * stats["pairs"]
-        achieved = flops / (screen_ms * 1e-3) / 1e12
-        roofline = {"kernel": "k_screen (v_mfma_f32_32x32x16_f16, {}, fp32 acc) + fused top-k "
-                              "filter".format(form),
-                    "bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "kernel_ms": screen_ms,
-                    "executed_tflops": nprod * 2.0 * kpad * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
-                    "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
-                    "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
-                    "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": fb_rows,
-                    "compactions": stats["compactions"],
-                    "appends": stats["appends"]}
-        if any(stats["phase_cycles"]):          # only with --debug-flags 4
-            roofline["phase_cycles"] = stats["phase_cycles"]
-    else:
-        flops = 3.0 * S * stats["pairs"]         # exact path: sub, mul, add per (pair, sample)
-        achieved = flops / (k_ms * 1e-3) / 1e12
-        roofline = {"kernel": "k_topk_exact (fp64 VALU, 3 flop per pair-sample)", "bound": "mfma",
-                    "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                    "kernel_ms": k_ms, "pairs_per_launch": stats["pairs"],
-                    "compactions": stats["compactions"]}
     # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (bench.py cannot read
-    # counters itself): profiles/r01/screen_traffic.json, recorded on this exact default workload
-    tpath = os.path.join(ROOT, "profiles", "r01", "screen_traffic.json")
-    if screen_ms >= 0 and world == 1 and os.path.exists(tpath) \
-            and (args.binsize, args.samples, args.refsize) == (15000, 100, 300):
-        tj = json.load(open(tpath))
-        roofline["traffic"] = tj["fetch_bytes_per_sweep_corrected_x2"] + tj["write_bytes_per_sweep"]
-        roofline["traffic_source"] = "profiles/r01/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
-                                     "WRITE_SIZE; bytes per screen sweep = the chunk launches of one search)"
-    roofline["null_ratios_ms"] = float(np.mean(nr_ms))
-    roofline["normalize_ms"] = float(np.mean(norm_ms)) if norm_ms else None
+    # counters itself); only valid for the kernel sources it was recorded with
+    if screen_ms >= 0 and world == 1 and os.path.exists(TRAFFIC_JSON):
+        tj = json.load(open(TRAFFIC_JSON))
+        key = "S{}".format(w.S)
+        if tj.get("kernel_sha") == screen_source_sha() and key in tj.get("workloads", {}) \
+                and (args.binsize, args.refsize) == (15000, 300):
+            e = tj["workloads"][key]
+            roofline["traffic"] = e["fetch_bytes_per_sweep_corrected_x2"] + e["write_bytes_per_sweep"]
+            roofline["traffic_source"] = "profiles/r02/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
+                                         "WRITE_SIZE; bytes per screen sweep; kernel_sha {})".format(
+                                             tj["kernel_sha"])
 
     out = {
         "metric": "newref+predict throughput @{}kb bins (bins x refs per second)".format(
             args.binsize // 1000),
-        "value": pairs_total / (ms_per_step * 1e-3),
+        "value": w.pairs_total / (ms_per_step * 1e-3),
         "unit": "bin-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "newref {} kb bins: B={} masked autosomal bins x S={} samples, "
-                               "refsize={} (search + null ratios), + predict normalise of 1 "
-                               "sample".format(args.binsize // 1000, B, S, k),
-                   "bins": int(B), "samples": int(S), "refsize": int(k),
-                   "pairs": pairs_total, "bin_samples_per_s": B * S / (ms_per_step * 1e-3),
-                   "mode": args.mode,
+                               "refsize={} (search + null ratios + gather of the reference), + "
+                               "predict of 1 sample (cut-off, weights, 3 normalisation passes, "
+                               "post-processing, CBS, segment z)".format(
+                                   args.binsize // 1000, w.B, w.S, w.k),
+                   "bins": int(w.B), "samples": int(w.S), "refsize": int(w.k),
+                   "pairs": w.pairs_total, "bin_samples_per_s": w.B * w.S / (ms_per_step * 1e-3),
+                   "spinup_steps_untimed": SPINUP_STEPS, "predict_segments": w.n_segments,
                    "precision": "indices and distances bit-identical to the reference's fp64 path; the "
                                 "fp16 MFMA product is only a rigorously bounded pre-filter, every "
                                 "kept pair is re-evaluated in sequential fp64",
-                   "partition": "target rows x{} (_get_part): one all-gather(X) for the search; "
-                                "predict row-sharded (all-reduce of cut-off moments, all-gather "
-                                "of B-vectors between passes)".format(world)},
+                   "partition": "target rows x{} (_get_part): one all-gather(X) for the search, one "
+                                "all-gather of the finished row blocks; predict replicated".format(world)},
         "roofline": roofline,
     }
+    if rank == 0 and world == 1 and not args.no_secondary and not args.debug_flags \
+            and args.samples != 100:
+        w2 = Workload(args, 100, torch, dev, dev_index, rank, world)
+        dt2 = run_steps(w2, args.steps, args.warmup, SPINUP_STEPS, barrier)
+        r2, _ = w2.roofline()
+        out["secondary"] = {"workload": "BASELINE configs[2]: 15 kb x 100 samples, same step",
+                            "ms_per_step": dt2 / args.steps * 1e3,
+                            "value": w2.pairs_total / (dt2 / args.steps),
+                            "roofline": {k_: r2[k_] for k_ in r2
+                                         if k_ not in ("kernel", "attainable_note",
+                                                       "fallback_rows_per_step")}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(Xs_host, cum, k)
+        out["cpu_baseline"] = cpu_baseline(w.Xs_host, w.cum, w.k)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -75,6 +75,17 @@ int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[16]);
  * into the sample-major layout the search takes (the bytes of the reference's F-ordered array). */
 int wcx_transpose_dev(wcx_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, double *d_dst);
 
+/* Multi-GPU plumbing: an RCCL all-gather delivers `world` equally padded row shards
+ * (shard r = rows [start_r, start_r+1) with the reference's _get_part boundaries,
+ * newref_tools.py:244-247, at padded row r * pad_rows).  wcx_gather_transpose_dev turns the padded
+ * shards of the row-major (bins x samples) matrix straight into the sample-major layout the search
+ * takes; wcx_compact_rows_dev turns padded shards of a row-major table (indexes, distances, null
+ * ratios; row_bytes a multiple of 4) into the dense table.  world <= 64. */
+int wcx_gather_transpose_dev(wcx_ctx *ctx, const double *d_src, int world, int64_t pad_rows,
+                             int64_t B, int S, double *d_dst);
+int wcx_compact_rows_dev(wcx_ctx *ctx, const void *d_src, int world, int64_t pad_rows, int64_t B,
+                         int64_t row_bytes, void *d_dst);
+
 /* ---- newref: reference-bin search ------------------------------------------------- */
 /* Replaces newref_tools.get_ref_for_bins (newref_tools.py:255-278) as driven by
  * newref_tools.get_reference (newref_tools.py:176-206) for target rows
@@ -164,6 +175,13 @@ int wcx_nanmedian2_dev(wcx_ctx *ctx, const double *d_a0, const double *d_a1, int
 int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_off, int n_chr,
             double alpha, int64_t binsize, uint64_t seed, double *out_seg, int cap,
             int *out_count);
+/* The same for a batch of n_samples samples that share the chromosome layout: r, w
+ * double[n_samples][n_bins] (sample-major; chr_off[n_chr] <= n_bins), out_seg
+ * double[n_samples][cap][4], out_count int[n_samples].  All chromosomes of all samples advance
+ * together (level-synchronous recursion): this is the throughput path of a predict batch. */
+int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples, int64_t n_bins,
+                  const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
+                  double *out_seg, int cap, int *out_count);
 /* Replaces overall_tools.get_z_score (overall_tools.py:88-119).  nr double[n_bins][m]
  * (rows of masked bins ignored; pad ragged rows with NaN), seg as produced by wcx_cbs;
  * out_z double[n_seg] (NaN where undefined), out_nnull double[n_seg] (may be NULL) = number of
@@ -172,6 +190,11 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
  * wcx_segment_z calls may pass nr = NULL to use it (batches: 165 MB at 15 kb stays in HBM).
  * nr = NULL detaches. */
 int wcx_set_null_matrix(wcx_ctx *ctx, const double *nr, int64_t n_bins, int m);
+/* The same from a DEVICE table of the masked bins' rows (d_nr double[B][m], e.g. straight out of
+ * wcx_null_ratios_dev): inflated to n_bins rows on the device with the reference's mask
+ * (mask[n_bins] host bytes, B of them non-zero; masked-out rows = 0, predict_tools.py:163-170). */
+int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
+                            const unsigned char *mask, int64_t n_bins);
 int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
                   const int64_t *chr_off, int n_chr, const double *seg, int n_seg,
                   double *out_z, double *out_nnull);

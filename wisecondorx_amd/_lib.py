@@ -33,6 +33,8 @@ SIGNATURES = {
     "wcx_last_kernel_ms": (C.c_double, [vp, C.c_char_p]),
     "wcx_last_topk_stats": (C.c_int, [vp, c_i64p]),
     "wcx_transpose_dev": (C.c_int, [vp, vp, c_i64, c_i64, vp]),
+    "wcx_gather_transpose_dev": (C.c_int, [vp, vp, C.c_int, c_i64, c_i64, C.c_int, vp]),
+    "wcx_compact_rows_dev": (C.c_int, [vp, vp, C.c_int, c_i64, c_i64, c_i64, vp]),
     "wcx_newref_topk": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64p, C.c_int, c_i64, c_i64,
                                   C.c_int, C.c_int, vp, vp]),
     "wcx_newref_topk_dev": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64p, C.c_int, c_i64, c_i64,
@@ -58,7 +60,10 @@ SIGNATURES = {
     "wcx_nanmedian2_dev": (C.c_int, [vp, vp, vp, c_i64, vp, vp]),
     "wcx_cbs": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64, vp,
                           C.c_int, C.POINTER(C.c_int)]),
+    "wcx_cbs_batch": (C.c_int, [vp, vp, vp, C.c_int, c_i64, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64,
+                                vp, C.c_int, vp]),
     "wcx_set_null_matrix": (C.c_int, [vp, vp, c_i64, C.c_int]),
+    "wcx_set_null_matrix_dev": (C.c_int, [vp, vp, c_i64, C.c_int, vp, c_i64]),
     "wcx_segment_z": (C.c_int, [vp, vp, vp, vp, C.c_int, c_i64p, C.c_int, vp, C.c_int, vp, vp]),
 }
 

@@ -26,23 +26,36 @@ def max_shard_rows(world, n_rows):
     return max(row_shard(r, world, n_rows)[1] - row_shard(r, world, n_rows)[0] for r in range(world))
 
 
-def allgather_rows(local_rows, n_rows, world, group=None):
-    """local_rows: torch tensor [max_shard_rows, ...] whose first (end-begin) rows are this rank's
-    shard (rest = padding).  Returns the full [n_rows, ...] tensor on every rank."""
+def gather_padded(local_rows, world, group=None):
+    """ONE collective: every rank's [pad, ...] buffer -> [world * pad, ...] on every rank (rank r's
+    rows at r * pad; the rows beyond its shard are padding)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
-        return local_rows[:n_rows]
     pad = local_rows.shape[0]
+    local_rows = local_rows.contiguous()
     if dist.get_backend(group) == "gloo" and local_rows.is_cuda:
         # testing only (two ranks sharing one device): gloo gathers through host memory
         host = torch.empty((world * pad,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype)
-        dist.all_gather_into_tensor(host, local_rows.contiguous().cpu(), group=group)
-        gathered = host.to(local_rows.device)
-    else:
-        gathered = torch.empty((world * pad,) + tuple(local_rows.shape[1:]),
-                               dtype=local_rows.dtype, device=local_rows.device)
-        dist.all_gather_into_tensor(gathered, local_rows.contiguous(), group=group)
+        dist.all_gather_into_tensor(host, local_rows.cpu(), group=group)
+        return host.to(local_rows.device)
+    gathered = torch.empty((world * pad,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype,
+                           device=local_rows.device)
+    dist.all_gather_into_tensor(gathered, local_rows, group=group)
+    return gathered
+
+
+def allgather_rows(local_rows, n_rows, world, group=None, backend=None):
+    """local_rows: torch tensor [max_shard_rows, ...] whose first (end-begin) rows are this rank's
+    shard (rest = padding).  Returns the dense [n_rows, ...] tensor on every rank.  With a GPU
+    backend the padding is squeezed out by one device kernel (wcx_compact_rows_dev); the generic
+    path (CPU tests) concatenates the shards."""
+    import torch
+    if world == 1:
+        return local_rows[:n_rows]
+    pad = local_rows.shape[0]
+    gathered = gather_padded(local_rows, world, group)
+    if backend is not None and hasattr(backend, "compact_rows") and gathered.is_cuda:
+        return backend.compact_rows(gathered, world, pad, n_rows)
     parts = []
     for r in range(world):
         b, e = row_shard(r, world, n_rows)
@@ -111,6 +124,28 @@ class GpuBackend(_GpuPredictMixin):
         _lib.check(self.ctx.lib.wcx_transpose_dev(self.ctx.h, full.data_ptr(), B, S, out.data_ptr()))
         return out
 
+    def gather_transpose(self, gathered, world, pad, B):
+        """Padded row shards of X [world*pad][S] -> sample-major [S][B], padding skipped, in one
+        kernel (no dense row-major intermediate)."""
+        import torch
+        from . import _lib
+        S = gathered.shape[1]
+        out = torch.empty((S, B), dtype=gathered.dtype, device=gathered.device)
+        _lib.check(self.ctx.lib.wcx_gather_transpose_dev(self.ctx.h, gathered.data_ptr(), world, pad,
+                                                         B, S, out.data_ptr()))
+        return out
+
+    def compact_rows(self, gathered, world, pad, B):
+        """Padded row shards of a row-major table -> dense [B, ...] (one device copy kernel)."""
+        import torch
+        from . import _lib
+        out = torch.empty((B,) + tuple(gathered.shape[1:]), dtype=gathered.dtype,
+                          device=gathered.device)
+        row_bytes = gathered[0].numel() * gathered.element_size()
+        _lib.check(self.ctx.lib.wcx_compact_rows_dev(self.ctx.h, gathered.data_ptr(), world, pad, B,
+                                                     row_bytes, out.data_ptr()))
+        return out
+
     def search(self, d_Xs, B, S, chr_cum, row_begin, row_end, k, sample_ids, d_idx, d_dist, d_nr,
                mode=0):
         from . import _lib
@@ -132,9 +167,13 @@ def newref_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, wo
     Returns (idx [n_local,k] int32, dist [n_local,k] f64, nr [n_local,m] f64) for this rank's
     rows, plus the gathered sample-major matrix it was computed from."""
     import torch
-    full = allgather_rows(local_rows, n_rows, world)            # the ONE exchange
-    full = full.contiguous()
-    Xs = backend.transpose(full) if hasattr(backend, "transpose") else full.t().contiguous()
+    if world > 1 and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
+        # the ONE exchange, then padded shards -> sample-major in one kernel
+        Xs = backend.gather_transpose(gather_padded(local_rows, world), world, local_rows.shape[0],
+                                      n_rows)
+    else:
+        full = allgather_rows(local_rows, n_rows, world).contiguous()
+        Xs = backend.transpose(full) if hasattr(backend, "transpose") else full.t().contiguous()
     # ^ sample-major [S][B]
     S = Xs.shape[0]
     b, e = row_shard(rank, world, n_rows)
@@ -148,20 +187,74 @@ def newref_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, wo
     return out[0][:n], out[1][:n], out[2][:n], Xs
 
 
-def gather_reference(idx_local, dist_local, n_rows, world):
+def _padded(t, pad):
+    import torch
+    if t.shape[0] == pad:
+        return t
+    p = torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    p[:t.shape[0]] = t
+    return p
+
+
+def gather_reference(idx_local, dist_local, n_rows, world, backend=None):
     """All-gather the finished row blocks so every rank (= predict replica) holds the whole
     reference.  Inputs are this rank's [n_local, k] blocks."""
-    import torch
     if world == 1:
         return idx_local, dist_local
     pad = max_shard_rows(world, n_rows)
+    return (allgather_rows(_padded(idx_local, pad), n_rows, world, backend=backend),
+            allgather_rows(_padded(dist_local, pad), n_rows, world, backend=backend))
 
-    def padded(t):
-        p = torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        p[:t.shape[0]] = t
-        return p
-    return (allgather_rows(padded(idx_local), n_rows, world),
-            allgather_rows(padded(dist_local), n_rows, world))
+
+def gather_reference3(idx_local, dist_local, nr_local, n_rows, world, backend=None):
+    """gather_reference + the null-ratio rows: the three tables `newref` writes to disk."""
+    if world == 1:
+        return idx_local, dist_local, nr_local
+    pad = max_shard_rows(world, n_rows)
+    return tuple(allgather_rows(_padded(t, pad), n_rows, world, backend=backend)
+                 for t in (idx_local, dist_local, nr_local))
+
+
+def predict_one_dev(backend, idx, dist, nr, d_x, B, k, chr_cum, rem_input, pt):
+    """predict of ONE sample against a reference resident on this device (main.py:191-279 for the
+    autosomal pass): cut-off, weights, normalize_repeat on the device tables; post-processing on
+    the host (O(B)); CBS + segment z on the device with the null ratios inflated in place.
+    Returns the reference's result rows [chr, start, end, z, ratio]."""
+    import numpy as np
+    import torch
+    from . import _lib
+    ctx = backend.ctx
+    lib = ctx.lib
+    cum, cum_p = _lib.i64_array(chr_cum)
+    h = _lib.vp()
+    _lib.check(lib.wcx_ref_wrap_dev(ctx.h, idx.data_ptr(), dist.data_ptr(), B, k, cum_p, len(cum),
+                                    _lib.C.byref(h)))
+    try:
+        args = rem_input["args"]
+        cutoff = _lib.C.c_double()
+        _lib.check(lib.wcx_cutoff(ctx.h, h, int(args.maskrepeats), _lib.C.byref(cutoff)))
+        w = np.empty(B)
+        _lib.check(lib.wcx_weights(ctx.h, h, _lib.ptr(w)))
+        out = torch.empty((3, B), dtype=torch.float64, device=d_x.device)
+        med = torch.empty(2, dtype=torch.float64, device=d_x.device)
+        _lib.check(lib.wcx_predict_normalize_dev(ctx.h, h, d_x.data_ptr(), 1, cutoff.value, 0, 0,
+                                                 out[0].data_ptr(), out[1].data_ptr(),
+                                                 out[2].data_ptr(), med[0:].data_ptr(),
+                                                 med[1:].data_ptr()))
+        ctx.sync()
+        zrn = out.cpu().numpy()
+        m_lr, m_z = (float(v) for v in med.cpu())
+    finally:
+        lib.wcx_ref_free(ctx.h, h)
+    z, r, n = zrn[0], zrn[1], zrn[2]
+    with np.errstate(all="ignore"):
+        results = {"results_r": r, "results_z": z - m_z, "results_w": w / np.nanmean(w)}
+    for key in results:
+        results[key] = pt.get_post_processed_result(args, results[key], n, rem_input)
+    pt.log_trans(results, m_lr)
+    pt.attach_null_matrix_dev(nr, rem_input["mask"], ctx)
+    results["results_nr"] = pt.ATTACHED
+    return pt.exec_cbs(rem_input, results, ctx)
 
 
 def _allreduce2(a, b, world):

@@ -253,6 +253,15 @@ def attach_null_matrix(results_nr, ctx=None):
     return nr.shape
 
 
+def attach_null_matrix_dev(d_nr, mask, ctx=None):
+    """attach_null_matrix for a null-ratio table that is already in HBM (torch tensor or any object
+    with data_ptr()/shape: rows of the MASKED bins): inflated on the device, no host round trip."""
+    ctx = ctx or _lib.default_context()
+    mask8 = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
+    _lib.check(ctx.lib.wcx_set_null_matrix_dev(ctx.h, _lib.ptr(d_nr.data_ptr()), int(d_nr.shape[0]),
+                                               int(d_nr.shape[1]), _lib.ptr(mask8), len(mask8)))
+
+
 ATTACHED = "attached"
 
 
@@ -306,28 +315,65 @@ def exec_cbs(rem_input, results, ctx=None):
     return [results_c[i][:3] + [segment_z[i]] + [results_c[i][3]] for i in range(len(results_c))]
 
 
-def segment_batch(results_list, rem_input, contexts, post=None):
-    """Config 5: CBS + segment z of a batch of samples, striped over `contexts`
-    (one per HIP stream / device; each needs its null matrix attached) from host threads -- ctypes
-    releases the GIL, so one sample's host post-processing overlaps another's kernels.
-    results_list[i] is either a finished results dict or the argument of `post(i)` -> dict.
-    Returns [results_c, ...] in input order."""
-    from concurrent.futures import ThreadPoolExecutor
+def run_cbs_batch(results_list, ref_gender, alpha, binsize, seed, ctx=None):
+    """CBS of a batch of samples in ONE library call (wcx_cbs_batch): all chromosomes of all
+    samples advance together on the device.  results_list: results dicts with the same chromosome
+    layout.  Returns [[chr0, s, e, r], ...] per sample."""
+    ctx = ctx or _lib.default_context()
+    if not results_list:
+        return []
+    n_chr = 24 if ref_gender == "M" else 23            # CBS.R:30-34
+    n_chr = min(n_chr, len(results_list[0]["results_r"]))
+    n = [len(results_list[0]["results_r"][c]) for c in range(n_chr)]
+    off, off_p = _lib.i64_array(np.concatenate(([0], np.cumsum(n))))
+    n_bins = int(off[-1])
+    ns = len(results_list)
+    r = np.empty((ns, n_bins))
+    w = np.empty((ns, n_bins))
+    for i, res in enumerate(results_list):
+        r[i] = np.concatenate([np.asarray(res["results_r"][c], dtype=float) for c in range(n_chr)])
+        w[i] = np.concatenate([np.asarray(res["results_w"][c], dtype=float) for c in range(n_chr)])
+    cap = 4096
+    seg = np.empty((ns, cap, 4))
+    cnt = np.zeros(ns, dtype=np.int32)
+    seed_v = 0 if seed is None else int(seed)
+    _lib.check(ctx.lib.wcx_cbs_batch(ctx.h, _lib.ptr(r), _lib.ptr(w), ns, n_bins, off_p, n_chr,
+                                     float(alpha), int(binsize), seed_v, _lib.ptr(seg), cap,
+                                     _lib.ptr(cnt)))
+    return [[[int(s[0]), int(s[1]), int(s[2]), float(s[3])] for s in seg[i, :cnt[i]]]
+            for i in range(ns)]
 
-    def work(t):
+
+def segment_batch(results_list, rem_input, contexts, post=None):
+    """Config 5: CBS + segment z of a batch of samples.  The segmentation of the
+    whole batch is one level-synchronous device pass (run_cbs_batch) on contexts[0]; the segment
+    z-scores are striped over `contexts` (each needs its null matrix attached) from host threads.
+    results_list[i] is either a finished results dict or the argument of `post(i)` -> dict.
+    Returns [results_c, ...] in input order (rows [chr, start, end, z, ratio])."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(results_list)
+
+    def prep(t):
+        return [(i, post(i) if post is not None else results_list[i])
+                for i in range(t, n, len(contexts))]
+    res = [None] * n
+    with ThreadPoolExecutor(max_workers=len(contexts)) as ex:     # host post-processing in parallel
+        for part in ex.map(prep, range(len(contexts))):
+            for i, rr in part:
+                res[i] = rr
+    segs = run_cbs_batch(res, rem_input["ref_gender"], rem_input["args"].alpha, rem_input["binsize"],
+                         rem_input["args"].seed, contexts[0])
+
+    def zwork(t):
         ctx = contexts[t]
         out = []
-        for i in range(t, len(results_list), len(contexts)):
-            res = post(i) if post is not None else results_list[i]
-            segs = run_cbs(res, rem_input["ref_gender"], rem_input["args"].alpha,
-                           rem_input["binsize"], rem_input["args"].seed, ctx)
-            zs = get_z_score(segs, res, ctx)
-            out.append((i, [[s[0], s[1], s[2], zs[j], s[3]] for j, s in enumerate(segs)]))
+        for i in range(t, n, len(contexts)):
+            zs = get_z_score(segs[i], res[i], ctx)
+            out.append((i, [[s[0], s[1], s[2], zs[j], s[3]] for j, s in enumerate(segs[i])]))
         return out
-    results = [None] * len(results_list)
+    results = [None] * n
     with ThreadPoolExecutor(max_workers=len(contexts)) as ex:
-        for part in ex.map(work, range(len(contexts))):
+        for part in ex.map(zwork, range(len(contexts))):
             for i, rows in part:
                 results[i] = rows
     return results
-
