@@ -154,7 +154,9 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_
  *   wcx_predict_pass_dev    one _normalize_once pass (predict_tools.py:111-142) over the local
  *                           rows >= ct: reads the full x / copy_in vectors [B], writes z, r, n, log2 r
  *                           at position (row - ct) and copy_out[row]; build_mask != 0 on the
- *                           first pass (turns dist < cutoff into the per-row selection mask)
+ *                           first pass (turns dist < cutoff into the per-row selection mask);
+ *                           r and log2 r are only computed when last != 0 (the earlier passes of
+ *                           normalize_repeat feed nothing but the z-mask, predict_tools.py:99-108)
  *   wcx_nanmedian2_dev      np.nanmedian of two arrays (m_lr, m_z; predict_tools.py:105-106) */
 int wcx_ref_wrap_rows_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, int64_t B,
                           int k, const int64_t *chr_cum /*host*/, int n_chr, int64_t row0,

@@ -143,7 +143,7 @@ def test_row_sharded_primitives_equal_batched_path(pt):
     rB, nB, lB = torch.zeros_like(zB), torch.zeros_like(zB), torch.zeros_like(zB)
     cout = xt.clone()
     for hh in (h0, h1):
-        be.predict_pass(hh, xt, xt, cout, cutoff, 0, True, False, zB, rB, nB, lB)
+        be.predict_pass(hh, xt, xt, cout, cutoff, 0, True, True, zB, rB, nB, lB)   # last: r too
     ctx.sync()
     oz, orr, on = O.normalize_once(x, x.copy(), mb, cum, idx, dist, cutoff, 0, 0)
     np.testing.assert_allclose(zB.cpu().numpy(), oz, rtol=1e-9, atol=1e-9)

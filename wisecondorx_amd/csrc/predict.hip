@@ -181,8 +181,12 @@ __global__ __launch_bounds__(NT) void k_normalize_pass(
       if ((keepmask >> q) & 1u) { const double e = v[q] - mean; ssl += e * e; }
     }
     const double sd = sqrt(wcx::wave_sum(ssl) / (double)n);
-    const double med = wcx::wave_median_bucket<IPL>(v, keepmask, n, s_hist[threadIdx.x >> 6],
-                                                    s_slots[threadIdx.x >> 6]);
+    // the ratio (median) of a pass is only ever read after the LAST one (predict_tools.py:99-108:
+    // the earlier passes feed nothing but the z-mask), so only that pass pays for the selection
+    double med = 1.0;
+    if (last_pass)
+      med = wcx::wave_median_bucket<IPL>(v, keepmask, n, s_hist[threadIdx.x >> 6],
+                                         s_slots[threadIdx.x >> 6]);
     if (lane == 0) {
       const double xi = xs[i];
       const double z = (xi - mean) / sd;              // predict_tools.py:136
@@ -194,6 +198,114 @@ __global__ __launch_bounds__(NT) void k_normalize_pass(
       if (last_pass) out_lr[o] = log2(r);
       cout[i] = (fabs(z) >= Z_MASK) ? -1.0 : cin[i];  // predict_tools.py:104
     }
+  }
+}
+
+// Batched form: a wave owns one bin and a TILE of T samples.  test_copy is kept SAMPLE-MINOR
+// (copyT[bin][NS]: the T values of a reference bin are one 8 T-byte piece), so the index row and
+// the selection words of a bin are read ONCE per tile and every gather brings T samples; the
+// statistics of the T samples follow one after the other in the same wave.
+template <int IPL, int T>
+__global__ __launch_bounds__(NT) void k_normalize_pass_tile(
+    const double *__restrict__ x, const double *__restrict__ copy_in,
+    double *__restrict__ copy_out, const int32_t *__restrict__ idx,
+    const unsigned long long *__restrict__ sel, int64_t B, int k, int NS, int n_samples, int64_t ct,
+    int64_t lo, int64_t hi, ChrTable chr, double *__restrict__ out_z, double *__restrict__ out_r,
+    double *__restrict__ out_n, double *__restrict__ out_lr, int last_pass) {
+  const int lane = wcx::lane_id();
+  __shared__ int s_hist[NT / 64][64];
+  __shared__ double s_slots[NT / 64][64];
+  const int s0 = blockIdx.y * T;                 // first sample of this tile
+  const int64_t Bp = B - ct;
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  for (int64_t i = lo + w0; i < hi; i += nw) {
+    int64_t cs = 0, ce = chr.cum[0];
+    for (int c = 1; c < chr.n_chr && i >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+    const int64_t own = ce - cs;
+    const int64_t len_cd = B - own;  // len(chr_data), predict_tools.py:125-130
+    double v[T][IPL];
+    unsigned int selmask = 0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const int t = q * 64 + lane;
+      const bool selq = (t < k) && ((sel[i * IPL + q] >> lane) & 1ull);
+      if (selq) {
+        int64_t c = idx[i * (int64_t)k + t];
+        if (c < 0) c += len_cd;                       // NumPy negative index
+        const int64_t g = c < cs ? c : c + own;       // chr_data index -> row
+        const double *src = copy_in + g * NS + s0;
+#pragma unroll
+        for (int s = 0; s < T; ++s) v[s][q] = src[s];
+        selmask |= 1u << q;
+      } else {
+#pragma unroll
+        for (int s = 0; s < T; ++s) v[s][q] = -1.0;   // fails the >= 0 test below
+      }
+    }
+    // per sample: count, mean, sum of squares (wave reductions), median (last pass only); the
+    // scalar tail (sqrt, two divisions, log2, stores) of the T samples then runs ONCE, sample s in
+    // lane s, instead of T times in lane 0
+    double st_n = 0.0, st_mean = 0.0, st_q = 0.0, st_med = 1.0;
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+      if (s0 + s >= n_samples) break;                 // padding samples of the last tile
+      int nloc = 0;
+      unsigned int keepmask = 0;
+      double sloc = 0.0;
+      double vs[IPL];
+#pragma unroll
+      for (int q = 0; q < IPL; ++q) {
+        const bool keep = ((selmask >> q) & 1u) && v[s][q] >= 0.0;   // predict_tools.py:134
+        vs[q] = keep ? v[s][q] : HUGE_VAL;
+        if (keep) { nloc += 1; sloc += v[s][q]; keepmask |= 1u << q; }
+      }
+      const int n = wcx::wave_sum_i(nloc);
+      const double mean = wcx::wave_sum(sloc) / (double)n;
+      double ssl = 0.0;
+#pragma unroll
+      for (int q = 0; q < IPL; ++q)
+        if ((keepmask >> q) & 1u) { const double e = vs[q] - mean; ssl += e * e; }
+      const double qsum = wcx::wave_sum(ssl);
+      double med = 1.0;                                 // (only the last pass's ratio is ever read)
+      if (last_pass)
+        med = wcx::wave_median_bucket<IPL>(vs, keepmask, n, s_hist[threadIdx.x >> 6],
+                                           s_slots[threadIdx.x >> 6]);
+      if (lane == s) { st_n = (double)n; st_mean = mean; st_q = qsum; st_med = med; }
+    }
+    if (lane < T && s0 + lane < n_samples) {
+      const double sd = sqrt(st_q / st_n);
+      const double xi = x[(int64_t)(s0 + lane) * B + i];
+      const double z = (xi - st_mean) / sd;             // predict_tools.py:136
+      const double r = xi / st_med;                     // predict_tools.py:137
+      const int64_t o = (int64_t)(s0 + lane) * Bp + (i - ct);
+      out_z[o] = z;
+      out_r[o] = r;
+      out_n[o] = st_n;
+      if (last_pass) out_lr[o] = log2(r);
+      copy_out[i * NS + s0 + lane] = (fabs(z) >= Z_MASK) ? -1.0 : copy_in[i * NS + s0 + lane];   // :104
+    }
+  }
+}
+
+// x [n_samples][B] -> sample-minor copies a[B][NS], b[B][NS] (padding samples = 0)
+__global__ __launch_bounds__(256) void k_to_sample_minor(const double *__restrict__ x, int64_t B,
+                                                         int n_samples, int NS, double *__restrict__ a,
+                                                         double *__restrict__ b) {
+  __shared__ double tile[32][33];
+  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int s0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int s = s0 + r;
+    const int64_t bb = b0 + tx;
+    tile[r][tx] = (s < n_samples && bb < B) ? x[(int64_t)s * B + bb] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t bb = b0 + r;
+    const int s = s0 + tx;
+    if (bb < B && s < NS) { const double v = tile[tx][r]; a[bb * NS + s] = v; b[bb * NS + s] = v; }
   }
 }
 
@@ -567,6 +679,40 @@ int launch_pass(wcx_ctx *ctx, const wcx_ref *ref, const double *d_x, const doubl
   return WCX_OK;
 }
 
+// One pass of the tiled (sample-minor) kernel over all rows >= ct of a whole-reference handle.
+template <int T>
+int launch_pass_tile(wcx_ctx *ctx, const wcx_ref *ref, const double *d_x, const double *cin,
+                     double *cout, int n_samples, int NS, int64_t ct, bool last, double *d_z,
+                     double *d_r, double *d_n, double *d_lr) {
+  const int64_t B = ref->B;
+  const int k = ref->k;
+  const int ipl = ipl_for(k);
+  const int64_t lo = ct, hi = B;
+  if (lo >= hi) return WCX_OK;
+  ChrTable tab;
+  tab.n_chr = (int)ref->chr_cum.size();
+  for (int c = 0; c < 32; ++c) tab.cum[c] = c < tab.n_chr ? ref->chr_cum[c] : B;
+  const int64_t nl = hi - lo;
+  dim3 grid((unsigned)((nl + 3) / 4 < 16384 ? (nl + 3) / 4 : 16384), (unsigned)(NS / T));
+#define WCX_NORMT_LAUNCH(IPL)                                                                     \
+  k_normalize_pass_tile<IPL, T><<<grid, NT, 0, ctx->stream>>>(d_x, cin, cout, ref->d_idx, ref->d_sel, \
+                                                               B, k, NS, n_samples, ct, lo, hi, tab, \
+                                                               d_z, d_r, d_n, d_lr, last ? 1 : 0)
+  switch (ipl) {
+    case 1: WCX_NORMT_LAUNCH(1); break;
+    case 2: WCX_NORMT_LAUNCH(2); break;
+    case 3: WCX_NORMT_LAUNCH(3); break;
+    case 4: WCX_NORMT_LAUNCH(4); break;
+    case 5: WCX_NORMT_LAUNCH(5); break;
+    case 6: WCX_NORMT_LAUNCH(6); break;
+    case 7: WCX_NORMT_LAUNCH(7); break;
+    default: WCX_NORMT_LAUNCH(8); break;
+  }
+#undef WCX_NORMT_LAUNCH
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
 int launch_select_mask(wcx_ctx *ctx, wcx_ref *ref, double cutoff, int64_t ct) {
   const int ipl = ipl_for(ref->k);
   int rc = ensure_sel(ctx, ref, ipl);
@@ -605,24 +751,39 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
   }
   const int64_t Bp = B - ct;
   if (Bp <= 0) return WCX_OK;
-  // scratch: copyA[n][B] | copyB[n][B] | lr[n][Bp]
-  const size_t cp_b = (size_t)n_samples * B * 8;
+  // scratch: copyA | copyB | lr[n][Bp].  One sample: copies are plain [B] vectors.  A batch: the
+  // copies are SAMPLE-MINOR [B][NS] (NS = n_samples rounded up to the tile) for the tiled kernel.
+  constexpr int TILE = 8;
+  const bool tiled = n_samples >= 2 && ipl_for(ref->k) <= 8;
+  const int NS = tiled ? (n_samples + TILE - 1) / TILE * TILE : n_samples;
+  const size_t cp_b = (size_t)NS * B * 8;
   const size_t lr_b = (size_t)n_samples * Bp * 8;
   void *scr = nullptr;
   int rc = wcx_scratch(ctx, 2 * cp_b + lr_b, &scr);
   if (rc) return rc;
   double *cA = reinterpret_cast<double *>(scr);
-  double *cB = cA + (size_t)n_samples * B;
-  double *lr = cB + (size_t)n_samples * B;
+  double *cB = cA + (size_t)NS * B;
+  double *lr = cB + (size_t)NS * B;
   rc = wcx_timer_begin(ctx, "normalize");
   if (rc) return rc;
-  const int64_t ntot = (int64_t)n_samples * B;
-  k_copy2<<<(unsigned)((ntot + 255) / 256), 256, 0, ctx->stream>>>(d_x, cA, cB, ntot);
+  if (tiled) {
+    k_to_sample_minor<<<dim3((unsigned)((B + 31) / 32), (unsigned)((NS + 31) / 32)), 256, 0,
+                        ctx->stream>>>(d_x, B, n_samples, NS, cA, cB);
+  } else {
+    const int64_t ntot = (int64_t)n_samples * B;
+    k_copy2<<<(unsigned)((ntot + 255) / 256), 256, 0, ctx->stream>>>(d_x, cA, cB, ntot);
+  }
   rc = launch_select_mask(ctx, ref, cutoff, ct);
   if (rc) return rc;
   for (int pass = 0; pass < 3; ++pass) {  // predict_tools.py:99
-    rc = launch_pass(ctx, ref, d_x, (pass & 1) ? cB : cA, (pass & 1) ? cA : cB, n_samples, ct,
-                     pass == 2, d_out_z, d_out_r, d_out_n, lr);
+    const double *cin = (pass & 1) ? cB : cA;
+    double *cout = (pass & 1) ? cA : cB;
+    if (tiled)
+      rc = launch_pass_tile<TILE>(ctx, ref, d_x, cin, cout, n_samples, NS, ct, pass == 2, d_out_z,
+                                  d_out_r, d_out_n, lr);
+    else
+      rc = launch_pass(ctx, ref, d_x, cin, cout, n_samples, ct, pass == 2, d_out_z, d_out_r, d_out_n,
+                       lr);
     if (rc) return rc;
   }
   // m_lr = nanmedian(log2 r), m_z = nanmedian(z)   (predict_tools.py:105-106)
