@@ -52,7 +52,8 @@ def make_workload(binsize, n_samples, seed=0):
     co = Cohort(binsize, struct_seed=1234 + seed)
     samples, genders = co.cohort(n_samples, seed0=100 + seed)
     mask, bpc = prep.get_mask(samples)
-    p = prep.prepare(samples, "A", mask, bpc)
+    from wisecondorx_amd import _lib
+    p = prep.prepare(samples, "A", mask, bpc, ctx=_lib.default_context(0))   # PCA stage on the GPU
     test = co.sample(777 + seed, "F", cnv=[(3, 100, 100 + max(4, int(4e7 // binsize)), 1.5)])
     return co, p, test
 

@@ -86,6 +86,25 @@ int wcx_gather_transpose_dev(wcx_ctx *ctx, const double *d_src, int world, int64
 int wcx_compact_rows_dev(wcx_ctx *ctx, const void *d_src, int world, int64_t pad_rows, int64_t B,
                          int64_t row_bytes, void *d_dst);
 
+/* ---- newref: PCA correction of the reference samples (input producer of the search) ---- */
+/* Replaces the numerical part of newref_tools.train_pca (newref_tools.py:138-147: PCA with 5
+ * components, X = t / inverse_transform(transform(t))) and the distance-to-median profile of the
+ * PCA-distance bin filter (newref_control.py:38-47).  Exact, deterministic thin SVD through the
+ * S x S Gram matrix instead of the reference's unseeded randomized SVD.  Two steps around the
+ * caller's symmetric eigensolver (numpy.linalg.eigh):
+ *   wcx_pca_begin   t_data double[S][B] sample-major (host) -> per-bin mean[B], Gram matrix
+ *                   double[S][S] of the centred data
+ *   wcx_pca_finish  u double[S][ncomp] (top eigenvectors), sv[ncomp] (singular values)
+ *                   -> components double[ncomp][B] (sign as computed: the caller applies
+ *                   scikit-learn's svd_flip), X double[S][B] sample-major (may be NULL),
+ *                   dist_to_med double[B] (may be NULL).  ncomp must be 5.
+ *   wcx_pca_end     frees the device buffers kept between the two. */
+int wcx_pca_begin(wcx_ctx *ctx, const double *t_data, int64_t B, int S, double *mean_out,
+                  double *gram_out);
+int wcx_pca_finish(wcx_ctx *ctx, const double *u, const double *sv, int ncomp, double *comps_out,
+                   double *X_out, double *dist_to_med_out);
+int wcx_pca_end(wcx_ctx *ctx);
+
 /* ---- newref: reference-bin search ------------------------------------------------- */
 /* Replaces newref_tools.get_ref_for_bins (newref_tools.py:255-278) as driven by
  * newref_tools.get_reference (newref_tools.py:176-206) for target rows

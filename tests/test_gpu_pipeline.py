@@ -46,8 +46,9 @@ def test_reference_file_format(built, g_pipe):
 
 
 def test_sub_references_match_oracle(built, g_pipe):
-    """Same X (the build's deterministic PCA) -> same neighbours as the oracle, A/F/M passes."""
-    from wisecondorx_amd import prep
+    """Same X (the build's deterministic PCA on the device, as the CLI runs it) -> same neighbours
+    as the oracle, A/F/M passes."""
+    from wisecondorx_amd import _lib, prep
     from wisecondorx_amd.overall_tools import gender_correct
     _, out, _ = built
     mine = np.load(out, encoding="latin1", allow_pickle=True)
@@ -60,7 +61,7 @@ def test_sub_references_match_oracle(built, g_pipe):
     total_mask = total_mask & prep.get_mask(samples[g == "F"])[0] & prep.get_mask(samples[g == "M"])[0]
     for gender, sub, ap in (("A", samples, ""), ("F", samples[g == "F"], ".F"),
                             ("M", samples[g == "M"], ".M")):
-        p = prep.prepare(sub, gender, total_mask, bins_per_chr)
+        p = prep.prepare(sub, gender, total_mask, bins_per_chr, ctx=_lib.default_context(0))
         assert np.array_equal(p["mask"], mine["mask" + ap])
         cum = p["masked_bins_per_chr_cum"].tolist()
         oi, od, _ = O.get_reference(p["X"], p["masked_bins_per_chr"].tolist(), cum, 60, 1, 1, [0])
@@ -98,3 +99,44 @@ def test_predict_cli_tables(built, g_pipe):
     assert stats.startswith("chr\tratio.mean\tratio.median\tzscore\n")
     assert "Gender based on --yfrac (or manually overridden by --gender): M" in stats
     assert "Copy number profile abnormality (CPA) score" in stats
+
+
+def test_pca_stage_on_gpu_matches_host(g_pipe):
+    """f2: wcx_pca_begin/finish (Gram, components, reconstruction, ratio, distance profile on the
+    device) vs prep.train_pca (host NumPy, itself pinned against scikit-learn's full-SVD PCA in
+    tests/test_host.py) -- 1e-11; deterministic (two runs, identical bits); prepare() takes the
+    same filter decision through either path on the cohort where the filter fires."""
+    from conftest import GOLDEN
+    from wisecondorx_amd import _lib, prep
+    from wisecondorx_amd.overall_tools import gender_correct
+    from wisecondorx_amd.synth import Cohort
+    ctx = _lib.default_context(0)
+    co = Cohort(100000, struct_seed=5)
+    samples, genders = co.cohort(60, seed0=900, reads=2e6)
+    samples = np.array(samples)
+    mask, bpc = prep.get_mask(samples)
+    data = prep.normalize_and_mask(samples, range(1, 23), mask[:int(np.sum(bpc[:22]))])
+    Xh, ph = prep.train_pca(data)
+    Xg, pg, d2m = prep.train_pca_gpu(data, ctx, want_dist=True)
+    np.testing.assert_allclose(pg.mean_, ph.mean_, rtol=1e-13)
+    np.testing.assert_allclose(Xg, Xh, rtol=1e-11)
+    # components 4-5 sit in a near-degenerate noise subspace: compare the projector, not the basis
+    np.testing.assert_allclose(pg.components_[:3], ph.components_[:3], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(pg.components_.T @ pg.components_ @ np.ones(Xh.shape[0]),
+                               ph.components_.T @ ph.components_ @ np.ones(Xh.shape[0]), rtol=1e-7,
+                               atol=1e-9)
+    med_prof = np.median(Xh, axis=0)
+    np.testing.assert_allclose(d2m, np.sum((Xh - med_prof) ** 2, axis=1), rtol=1e-9)
+    Xg2, pg2, d2m2 = prep.train_pca_gpu(data, ctx, want_dist=True)
+    assert np.array_equal(Xg, Xg2) and np.array_equal(pg.components_, pg2.components_)
+    assert np.array_equal(d2m, d2m2)
+    # the cohort in which the PCA-distance filter fires (reference-run fixture): same decisions
+    g = np.load(os.path.join(GOLDEN, "prep_filter.npz"), allow_pickle=False)
+    gcs = np.array([str(x) for x in g["cohort_genders"]])
+    smp = np.array([gender_correct(sample_from_counts(c, g["cohort_bpc"]), gd)
+                    for c, gd in zip(g["cohort_counts"], gcs)])
+    tm, bins = prep.get_mask(smp)
+    tm = tm & prep.get_mask(smp[gcs == "F"])[0] & prep.get_mask(smp[gcs == "M"])[0]
+    for gender, sub in (("A", smp), ("F", smp[gcs == "F"]), ("M", smp[gcs == "M"])):
+        p = prep.prepare(sub, gender, tm, bins, ctx=ctx)
+        assert np.array_equal(p["mask"], g[gender + "_mask"]), gender

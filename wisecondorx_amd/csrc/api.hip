@@ -133,6 +133,7 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_small) hipFree(ctx->d_small);
   if (ctx->d_nullm) hipFree(ctx->d_nullm);
+  if (ctx->d_pca) hipFree(ctx->d_pca);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return WCX_OK;

@@ -519,6 +519,15 @@ static int launch_nanmedian_wide(wcx_ctx *ctx, const double *a0, const double *a
   return WCX_OK;
 }
 
+// np.nanmedian of `count` rows of n doubles (row r at d_a + r * stride) -> d_out[count]; used by the
+// PCA stage (pca.hip) for np.median(X, axis=0).
+int wcx_nanmedian_rows_launch(wcx_ctx *ctx, const double *d_a, int64_t n, int64_t stride, int count,
+                              double *d_out) {
+  k_nanmedian<<<dim3((unsigned)count, 1), NTM, 0, ctx->stream>>>(d_a, d_a, n, stride, d_out, d_out);
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
 extern "C" {
 
 int wcx_ref_wrap_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, int64_t B, int k,

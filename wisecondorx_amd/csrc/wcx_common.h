@@ -54,6 +54,11 @@ struct wcx_ctx {
   double *d_nullm = nullptr;
   int64_t nullm_bins = 0;
   int nullm_m = 0;
+  // PCA stage (wcx_pca_begin .. wcx_pca_end): t | X | mean | components | dist_to_med
+  void *d_pca = nullptr;
+  size_t pca_bytes = 0;
+  int64_t pca_B = 0;
+  int pca_S = 0;
   // host staging for small async uploads (kept alive until the next stream sync)
   std::vector<std::vector<unsigned char>> stage;
 };

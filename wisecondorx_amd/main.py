@@ -88,7 +88,7 @@ def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, context
     """One of the A / F / M passes: tool_newref_prep + tool_newref_main + tool_newref_post
     (newref_control.py:24-189) without the temp-file round trips."""
     from . import newref_tools
-    p = prep.prepare(samples, gender, total_mask, bins_per_chr)
+    p = prep.prepare(samples, gender, total_mask, bins_per_chr, ctx=contexts[0])   # PCA on the device
     X = p.pop("X")
     cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
     n_parts = len(contexts)

@@ -74,6 +74,43 @@ def train_pca(ref_data, pcacomp=5):
     return corrected.T, PCAModel(comps, mean)
 
 
+def train_pca_gpu(ref_data, ctx, pcacomp=5, want_dist=False):
+    """train_pca on the MI355X (libwcx_hip.so: wcx_pca_begin / wcx_pca_finish): Gram matrix,
+    components, reconstruction and ratio on the device, the S x S eigenproblem here (LAPACK).
+    Same return values as train_pca (+ the filter's dist_to_med profile if want_dist)."""
+    from . import _lib
+    t_data = np.ascontiguousarray(ref_data.T, dtype=np.float64)          # (S, B) sample-major
+    S, B = t_data.shape
+    mean = np.empty(B)
+    gram = np.empty((S, S))
+    _lib.check(ctx.lib.wcx_pca_begin(ctx.h, _lib.ptr(t_data), B, S, _lib.ptr(mean), _lib.ptr(gram)))
+    try:
+        w, v = np.linalg.eigh(gram)
+        order = np.argsort(w)[::-1][:pcacomp]
+        sv = np.ascontiguousarray(np.sqrt(np.maximum(w[order], 0.0)))
+        u = np.ascontiguousarray(v[:, order])                             # (S, pcacomp)
+        comps = np.empty((pcacomp, B))
+        Xs = np.empty((S, B))
+        d2m = np.empty(B) if want_dist else None
+        _lib.check(ctx.lib.wcx_pca_finish(ctx.h, _lib.ptr(u), _lib.ptr(sv), pcacomp, _lib.ptr(comps),
+                                          _lib.ptr(Xs), _lib.ptr(d2m)))
+    finally:
+        ctx.lib.wcx_pca_end(ctx.h)
+    # sklearn's svd_flip convention: largest |loading| of each component is positive
+    signs = np.sign(comps[np.arange(pcacomp), np.argmax(np.abs(comps), axis=1)])
+    signs[signs == 0] = 1.0
+    comps = comps * signs[:, None]
+    out = (Xs.T, PCAModel(comps, mean))                                   # X: F-ordered (B, S) view
+    return out + (d2m,) if want_dist else out
+
+
+def filter_from_dist(dist_to_med):
+    """newref_control.py:42-47 on a precomputed distance profile."""
+    mad = np.median(np.abs(dist_to_med - np.median(dist_to_med)))
+    cutoff = max(np.median(dist_to_med) + 10 * mad, 5.0)
+    return dist_to_med > cutoff, cutoff
+
+
 def pca_distance_filter(pca_corrected_data):
     """newref_control.py:38-47: bins far from the median profile.  Returns bad-bin mask."""
     med_prof = np.median(pca_corrected_data, axis=0)
@@ -83,22 +120,26 @@ def pca_distance_filter(pca_corrected_data):
     return dist_to_med > cutoff, cutoff
 
 
-def prepare(samples, gender, mask, bins_per_chr):
+def prepare(samples, gender, mask, bins_per_chr, ctx=None):
     """The numerical part of newref_control.tool_newref_prep (newref_control.py:24-66).
     NOTE: like the reference, this mutates `mask` IN PLACE when the PCA-distance filter
-    fires (newref_control.py:48-54)."""
+    fires (newref_control.py:48-54).  ctx: a device context -> the PCA stage runs on the GPU."""
     last_chr = {"A": 22, "F": 23}.get(gender, 24)
     bins_per_chr = list(bins_per_chr[:last_chr])
     mask = mask[:int(np.sum(bins_per_chr))]
     masked_data = normalize_and_mask(samples, range(1, last_chr + 1), mask)
-    X, pca = train_pca(masked_data)
-    bad, cutoff = pca_distance_filter(X)
+    if ctx is not None:
+        X, pca, d2m = train_pca_gpu(masked_data, ctx, want_dist=True)
+        bad, cutoff = filter_from_dist(d2m)
+    else:
+        X, pca = train_pca(masked_data)
+        bad, cutoff = pca_distance_filter(X)
     if np.any(bad):
         logging.info("Removing {} anomalous bins based on PCA distance (cutoff={:.4f})".format(
             int(np.sum(bad)), cutoff))
         mask[np.where(mask)[0][bad]] = False
         masked_data = normalize_and_mask(samples, range(1, last_chr + 1), mask)
-        X, pca = train_pca(masked_data)
+        X, pca = train_pca_gpu(masked_data, ctx) if ctx is not None else train_pca(masked_data)
     off = np.concatenate(([0], np.cumsum(bins_per_chr)))
     masked_bins_per_chr = [int(np.sum(mask[off[i]:off[i + 1]])) for i in range(len(bins_per_chr))]
     masked_bins_per_chr_cum = np.cumsum(masked_bins_per_chr).tolist()
