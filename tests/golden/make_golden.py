@@ -294,6 +294,96 @@ def golden_prep_filter():
     save("prep_filter.npz", **out)
 
 
+# --------------------------------------------------------------------------- f3 output tables
+def golden_tables():
+    """Byte pins of the `predict --bed --regions` tables: the reference's own tool_test run end to
+    end on the tiny cohort with only the R call stubbed (exec_R -> hand-made segments: DNAcopy is
+    not available).  Captured: the arguments of generate_output_tables (what the formatting code
+    sees) and the files it wrote."""
+    import wisecondorx.predict_output as ref_po
+    binsize = 4000000
+    co = Cohort(binsize, struct_seed=11, female_y=0.1)
+    samples, genders = co.cohort(24, seed0=500, reads=4e6)
+    tmp = tempfile.mkdtemp(prefix="wcx_golden_tab_")
+    infiles = []
+    for i, smp in enumerate(samples):
+        path = os.path.join(tmp, "s{}.npz".format(i))
+        write_sample(path, smp, binsize)
+        infiles.append(path)
+    args = argparse.Namespace(infiles=infiles, outfile=os.path.join(tmp, "ref.npz"), nipt=False,
+                              yfrac=0.004, plotyfrac=None, refsize=60, binsize=binsize, cpus=1)
+    np.random.seed(5)
+    random.seed(5)
+    try:
+        ref_main.tool_newref(args)
+    except NameError as e:
+        print("expected reference bug:", e)
+    test = co.sample(9001, "M", reads=4e6, cnv=[(3, 10, 25, 1.5)])
+    tpath = os.path.join(tmp, "t.npz")
+    write_sample(tpath, test, binsize)
+    regions = os.path.join(tmp, "regions.bed")
+    with open(regions, "w") as fh:
+        fh.write("chr3\t40000001\t100000000\tplanted\n2\t1\t12000000\tquiet\nchr1\t999000000\t999900000\tbeyond\n")
+
+    def stub_exec_R(json_dict):          # stands in for Rscript CBS.R (DNAcopy absent)
+        out = []
+        for c, (rr, ww) in enumerate(zip(json_dict["results_r"], json_dict["results_w"])):
+            n = len(rr)
+            cuts = [0, 10, 25, n] if c == 2 else ([0, n // 2, n] if c % 3 == 0 else [0, n])
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                r = np.asarray(rr[a:b], dtype=float)
+                w = np.asarray(ww[a:b], dtype=float)
+                keep = r != 0
+                if b - a < 1 or not keep.any():
+                    continue
+                out.append({"chr": c + 1, "s": a, "e": b,
+                            "r": float(np.sum(r[keep] * w[keep]) / np.sum(w[keep]))})
+        return out
+    ref_pt.exec_R = stub_exec_R
+    captured = {}
+    real_tables = ref_po.generate_output_tables
+
+    def spy_tables(rem_input, results):
+        captured["rem"], captured["res"] = rem_input, results
+        real_tables(rem_input, results)
+    ref_main.generate_output_tables = spy_tables
+    outid = os.path.join(tmp, "ID")
+    targs = argparse.Namespace(infile=tpath, reference=args.outfile, outid=outid, minrefbins=20,
+                               maskrepeats=5, alpha=1e-4, zscore=4.0, beta=None, blacklist=None,
+                               gender=None, ylim="def", bed=True, plot=False, cairo=False,
+                               add_plot_title=False, seed=3, regions=regions)
+    ref_main.tool_test(targs)
+    ref_main.generate_output_tables = real_tables
+    rem, res = captured["rem"], captured["res"]
+    out = {"binsize": np.array(rem["binsize"]), "n_reads": np.array(rem["n_reads"]),
+           "ref_gender": np.array(rem["ref_gender"]), "gender": np.array(rem["gender"]),
+           "bins_per_chr": np.asarray(rem["bins_per_chr"]), "zscore": np.array(4.0),
+           "regions_text": np.array(open(regions).read())}
+    nchr = len(res["results_r"])
+    for key in ("results_r", "results_z", "results_w"):
+        out[key] = np.concatenate([np.asarray(c, dtype=float) for c in res[key]])
+    m = max(len(row) for c in res["results_nr"] for row in c if np.ndim(row) > 0)
+    nr = np.full((len(out["results_r"]), m), np.nan)
+    i = 0
+    for c in res["results_nr"]:
+        for row in c:
+            if np.ndim(row) > 0:
+                nr[i, :len(row)] = row
+            else:
+                nr[i, :] = 0.0                 # the int 0 placeholder of masked bins
+            i += 1
+    out["results_nr"] = nr
+    out["results_c_num"] = np.array([[s[0], s[1], s[2], np.nan if isinstance(s[3], str) else s[3], s[4]]
+                                     for s in res["results_c"]], dtype=float)
+    out["results_c_isstr"] = np.array([isinstance(s[3], str) for s in res["results_c"]])
+    assert nchr == 24
+    for suffix in ("_bins.bed", "_segments.bed", "_aberrations.bed", "_statistics.txt", "_regions.bed"):
+        out["file" + suffix.replace(".", "_")] = np.array(open(outid + suffix).read())
+    print(open(outid + "_aberrations.bed").read())
+    print(open(outid + "_statistics.txt").read()[-400:])
+    save("tables.npz", **out)
+
+
 # --------------------------------------------------------------------------- BASELINE config 1
 def golden_config1():
     """BASELINE.json configs[0]: predict one synthetic sample at 1 Mb bins (~3.1 k bins) against
@@ -365,7 +455,9 @@ def golden_config1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["search", "pipeline", "prep_filter", "config1"]
+    which = sys.argv[1:] or ["search", "pipeline", "prep_filter", "config1", "tables"]
+    if "tables" in which:
+        golden_tables()
     if "config1" in which:
         golden_config1()
     if "search" in which:

@@ -140,3 +140,23 @@ def test_pca_stage_on_gpu_matches_host(g_pipe):
     for gender, sub in (("A", smp), ("F", smp[gcs == "F"]), ("M", smp[gcs == "M"])):
         p = prep.prepare(sub, gender, tm, bins, ctx=ctx)
         assert np.array_equal(p["mask"], g[gender + "_mask"]), gender
+
+
+def test_statistics_file_matches_reference(tmp_path):
+    """f3 pin of ID_statistics.txt (predict_output.py:197-263): every text field identical, every
+    number within 1e-9 of the reference's file (the per-chromosome z-scores come out of the
+    segment-z kernel; MSV / CPA / read count / gender lines are byte-identical)."""
+    from test_host import _tables_case
+    from wisecondorx_amd import predict_output as po
+    g, rem, results = _tables_case(tmp_path)
+    po.generate_output_tables(rem, results)
+    mine = open(rem["args"].outid + "_statistics.txt").read().splitlines()
+    gold = str(g["file_statistics_txt"]).splitlines()
+    assert len(mine) == len(gold) == 1 + 24 + 5
+    assert mine[0] == gold[0] and mine[25:] == gold[25:]
+    for a, b in zip(mine[1:25], gold[1:25]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert fa[0] == fb[0] and len(fa) == len(fb) == 4
+        np.testing.assert_allclose([float(v) for v in fa[1:]], [float(v) for v in fb[1:]], rtol=1e-9)
+    for suffix in ("_bins.bed", "_segments.bed", "_aberrations.bed", "_regions.bed"):
+        assert open(rem["args"].outid + suffix).read() == str(g["file" + suffix.replace(".", "_")])

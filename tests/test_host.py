@@ -210,3 +210,39 @@ def test_pca_distance_filter_fires_and_skews_masks():
         np.testing.assert_allclose(p["pca_mean"], g[gender + "_pca_mean"], rtol=1e-13, atol=0)
     assert len(g["A_removed"]) == 9 and len(g["F_removed"]) == 1
     assert g["A_mask"][:n_aut].sum() == g["F_mask"][:n_aut].sum() + 1      # the skew
+
+
+def _tables_case(tmp_path):
+    """results / rem_input exactly as the reference's tool_test handed them to its
+    generate_output_tables (tests/golden/tables.npz; exec_R stubbed, see make_golden.py)."""
+    import argparse
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "tables.npz"), allow_pickle=False)
+    bpc = g["bins_per_chr"]
+    off = np.concatenate(([0], np.cumsum(bpc)))
+    split = lambda a: [a[off[c]:off[c + 1]] for c in range(len(bpc))]
+    segs = [[int(s[0]), int(s[1]), int(s[2]), "nan" if isstr else float(s[3]), float(s[4])]
+            for s, isstr in zip(g["results_c_num"], g["results_c_isstr"])]
+    results = {"results_r": split(g["results_r"]), "results_z": split(g["results_z"]),
+               "results_w": split(g["results_w"]), "results_nr": split(g["results_nr"]),
+               "results_c": segs}
+    regions = tmp_path / "regions.bed"
+    regions.write_text(str(g["regions_text"]))
+    args = argparse.Namespace(outid=str(tmp_path / "ID"), zscore=float(g["zscore"]), beta=None,
+                              regions=str(regions))
+    rem = {"args": args, "binsize": int(g["binsize"]), "n_reads": int(g["n_reads"]),
+           "ref_gender": str(g["ref_gender"]), "gender": str(g["gender"]), "bins_per_chr": bpc}
+    return g, rem, results
+
+
+def test_output_tables_byte_identical_to_reference(tmp_path):
+    """f3 pin: ID_bins.bed, ID_segments.bed, ID_aberrations.bed, ID_regions.bed are BYTE-identical
+    to the files the reference's predict_output.py:51-194 wrote for the same results."""
+    from wisecondorx_amd import predict_output as po
+    g, rem, results = _tables_case(tmp_path)
+    po._generate_bins_bed(rem, results)
+    po._generate_segments_and_aberrations_bed(rem, results)
+    po._generate_regions_bed(rem, results)
+    for suffix in ("_bins.bed", "_segments.bed", "_aberrations.bed", "_regions.bed"):
+        mine = open(rem["args"].outid + suffix).read()
+        assert mine == str(g["file" + suffix.replace(".", "_")]), suffix
