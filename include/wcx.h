@@ -135,6 +135,12 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
 int wcx_null_ratios(wcx_ctx *ctx, const double *Xs, int64_t B, int S, const int32_t *idx,
                     int64_t row_begin, int64_t row_end, int k, const int32_t *sample_ids,
                     int n_ids, double *out);
+/* Optional head start for wcx_null_ratios_dev: ranks the null samples (the part of the null-ratio
+ * work that depends on X only) on an auxiliary stream of the context, concurrently with whatever
+ * follows on the main stream (the search); the next wcx_null_ratios_dev with the same dXs and
+ * sample_ids uses it.  Results are identical with or without this call. */
+int wcx_null_rank_prepare_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                              const int32_t *sample_ids /*host*/, int n_ids);
 int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                         const int32_t *d_idx, int64_t row_begin, int64_t row_end, int k,
                         const int32_t *sample_ids /*host*/, int n_ids, double *d_out);

@@ -44,6 +44,7 @@ SIGNATURES = {
                                       C.c_int, C.c_int, vp, vp]),
     "wcx_null_ratios": (C.c_int, [vp, vp, c_i64, C.c_int, vp, c_i64, c_i64, C.c_int, c_i32p,
                                   C.c_int, vp]),
+    "wcx_null_rank_prepare_dev": (C.c_int, [vp, vp, c_i64, C.c_int, c_i32p, C.c_int]),
     "wcx_null_ratios_dev": (C.c_int, [vp, vp, c_i64, C.c_int, vp, c_i64, c_i64, C.c_int,
                                       c_i32p, C.c_int, vp]),
     "wcx_ref_upload": (C.c_int, [vp, vp, vp, c_i64, C.c_int, c_i64p, C.c_int, C.POINTER(vp)]),

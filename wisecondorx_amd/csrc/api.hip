@@ -134,6 +134,13 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
   if (ctx->d_small) hipFree(ctx->d_small);
   if (ctx->d_nullm) hipFree(ctx->d_nullm);
   if (ctx->d_pca) hipFree(ctx->d_pca);
+  if (ctx->aux_stream) {
+    hipStreamSynchronize(ctx->aux_stream);
+    hipStreamDestroy(ctx->aux_stream);
+    hipEventDestroy(ctx->ev_main);
+    hipEventDestroy(ctx->ev_rank);
+  }
+  if (ctx->d_rank) hipFree(ctx->d_rank);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return WCX_OK;

@@ -20,6 +20,8 @@
 // 15 kb); the selection arithmetic still dominates -- see DESIGN.md.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+
 #include "wave_sort.h"
 #include "wcx_common.h"
 
@@ -244,6 +246,120 @@ __global__ __launch_bounds__(NT) void k_null_ratios(
 
 extern "C" {
 
+// Ranking of every null sample (keys, two radix sorts, scatter into rank pieces + sorted values)
+// on stream `st` into the buffer at `base` (layout from rank_layout()).
+struct RankLayout {
+  size_t o_sid, o_nan, o_k32a, o_k32b, o_pa, o_pb, o_k64a, o_k64b, o_rg, o_v, o_tmp, total, tmp_a, tmp_b;
+  int sample_bits, n_sg;
+};
+
+static int rank_layout(int64_t B, int n_ids, hipStream_t st, RankLayout &L) {
+  const int64_t n = (int64_t)n_ids * B;
+  L.n_sg = (n_ids + 7) / 8;
+  L.sample_bits = 1;
+  while ((1 << L.sample_bits) < n_ids) ++L.sample_bits;
+  L.tmp_a = L.tmp_b = 0;
+  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, L.tmp_a, (const unsigned int *)nullptr,
+                                             (unsigned int *)nullptr, (const unsigned int *)nullptr,
+                                             (unsigned int *)nullptr, (int)n, 0, 32, st));
+  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, L.tmp_b, (const unsigned long long *)nullptr,
+                                             (unsigned long long *)nullptr,
+                                             (const unsigned int *)nullptr, (unsigned int *)nullptr,
+                                             (int)n, 0, 32 + L.sample_bits, st));
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  L.o_sid = carve((size_t)n_ids * 4);
+  L.o_nan = carve((size_t)n_ids * 4);
+  L.o_k32a = carve((size_t)n * 4); L.o_k32b = carve((size_t)n * 4);
+  L.o_pa = carve((size_t)n * 4); L.o_pb = carve((size_t)n * 4);
+  L.o_k64a = carve((size_t)n * 8); L.o_k64b = carve((size_t)n * 8);
+  L.o_rg = carve((size_t)L.n_sg * B * 32);
+  L.o_v = carve((size_t)n * 8);
+  L.o_tmp = carve(L.tmp_a > L.tmp_b ? L.tmp_a : L.tmp_b);
+  L.total = off;
+  return WCX_OK;
+}
+
+static int rank_run(const double *dXs, int64_t B, int n_ids, const RankLayout &L, char *base,
+                    hipStream_t st) {
+  const int64_t n = (int64_t)n_ids * B;
+  int32_t *d_sids = reinterpret_cast<int32_t *>(base + L.o_sid);
+  int *d_nan = reinterpret_cast<int *>(base + L.o_nan);
+  unsigned int *k32a = reinterpret_cast<unsigned int *>(base + L.o_k32a);
+  unsigned int *k32b = reinterpret_cast<unsigned int *>(base + L.o_k32b);
+  unsigned int *pa = reinterpret_cast<unsigned int *>(base + L.o_pa);
+  unsigned int *pb = reinterpret_cast<unsigned int *>(base + L.o_pb);
+  unsigned long long *k64a = reinterpret_cast<unsigned long long *>(base + L.o_k64a);
+  unsigned long long *k64b = reinterpret_cast<unsigned long long *>(base + L.o_k64b);
+  unsigned int *Rg = reinterpret_cast<unsigned int *>(base + L.o_rg);
+  double *V = reinterpret_cast<double *>(base + L.o_v);
+  void *tmp = base + L.o_tmp;
+  WCX_HIP(hipMemsetAsync(d_nan, 0, (size_t)n_ids * 4, st));
+  if (n_ids & 7) WCX_HIP(hipMemsetAsync(Rg + (int64_t)(L.n_sg - 1) * B * 8, 0, (size_t)B * 32, st));
+  const unsigned gb = (unsigned)((B + NT - 1) / NT), gn = (unsigned)((n + NT - 1) / NT);
+  k_nr_keys<<<dim3(gb, (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, k32a, pa, d_nan);
+  size_t ta = L.tmp_a, tb = L.tmp_b;
+  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, ta, k32a, k32b, pa, pb, (int)n, 0, 32, st));
+  k_nr_key64<<<gn, NT, 0, st>>>(dXs, B, d_sids, pb, n, k64a);
+  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k64a, k64b, pb, pa, (int)n, 0,
+                                             32 + L.sample_bits, st));
+  k_nr_scatter<<<gn, NT, 0, st>>>(dXs, B, d_sids, pa, n, Rg, V);
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
+static int check_ids(const int32_t *sample_ids, int n_ids, int S) {
+  for (int i = 0; i < n_ids; ++i)
+    WCX_ARG(sample_ids[i] >= 0 && sample_ids[i] < S, "sample id out of range");
+  return WCX_OK;
+}
+
+// Optional head start: rank the null samples on the context's AUXILIARY stream while the search
+// (which needs nothing of this) runs on the main one; the next wcx_null_ratios_dev with the same
+// matrix and ids picks the result up.  The ranking depends on X only, not on the row shard: in a
+// multi-GPU build it is per-rank fixed cost, so it is worth hiding.
+int wcx_null_rank_prepare_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
+                              const int32_t *sample_ids, int n_ids) {
+  WCX_ARG(ctx && dXs && sample_ids, "NULL argument");
+  WCX_ARG(B > 0 && S > 0 && n_ids > 0, "bad sizes");
+  WCX_ARG(B < (1ll << BIN_BITS) && n_ids <= 128, "too many bins / null samples");
+  WCX_ARG((int64_t)n_ids * B < (1ll << 31), "null samples x bins exceeds 2^31");
+  int rc = check_ids(sample_ids, n_ids, S);
+  if (rc) return rc;
+  WCX_HIP(hipSetDevice(ctx->device));
+  if (!ctx->aux_stream) {
+    WCX_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    WCX_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+    WCX_HIP(hipEventCreateWithFlags(&ctx->ev_rank, hipEventDisableTiming));
+  }
+  RankLayout L;
+  rc = rank_layout(B, n_ids, ctx->aux_stream, L);
+  if (rc) return rc;
+  if (ctx->rank_bytes < L.total) {
+    WCX_HIP(hipStreamSynchronize(ctx->aux_stream));
+    WCX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_rank) { WCX_HIP(hipFree(ctx->d_rank)); ctx->d_rank = nullptr; ctx->rank_bytes = 0; }
+    if (hipMalloc(&ctx->d_rank, L.total) != hipSuccess) {
+      wcx_set_error("hipMalloc(%zu) for the null-sample ranks failed", L.total);
+      return WCX_ERR_NOMEM;
+    }
+    ctx->rank_bytes = L.total;
+  }
+  char *base = reinterpret_cast<char *>(ctx->d_rank);
+  // X is produced on the main stream: the auxiliary stream starts behind its current position
+  WCX_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
+  WCX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_main, 0));
+  ctx->rank_ids.assign(sample_ids, sample_ids + n_ids);
+  WCX_HIP(hipMemcpyAsync(base + L.o_sid, ctx->rank_ids.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice,
+                         ctx->aux_stream));
+  rc = rank_run(dXs, B, n_ids, L, base, ctx->aux_stream);
+  if (rc) return rc;
+  WCX_HIP(hipEventRecord(ctx->ev_rank, ctx->aux_stream));
+  ctx->rank_X = dXs;
+  ctx->rank_B = B;
+  return WCX_OK;
+}
+
 int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                         const int32_t *d_idx, int64_t row_begin, int64_t row_end, int k,
                         const int32_t *sample_ids, int n_ids, double *d_out) {
@@ -252,64 +368,39 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_ARG(0 <= row_begin && row_begin <= row_end && row_end <= B, "bad row range");
   WCX_ARG(B < (1ll << BIN_BITS) && n_ids <= 128, "too many bins / null samples");
   WCX_ARG((int64_t)n_ids * B < (1ll << 31), "null samples x bins exceeds 2^31");
-  for (int i = 0; i < n_ids; ++i)
-    WCX_ARG(sample_ids[i] >= 0 && sample_ids[i] < S, "sample id out of range");
+  int rc = check_ids(sample_ids, n_ids, S);
+  if (rc) return rc;
   WCX_HIP(hipSetDevice(ctx->device));
   const int64_t n_rows = row_end - row_begin;
   if (n_rows == 0 || n_ids == 0) return WCX_OK;
-  const int n_sg = (n_ids + 7) / 8;
-  const int64_t n = (int64_t)n_ids * B;
   hipStream_t st = ctx->stream;
-
-  // temp storage of the two sorts (sizes only)
-  size_t tmp_a = 0, tmp_b = 0;
-  int sample_bits = 1;
-  while ((1 << sample_bits) < n_ids) ++sample_bits;
-  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_a, (const unsigned int *)nullptr,
-                                             (unsigned int *)nullptr, (const unsigned int *)nullptr,
-                                             (unsigned int *)nullptr, (int)n, 0, 32, st));
-  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_b, (const unsigned long long *)nullptr,
-                                             (unsigned long long *)nullptr,
-                                             (const unsigned int *)nullptr, (unsigned int *)nullptr,
-                                             (int)n, 0, 32 + sample_bits, st));
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t o_sid = carve((size_t)n_ids * 4);
-  const size_t o_nan = carve((size_t)n_ids * 4);
-  const size_t o_k32a = carve((size_t)n * 4), o_k32b = carve((size_t)n * 4);
-  const size_t o_pa = carve((size_t)n * 4), o_pb = carve((size_t)n * 4);
-  const size_t o_k64a = carve((size_t)n * 8), o_k64b = carve((size_t)n * 8);
-  const size_t o_rg = carve((size_t)n_sg * B * 32);
-  const size_t o_v = carve((size_t)n * 8);
-  const size_t o_tmp = carve(tmp_a > tmp_b ? tmp_a : tmp_b);
-  void *scr = nullptr;
-  int rc = wcx_scratch(ctx, off, &scr);
+  RankLayout L;
+  rc = rank_layout(B, n_ids, st, L);
   if (rc) return rc;
-  char *base = reinterpret_cast<char *>(scr);
-  int32_t *d_sids = reinterpret_cast<int32_t *>(base + o_sid);
-  int *d_nan = reinterpret_cast<int *>(base + o_nan);
-  unsigned int *k32a = reinterpret_cast<unsigned int *>(base + o_k32a);
-  unsigned int *k32b = reinterpret_cast<unsigned int *>(base + o_k32b);
-  unsigned int *pa = reinterpret_cast<unsigned int *>(base + o_pa);
-  unsigned int *pb = reinterpret_cast<unsigned int *>(base + o_pb);
-  unsigned long long *k64a = reinterpret_cast<unsigned long long *>(base + o_k64a);
-  unsigned long long *k64b = reinterpret_cast<unsigned long long *>(base + o_k64b);
-  unsigned int *Rg = reinterpret_cast<unsigned int *>(base + o_rg);
-  double *V = reinterpret_cast<double *>(base + o_v);
-  void *tmp = base + o_tmp;
-  rc = wcx_upload_small(ctx, d_sids, sample_ids, (size_t)n_ids * 4);
-  if (rc) return rc;
+  char *base = nullptr;
+  const bool prepared = ctx->rank_X == dXs && ctx->rank_B == B && (int)ctx->rank_ids.size() == n_ids &&
+                        std::equal(ctx->rank_ids.begin(), ctx->rank_ids.end(), sample_ids);
   rc = wcx_timer_begin(ctx, "null_ratios");
   if (rc) return rc;
-  WCX_HIP(hipMemsetAsync(d_nan, 0, (size_t)n_ids * 4, st));
-  if (n_ids & 7) WCX_HIP(hipMemsetAsync(Rg + (int64_t)(n_sg - 1) * B * 8, 0, (size_t)B * 32, st));
-  const unsigned gb = (unsigned)((B + NT - 1) / NT), gn = (unsigned)((n + NT - 1) / NT);
-  k_nr_keys<<<dim3(gb, (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, k32a, pa, d_nan);
-  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_a, k32a, k32b, pa, pb, (int)n, 0, 32, st));
-  k_nr_key64<<<gn, NT, 0, st>>>(dXs, B, d_sids, pb, n, k64a);
-  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_b, k64a, k64b, pb, pa, (int)n, 0,
-                                             32 + sample_bits, st));
-  k_nr_scatter<<<gn, NT, 0, st>>>(dXs, B, d_sids, pa, n, Rg, V);
+  if (prepared) {          // ranked ahead on the auxiliary stream (wcx_null_rank_prepare_dev)
+    base = reinterpret_cast<char *>(ctx->d_rank);
+    WCX_HIP(hipStreamWaitEvent(st, ctx->ev_rank, 0));
+    ctx->rank_X = nullptr;
+  } else {
+    void *scr = nullptr;
+    rc = wcx_scratch(ctx, L.total, &scr);
+    if (rc) return rc;
+    base = reinterpret_cast<char *>(scr);
+    rc = wcx_upload_small(ctx, base + L.o_sid, sample_ids, (size_t)n_ids * 4);
+    if (rc) return rc;
+    rc = rank_run(dXs, B, n_ids, L, base, st);
+    if (rc) return rc;
+  }
+  const int32_t *d_sids = reinterpret_cast<const int32_t *>(base + L.o_sid);
+  const int *d_nan = reinterpret_cast<const int *>(base + L.o_nan);
+  const unsigned int *Rg = reinterpret_cast<const unsigned int *>(base + L.o_rg);
+  const double *V = reinterpret_cast<const double *>(base + L.o_v);
+  const int n_sg = L.n_sg;
   const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)n_sg);
 #define WCX_NR_LAUNCH(IPL)                                                                      \
   k_null_ratios<IPL><<<grid, NT, 0, st>>>(Rg, V, d_nan, dXs, d_sids, B, d_idx, row_begin, n_rows, \

@@ -54,6 +54,14 @@ struct wcx_ctx {
   double *d_nullm = nullptr;
   int64_t nullm_bins = 0;
   int nullm_m = 0;
+  // null-sample ranking done ahead on an auxiliary stream (wcx_null_rank_prepare_dev)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_main = nullptr, ev_rank = nullptr;
+  void *d_rank = nullptr;
+  size_t rank_bytes = 0;
+  const double *rank_X = nullptr;
+  int64_t rank_B = 0;
+  std::vector<int32_t> rank_ids;
   // PCA stage (wcx_pca_begin .. wcx_pca_end): t | X | mean | components | dist_to_med
   void *d_pca = nullptr;
   size_t pca_bytes = 0;

@@ -152,6 +152,9 @@ class GpuBackend(_GpuPredictMixin):
         lib = self.ctx.lib
         cum, cum_p = _lib.i64_array(chr_cum)
         ids, ids_p = _lib.i32_array(sample_ids)
+        # the ranking of the null samples needs X only: start it on the auxiliary stream now, it
+        # runs beside the search
+        _lib.check(lib.wcx_null_rank_prepare_dev(self.ctx.h, d_Xs.data_ptr(), B, S, ids_p, len(ids)))
         _lib.check(lib.wcx_newref_topk_dev(self.ctx.h, d_Xs.data_ptr(), B, S, cum_p, len(cum),
                                            row_begin, row_end, k, mode, d_idx.data_ptr(),
                                            d_dist.data_ptr()))
