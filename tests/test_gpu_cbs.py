@@ -111,3 +111,24 @@ def test_cbs_wrapper_logic_matches_oracle(pt):
     np.testing.assert_allclose([s[3] for s in segs], [s[3] for s in exp], rtol=1e-12)
     assert not any(s[0] == 1 for s in segs)
     assert [s[:3] for s in segs if s[0] == 3] == [[3, 0, 100], [3, 159, 400]]  # piece starts AT the last NA bin
+
+
+@pytest.mark.parametrize("n_big", [20000, 40000])
+def test_cbs_long_chromosomes(pt, n_big):
+    """Chromosomes beyond 16 384 bins (chr1/chr2 below ~14 kb bins) and beyond the LDS sort
+    capacity of the permutation kernel (32 768 keys -> global-scratch variant): planted
+    change-points are found where they are, noise stays whole (the old bucket scan
+    covered only 1024 buckets; the old API refused > 32 768 bins)."""
+    rng = np.random.default_rng(11)
+    n_per_chr = [n_big, 3000, 250]
+    res = _noise_results(rng, n_per_chr, sd=0.06)
+    res["results_r"][0][7000:7400] += 0.3              # interior gain on the long chromosome
+    res["results_r"][0][n_big - 900:] -= 0.35          # loss running to its end
+    res["results_r"][1][rng.random(3000) < 0.03] = 0   # scattered missing bins
+    segs = pt.run_cbs(res, "F", 1e-4, 5000, 3)
+    c0 = sorted((s, e, r) for c, s, e, r in segs if c == 0)
+    assert len(c0) == 4, c0
+    assert abs(c0[1][0] - 7000) <= 3 and abs(c0[1][1] - 7400) <= 3 and abs(c0[1][2] - 0.3) < 0.03
+    assert abs(c0[3][0] - (n_big - 900)) <= 3 and c0[3][1] == n_big and abs(c0[3][2] + 0.35) < 0.03
+    assert len([1 for c, s, e, r in segs if c == 1]) == 1 and len([1 for c, s, e, r in segs if c == 2]) == 1
+    assert pt.run_cbs(res, "F", 1e-4, 5000, 3) == segs  # deterministic in the seed

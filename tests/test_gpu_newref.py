@@ -317,3 +317,28 @@ def test_large_bin_count_5kb(nt):
     ids = [0, 7, 23]
     nr = nt.get_null_ratios(X, idx[r0:], r0, B, ids)
     np.testing.assert_allclose(nr, O.null_ratios(X, idx[r0:], r0, B, ids), rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("segments", ["1", "3"])
+def test_failed_threshold_estimates_are_redone_exactly(nt, segments, monkeypatch):
+    """The sampled pre-pass hands every target an ESTIMATED threshold; a wrong (too tight) estimate
+    must be caught by the final cut and the row redone by the exact kernel -- on the device, no host
+    round trip.  Forced here with an absurd sample rank (r = 2 at a 1/4 sample): most rows fail,
+    every result is still bit-identical to the C oracle."""
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd.synth import corrected_matrix
+    monkeypatch.setenv("WCX_SCREEN_SAMPLE", "4")
+    monkeypatch.setenv("WCX_SCREEN_CUT_R", "2")
+    monkeypatch.setenv("WCX_SCREEN_SEGMENTS", segments)
+    X, mbpc, cum = corrected_matrix([1500, 1300, 1100, 900, 700, 500], 36, seed=23)
+    k = 80
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, cum[-1], mode=2)
+    st = _lib.default_context().topk_stats()
+    assert st["fallback_rows"] > 100                    # the estimates did fail ...
+    oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, 0, cum[-1], k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)   # ... and nothing shows
+    # sane estimate on the same data: no row needs the exact kernel
+    monkeypatch.delenv("WCX_SCREEN_CUT_R")
+    idx2, dist2 = nt.get_ref_for_rows(X, cum, k, 0, cum[-1], mode=2)
+    assert _lib.default_context().topk_stats()["fallback_rows"] == 0
+    assert np.array_equal(idx2, oi) and np.array_equal(dist2, od)

@@ -538,6 +538,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     cut_r = (int)ceil(1.1 * kf + 6.0 * sqrt(kf)) + 1;
     // the sample must hold several times cut_r candidates and cut_r must be well below k
     if (cut_r * 2 > k || P_s / n_seg < 16 * (int64_t)cut_r) cut_r = 0;
+    // testing: a deliberately unsafe rank makes estimates fail, which the final cut must detect
+    // (rows go to the exact kernel; results stay identical)
+    const int forced = env_int("WCX_SCREEN_CUT_R", 0);
+    if (forced > 0 && forced < k) cut_r = forced;
   }
   // scratch layout
   size_t off = 0;
