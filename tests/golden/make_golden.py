@@ -244,6 +244,42 @@ def golden_pipeline():
         out[name + "_segz"] = np.array([np.nan if isinstance(z, str) else float(z) for z in zs])
         out[name + "_segz_isstr"] = np.array([isinstance(z, str) for z in zs])
     save("pipeline.npz", **out)
+    golden_ref_qc(args.outfile, ref_dict)
+
+
+def golden_ref_qc(ref_path, ref_dict):
+    """The reference's ref_qc on the golden reference file and on two doctored copies (a WARN and a
+    FAIL case): per-sub-reference metrics (ref_qc._compute_metrics) and the overall return code."""
+    import wisecondorx.ref_qc as ref_qc
+    out = {}
+    cases = {"plain": dict(ref_dict)}
+    wide = dict(ref_dict)            # refsize 180 >= MINREFBINS, so that the other rules are reached
+    for suf in (".F", ".M"):
+        wide["indexes" + suf] = np.tile(ref_dict["indexes" + suf], (1, 3))
+        wide["distances" + suf] = np.tile(ref_dict["distances" + suf], (1, 3))
+    cases["wide"] = wide
+    warn = dict(wide)
+    warn["distances.F"] = np.array(wide["distances.F"]) * np.linspace(1, 60, len(wide["distances.F"]))[:, None] * 4e1
+    cases["spread"] = warn
+    fail = dict(wide)
+    fail["distances.M"] = np.array(wide["distances.M"]) * 1e4
+    fail["distances.F"] = np.array(wide["distances.F"]) * np.linspace(1, 60, len(wide["distances.F"]))[:, None] * 4e3
+    cases["heavy"] = fail
+    for name, d in cases.items():
+        path = os.path.join(os.path.dirname(ref_path), "qc_{}.npz".format(name))
+        np.savez(path, **d)
+        out[name + "_code"] = np.array(ref_qc.qc_reference(path))
+        npz = np.load(path, encoding="latin1", allow_pickle=True)
+        for suf in (".F", ".M"):
+            m = ref_qc._compute_metrics(npz, suf)
+            for key in ("n_bins", "n_valid", "mean_of_means", "std_of_means", "n_mean_outlier",
+                        "outlier_pct", "n_low_refs"):
+                out["{}{}_{}".format(name, suf, key)] = np.array(m[key])
+            if m.get("chrY"):
+                for key, val in m["chrY"].items():
+                    out["{}{}_chrY_{}".format(name, suf, key)] = np.array(val)
+    out["spread_scale_F"] = np.linspace(1, 60, len(wide["distances.F"]))
+    save("ref_qc.npz", **out)
 
 
 # --------------------------------------------------------------------------- a1/a3 prep pins

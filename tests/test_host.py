@@ -246,3 +246,37 @@ def test_output_tables_byte_identical_to_reference(tmp_path):
     for suffix in ("_bins.bed", "_segments.bed", "_aberrations.bed", "_regions.bed"):
         mine = open(rem["args"].outid + suffix).read()
         assert mine == str(g["file" + suffix.replace(".", "_")]), suffix
+
+
+def test_ref_qc_matches_reference(g_pipe):
+    """f4: ref_qc.compute_metrics / qc_reference vs the reference's own ref_qc.py run on the golden
+    reference and on doctored copies reaching the WARN and FAIL rules (tests/golden/ref_qc.npz)."""
+    from conftest import GOLDEN, ref_dict_from_golden
+    from wisecondorx_amd import ref_qc
+    g = np.load(os.path.join(GOLDEN, "ref_qc.npz"), allow_pickle=False)
+    plain = ref_dict_from_golden(g_pipe)
+    wide = dict(plain)
+    for suf in (".F", ".M"):
+        wide["indexes" + suf] = np.tile(plain["indexes" + suf], (1, 3))
+        wide["distances" + suf] = np.tile(plain["distances" + suf], (1, 3))
+    spread = dict(wide)
+    spread["distances.F"] = wide["distances.F"] * g["spread_scale_F"][:, None] * 4e1
+    heavy = dict(wide)
+    heavy["distances.M"] = wide["distances.M"] * 1e4
+    heavy["distances.F"] = wide["distances.F"] * g["spread_scale_F"][:, None] * 4e3
+    codes = {}
+    for name, ref in (("plain", plain), ("wide", wide), ("spread", spread), ("heavy", heavy)):
+        codes[name] = ref_qc.qc_reference(ref)
+        assert codes[name] == int(g[name + "_code"]), name
+        for suf in (".F", ".M"):
+            m = ref_qc.compute_metrics(ref, suf)
+            for key in ("n_bins", "n_valid", "n_mean_outlier", "n_low_refs"):
+                assert m[key] == int(g["{}{}_{}".format(name, suf, key)]), (name, suf, key)
+            for key in ("mean_of_means", "std_of_means", "outlier_pct"):
+                np.testing.assert_allclose(m[key], float(g["{}{}_{}".format(name, suf, key)]), rtol=1e-12)
+            if suf == ".M":
+                for key, val in m["chrY"].items():
+                    np.testing.assert_allclose(val, float(g["{}{}_chrY_{}".format(name, suf, key)]),
+                                               rtol=1e-12)
+    assert sorted(set(codes.values())) == [0, 1, 2]          # PASS, WARN and FAIL all reached
+    assert ref_qc.qc_reference(os.path.join(GOLDEN, "no_such_file.npz")) == 2

@@ -174,6 +174,9 @@ def tool_newref(args):
                                             np.sum(final_ref["mask" + ap][:n_aut]))))
     npz_io.save_npz(args.outfile, final_ref)
     logging.info("Finished creating reference")
+    logging.info("Running QC on the newly created reference...")       # main.py:134-135
+    from .ref_qc import qc_reference
+    qc_reference(final_ref)
 
 
 # --------------------------------------------------------------------------- gender / predict
