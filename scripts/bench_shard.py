@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Search time of ONE rank's row shard (what each GPU does in an N-GPU newref): rows [0, B/N) of the
-15 kb problem on this device, for N = 1, 2, 4, 8 and candidate-segment counts (WCX_SCREEN_SEGMENTS)."""
+"""Per-rank compute of an N-GPU newref, measured on ONE device: rank r = 3 (N = 8), 1 (N = 2, 4), 0
+(N = 1) builds its row shard of the 15 kb problem (search + null ratios) for N = 1, 2, 4, 8 and several
+candidate-segment counts (WCX_SCREEN_SEGMENTS); wall time of the whole shard build incl. the ranking
+on the auxiliary stream.  This is what the 1 -> 8 GPU curve can at best look like (the all-gathers come
+on top): DESIGN.md section 5."""
 import json
 import os
 import sys
@@ -27,20 +30,28 @@ def main():
     d_Xs = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)
     ids = np.arange(min(S, 100), dtype=np.int32)
     out = {}
+    import time
+    from wisecondorx_amd.newref_tools import _get_part
     for n in (1, 2, 4, 8):
-        rows = B // n
+        r0, r1 = _get_part(min(n - 1, {1: 0, 2: 1, 4: 1, 8: 3}[n]), n, B)
+        rows = r1 - r0
         d_idx = torch.empty((rows, 300), dtype=torch.int32, device=dev)
         d_dist = torch.empty((rows, 300), dtype=torch.float64, device=dev)
         d_nr = torch.empty((rows, len(ids)), dtype=torch.float64, device=dev)
-        for seg in ("auto", "1", "2", "4"):
+        for seg in ("auto", "1", "4", "8"):
             if seg == "auto":
                 os.environ.pop("WCX_SCREEN_SEGMENTS", None)
             else:
                 os.environ["WCX_SCREEN_SEGMENTS"] = seg
-            for _ in range(2):
-                be.search(d_Xs, B, S, cum, 0, rows, 300, ids, d_idx, d_dist, d_nr)
+            for _ in range(3):
                 ctx.sync()
+                t0 = time.perf_counter()
+                be.search(d_Xs, B, S, cum, r0, r1, 300, ids, d_idx, d_dist, d_nr)
+                ctx.sync()
+                wall = 1e3 * (time.perf_counter() - t0)
             out["N{}_seg{}".format(n, seg)] = {
+                "rows": rows, "shard_wall_ms": round(wall, 3),
+                "fallback_rows": ctx.topk_stats()["fallback_rows"],
                 "screen_ms": round(ctx.kernel_ms("topk_screen"), 3),
                 "refine_ms": round(ctx.kernel_ms("topk_refine"), 3),
                 "topk_ms": round(ctx.kernel_ms("topk"), 3),

@@ -56,7 +56,7 @@ __device__ void bitonic_sort_lds(double *sd, int *si, int n) {
 // are per workgroup (TM rows each).
 __global__ __launch_bounds__(NT) void k_topk_exact(
     const double *__restrict__ Xs, int64_t B, int S, const TopkBlock *__restrict__ blocks,
-    const unsigned int *__restrict__ n_blocks_dev,
+    const unsigned int *__restrict__ n_blocks_dev, unsigned int first_blk,
     int k, int C, double *__restrict__ scr_d, int *__restrict__ scr_i, int64_t row_begin,
     int32_t *__restrict__ out_idx, double *__restrict__ out_dist,
     unsigned long long *__restrict__ stats) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NT) void k_topk_exact(
   const unsigned int n_blk = n_blocks_dev ? *n_blocks_dev : gridDim.x;
   const int lim = C - TN;  // a row may receive at most TN appends per tile
   unsigned long long n_compact = 0;
-  for (unsigned int bi = blockIdx.x; bi < n_blk; bi += gridDim.x) {
+  for (unsigned int bi = first_blk + blockIdx.x; bi < n_blk; bi += gridDim.x) {
   const TopkBlock blk = blocks[bi];
   const int64_t orow0 = blk.row0 - row_begin;                       // output row of local row 0
   const int64_t srow0 = n_blocks_dev ? (int64_t)blockIdx.x * TM : orow0;   // scratch row
@@ -186,6 +186,147 @@ __global__ __launch_bounds__(NT) void k_topk_exact(
   if (tid == 0 && stats && n_compact) atomicAdd(&stats[2], n_compact);
 }
 
+// Fast redo of a HANDFUL of flagged rows (the normal case when the screen's sampled estimate fails
+// for a row): the candidate sweep of one row is spread over the whole device instead of one
+// workgroup.  k_redo_dist writes the row's exact distances to all candidates outside its chromosome
+// (same arithmetic as k_topk_exact: sequential, separately rounded) as order-preserving 64-bit keys;
+// k_redo_select finds the k-th smallest key by an 8 x 8-bit radix select, collects everything below
+// it plus the lowest-index ties, and rank-sorts the k pairs by (distance, index).
+constexpr int RS_NT = 1024;
+
+__global__ __launch_bounds__(NT) void k_redo_dist(const double *__restrict__ Xs, int64_t B, int S,
+                                                  const TopkBlock *__restrict__ blocks,
+                                                  const unsigned int *__restrict__ n_blocks_dev,
+                                                  unsigned long long *__restrict__ keys) {
+  unsigned int n = *n_blocks_dev;
+  if (n > (unsigned)WCX_REDO_FAST) n = WCX_REDO_FAST;
+  const int64_t nchunk = (B + NT - 1) / NT;
+  for (int64_t w = blockIdx.x; w < (int64_t)n * nchunk; w += gridDim.x) {
+    const unsigned int slot = (unsigned int)(w / nchunk);
+    const int64_t c = (w % nchunk) * NT + threadIdx.x;
+    const TopkBlock blk = blocks[slot];
+    if (c >= B || (c >= blk.cs && c < blk.ce)) continue;
+    double acc = 0.0;
+    for (int j = 0; j < S; ++j) {
+      const double *row = Xs + (int64_t)j * B;
+      const double diff = row[c] - row[blk.row0];
+      const double sq = diff * diff;
+      acc = acc + sq;
+    }
+    const int64_t stored = c < blk.cs ? c : c - (blk.ce - blk.cs);
+    keys[(int64_t)slot * B + stored] = acc < 1e10 ? (unsigned long long)__double_as_longlong(acc) : ~0ull;
+  }
+}
+
+__global__ __launch_bounds__(RS_NT) void k_redo_select(int64_t B, const TopkBlock *__restrict__ blocks,
+                                                       const unsigned int *__restrict__ n_blocks_dev,
+                                                       const unsigned long long *__restrict__ keys,
+                                                       int k, int64_t row_begin,
+                                                       int32_t *__restrict__ out_idx,
+                                                       double *__restrict__ out_dist) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double *sd = reinterpret_cast<double *>(smem);                  // [k]
+  int *si = reinterpret_cast<int *>(smem + (size_t)k * 8);        // [k]
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int wtot[RS_NT / 64];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned int s_rem, s_cnt;
+  unsigned int n = *n_blocks_dev;
+  if (n > (unsigned)WCX_REDO_FAST) n = WCX_REDO_FAST;
+  const int tid = threadIdx.x;
+  for (unsigned int slot = blockIdx.x; slot < n; slot += gridDim.x) {
+    const TopkBlock blk = blocks[slot];
+    const int64_t Bc = B - (blk.ce - blk.cs);
+    const unsigned long long *kb = keys + (int64_t)slot * B;
+    __syncthreads();
+    int mine = 0;
+    for (int64_t i = tid; i < Bc; i += RS_NT) mine += kb[i] != ~0ull;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&s_cnt, (unsigned)mine);
+    __syncthreads();
+    const int kk = (int)((unsigned)k < s_cnt ? (unsigned)k : s_cnt);
+    __syncthreads();
+    if (tid == 0) { s_prefix = 0; s_rem = (unsigned)kk; s_cnt = 0; }
+    if (kk > 0) {
+      for (int pass = 7; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        for (int64_t i0 = tid; i0 < Bc; i0 += 4 * RS_NT) {
+          unsigned long long kv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + (int64_t)u * RS_NT;
+            kv[u] = i < Bc ? kb[i] : ~0ull;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool in = kv[u] != ~0ull && (pass == 7 || (kv[u] >> (shift + 8)) == (prefix >> (shift + 8)));
+            if (in) atomicAdd(&hist[(unsigned)(kv[u] >> shift) & 255u], 1u);
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned int cum = 0, rem = s_rem;
+          int b = 0;
+          for (; b < 255; ++b) {
+            if (cum + hist[b] >= rem) break;
+            cum += hist[b];
+          }
+          s_rem = rem - cum;
+          s_prefix = prefix | ((unsigned long long)b << shift);
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+    const unsigned long long T = s_prefix;
+    const int m = (int)s_rem;          // ties at T to take (lowest indices first)
+    const int n_lt = kk - m;
+    int tie_base = 0;
+    if (kk > 0) {
+      for (int64_t base = 0; base < Bc; base += RS_NT) {
+        const int64_t i = base + tid;
+        const unsigned long long key = i < Bc ? kb[i] : ~0ull;
+        if (key < T) {
+          const unsigned int pos = atomicAdd(&s_cnt, 1u);
+          sd[pos] = __longlong_as_double((long long)key);
+          si[pos] = (int)i;
+        }
+        const bool tie = key == T;
+        const int nt = __syncthreads_count(tie);
+        if (nt && tie_base < m) {
+          const unsigned long long bal = __ballot(tie);
+          const int lane = tid & 63, wv = tid >> 6;
+          if (lane == 0) wtot[wv] = (unsigned)__popcll(bal);
+          __syncthreads();
+          int p = __popcll(bal & ((1ull << lane) - 1ull));
+          for (int w2 = 0; w2 < wv; ++w2) p += (int)wtot[w2];
+          if (tie && tie_base + p < m) {
+            sd[n_lt + tie_base + p] = __longlong_as_double((long long)key);
+            si[n_lt + tie_base + p] = (int)i;
+          }
+          __syncthreads();
+        }
+        tie_base += nt;
+      }
+    }
+    __syncthreads();
+    const int64_t ob = (blk.row0 - row_begin) * (int64_t)k;
+    for (int t = tid; t < kk; t += RS_NT) {
+      const double d = sd[t];
+      const int ix = si[t];
+      int rank = 0;
+      for (int j = 0; j < kk; ++j) rank += key_less(sd[j], si[j], d, ix);
+      out_idx[ob + rank] = ix;
+      out_dist[ob + rank] = d;
+    }
+    for (int t = kk + tid; t < k; t += RS_NT) { out_idx[ob + t] = -1; out_dist[ob + t] = 1e10; }
+  }
+}
+
 __global__ void k_fill_dummy(int32_t *idx, double *dist, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { idx[i] = 0; dist[i] = 1.0; }
@@ -237,7 +378,7 @@ int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   rc = wcx_timer_begin(ctx, "topk");
   if (rc) return rc;
   k_topk_exact<<<(unsigned)blocks.size(), NT, lds, ctx->stream>>>(
-      dXs, B, S, d_blocks, nullptr, k, C, scr_d, scr_i, row_begin, d_out_idx, d_out_dist, d_stats);
+      dXs, B, S, d_blocks, nullptr, 0u, k, C, scr_d, scr_i, row_begin, d_out_idx, d_out_dist, d_stats);
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk");
   if (rc) return rc;
@@ -245,12 +386,18 @@ int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
 }
 
 // Device-driven redo (no host round trip): `d_blocks[0 .. *d_count)` was written by the screen's
-// k_collect_redo; a fixed grid of WCX_REDO_GRID workgroups strides over it (normally *d_count = 0
-// and the launch returns at once).  `scratch` must hold wcx_topk_redo_scratch_bytes(k) bytes.
-size_t wcx_topk_redo_scratch_bytes(int k) {
+// k_collect_redo (normally *d_count = 0 and every launch returns at once).  The first
+// WCX_REDO_FAST rows take the device-wide path (k_redo_dist + k_redo_select, ~1 ms for a handful of
+// rows); anything beyond that goes to a fixed grid of WCX_REDO_GRID workgroups of the blocked exact
+// kernel.  `scratch` must hold wcx_topk_redo_scratch_bytes(k, B) bytes.
+static size_t redo_blocked_bytes(int k) {
   int C = 1024;
   while (C < k + TN) C <<= 1;
-  return (size_t)WCX_REDO_GRID * TM * C * 12;
+  return ((size_t)WCX_REDO_GRID * TM * C * 12 + 255) / 256 * 256;
+}
+
+size_t wcx_topk_redo_scratch_bytes(int k, int64_t B) {
+  return redo_blocked_bytes(k) + (size_t)WCX_REDO_FAST * (size_t)B * 8;
 }
 
 int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
@@ -258,6 +405,21 @@ int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S
                                int64_t row_begin, int k, int32_t *d_out_idx, double *d_out_dist) {
   int C = 1024;
   while (C < k + TN) C <<= 1;
+  if (C > 8192) {
+    wcx_set_error("refsize %d too large for the exact top-k kernel (max %d)", k, 8192 - TN);
+    return WCX_ERR_UNSUPPORTED;
+  }
+  unsigned long long *keys =
+      reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(scratch) + redo_blocked_bytes(k));
+  k_redo_dist<<<1024, NT, 0, ctx->stream>>>(dXs, B, S, d_blocks, d_count, keys);
+  WCX_HIP(hipGetLastError());
+  const size_t sel_lds = (size_t)k * 12;
+  WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_redo_select),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+  k_redo_select<<<WCX_REDO_FAST, RS_NT, sel_lds, ctx->stream>>>(B, d_blocks, d_count, keys, k, row_begin,
+                                                               d_out_idx, d_out_dist);
+  WCX_HIP(hipGetLastError());
+
   const size_t tile_bytes = (size_t)JC * (TM + TN) * 8;
   const size_t sort_bytes = (size_t)C * 12;
   const size_t lds = HDR + (tile_bytes > sort_bytes ? tile_bytes : sort_bytes);
@@ -266,9 +428,9 @@ int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S
                                        (size_t)WCX_REDO_GRID * TM * C * 8);
   WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_topk_exact),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_topk_exact<<<WCX_REDO_GRID, NT, lds, ctx->stream>>>(dXs, B, S, d_blocks, d_count, k, C, scr_d,
-                                                        scr_i, row_begin, d_out_idx, d_out_dist,
-                                                        nullptr);
+  k_topk_exact<<<WCX_REDO_GRID, NT, lds, ctx->stream>>>(dXs, B, S, d_blocks, d_count,
+                                                        (unsigned)WCX_REDO_FAST, k, C, scr_d, scr_i,
+                                                        row_begin, d_out_idx, d_out_dist, nullptr);
   WCX_HIP(hipGetLastError());
   return WCX_OK;
 }

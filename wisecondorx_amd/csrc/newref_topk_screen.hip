@@ -521,21 +521,31 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   }
   const int wg_per_cu = cfg.lb * 4 / cfg.wpb > 0 ? cfg.lb * 4 / cfg.wpb : 1;
   const int slots = hw_cus * wg_per_cu;
+  // (measured on row shards of 1/2 .. 1/8 of the 15 kb problem, profiles/r02/shard_search_*.json: with
+  // the sampled pre-pass and 2-3 resident workgroups per CU the split no longer pays -- 1 segment
+  // is as fast or faster down to 178 blocks -- so it is off unless asked for)
   int n_seg = 1;
-  if ((int)blocks.size() < slots) {
-    n_seg = (int)((2 * slots + blocks.size() - 1) / blocks.size());   // >= 2 rounds of work items
-    if (n_seg > 8) n_seg = 8;
-  }
+  (void)slots;
   n_seg = env_int("WCX_SCREEN_SEGMENTS", n_seg);
   if (n_seg < 1) n_seg = 1;
   if (n_seg > 8) n_seg = 8;
   // r = a rank in the sample that the k-th nearest of all candidates stays below with
   // overwhelming probability (mean k/SF of the k nearest fall into the sample; + 10 % for the
-  // uneven share of the own chromosome, + 6 sigma): the estimate admits ~r SF candidates.
+  // uneven share of the own chromosome, Poisson tail 1e-6 per row): the estimate admits ~r SF
+  // candidates; a row whose estimate fails costs ~0.1 ms in the device-wide redo.
   int cut_r = 0;
   if (SF) {
-    const double kf = (double)k / ((double)SF * n_seg);
-    cut_r = (int)ceil(1.1 * kf + 6.0 * sqrt(kf)) + 1;
+    // smallest r with P(Poisson(lambda) >= r) <= 1e-6 / n_seg,  lambda = 1.1 k / (SF n_seg)
+    const double lambda = 1.1 * (double)k / ((double)SF * n_seg);
+    const double target = 1e-6 / n_seg;
+    double term = exp(-lambda), cdf = 0.0;   // term = P(X = i)
+    int i = 0;
+    for (; i < 4 * k; ++i) {
+      if (1.0 - cdf <= target && (double)i > lambda) break;
+      cdf += term;
+      term *= lambda / (double)(i + 1);
+    }
+    cut_r = i + 1;
     // the sample must hold several times cut_r candidates and cut_r must be well below k
     if (cut_r * 2 > k || P_s / n_seg < 16 * (int64_t)cut_r) cut_r = 0;
     // testing: a deliberately unsafe rank makes estimates fail, which the final cut must detect
@@ -569,7 +579,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_blk = carve(blocks.size() * sizeof(ScreenBlock));
   const size_t o_redo = carve((size_t)n_rows * sizeof(TopkBlock));
   const size_t o_nredo = carve(256);
-  const size_t o_rscr = carve(wcx_topk_redo_scratch_bytes(k));
+  const size_t o_rscr = carve(wcx_topk_redo_scratch_bytes(k, B));
   void *scr = nullptr;
   int rc = wcx_scratch(ctx, off, &scr);
   if (rc) return rc;

@@ -103,7 +103,8 @@ int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                           const std::vector<TopkBlock> &blocks, int64_t row_begin,
                           int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist);
 constexpr int WCX_REDO_GRID = 64;   // workgroups of the device-driven exact redo
-size_t wcx_topk_redo_scratch_bytes(int k);
+constexpr int WCX_REDO_FAST = 128;  // flagged rows that take the device-wide redo path
+size_t wcx_topk_redo_scratch_bytes(int k, int64_t B);
 int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                                const TopkBlock *d_blocks, const unsigned int *d_count, void *scratch,
                                int64_t row_begin, int k, int32_t *d_out_idx, double *d_out_dist);
