@@ -655,6 +655,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_prep");
   if (rc) return rc;
+  rc = wcx_aux_kick(ctx);   // pending null-sample ranking: beside the MFMA-bound sweep
+  if (rc) return rc;
   rc = wcx_timer_begin(ctx, "topk_screen");
   if (rc) return rc;
 

@@ -345,20 +345,38 @@ int wcx_null_rank_prepare_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     }
     ctx->rank_bytes = L.total;
   }
-  char *base = reinterpret_cast<char *>(ctx->d_rank);
-  // X is produced on the main stream: the auxiliary stream starts behind its current position
-  WCX_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
-  WCX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_main, 0));
   ctx->rank_ids.assign(sample_ids, sample_ids + n_ids);
-  WCX_HIP(hipMemcpyAsync(base + L.o_sid, ctx->rank_ids.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice,
-                         ctx->aux_stream));
-  rc = rank_run(dXs, B, n_ids, L, base, ctx->aux_stream);
-  if (rc) return rc;
-  WCX_HIP(hipEventRecord(ctx->ev_rank, ctx->aux_stream));
   ctx->rank_X = dXs;
   ctx->rank_B = B;
+  ctx->rank_pending = true;   // started by wcx_aux_kick: behind the search's prep, beside its screen
   return WCX_OK;
 }
+
+}  // extern "C"
+
+// Starts the pending ranking on the auxiliary stream, behind the main stream's current position.
+// The search calls this once its (HBM-bound) prep kernels are enqueued, so that the (HBM-bound)
+// radix sort runs beside the MFMA-bound screen instead of beside the prep; wcx_null_ratios_dev
+// calls it as a catch-all.
+int wcx_aux_kick(wcx_ctx *ctx) {
+  if (!ctx->rank_pending) return WCX_OK;
+  ctx->rank_pending = false;
+  const int n_ids = (int)ctx->rank_ids.size();
+  RankLayout L;
+  int rc = rank_layout(ctx->rank_B, n_ids, ctx->aux_stream, L);
+  if (rc) return rc;
+  char *base = reinterpret_cast<char *>(ctx->d_rank);
+  WCX_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
+  WCX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_main, 0));
+  WCX_HIP(hipMemcpyAsync(base + L.o_sid, ctx->rank_ids.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice,
+                         ctx->aux_stream));
+  rc = rank_run(ctx->rank_X, ctx->rank_B, n_ids, L, base, ctx->aux_stream);
+  if (rc) return rc;
+  WCX_HIP(hipEventRecord(ctx->ev_rank, ctx->aux_stream));
+  return WCX_OK;
+}
+
+extern "C" {
 
 int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                         const int32_t *d_idx, int64_t row_begin, int64_t row_end, int k,
@@ -383,10 +401,13 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   rc = wcx_timer_begin(ctx, "null_ratios");
   if (rc) return rc;
   if (prepared) {          // ranked ahead on the auxiliary stream (wcx_null_rank_prepare_dev)
+    rc = wcx_aux_kick(ctx);
+    if (rc) return rc;
     base = reinterpret_cast<char *>(ctx->d_rank);
     WCX_HIP(hipStreamWaitEvent(st, ctx->ev_rank, 0));
     ctx->rank_X = nullptr;
   } else {
+    ctx->rank_pending = false;
     void *scr = nullptr;
     rc = wcx_scratch(ctx, L.total, &scr);
     if (rc) return rc;

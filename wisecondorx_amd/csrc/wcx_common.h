@@ -62,6 +62,7 @@ struct wcx_ctx {
   const double *rank_X = nullptr;
   int64_t rank_B = 0;
   std::vector<int32_t> rank_ids;
+  bool rank_pending = false;   // ranking requested, not yet started (wcx_aux_kick)
   // PCA stage (wcx_pca_begin .. wcx_pca_end): t | X | mean | components | dist_to_med
   void *d_pca = nullptr;
   size_t pca_bytes = 0;
@@ -105,6 +106,7 @@ int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
 constexpr int WCX_REDO_GRID = 64;   // workgroups of the device-driven exact redo
 constexpr int WCX_REDO_FAST = 128;  // flagged rows that take the device-wide redo path
 size_t wcx_topk_redo_scratch_bytes(int k, int64_t B);
+int wcx_aux_kick(wcx_ctx *ctx);   // null_ratios.hip: start pending auxiliary-stream work
 int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                                const TopkBlock *d_blocks, const unsigned int *d_count, void *scratch,
                                int64_t row_begin, int k, int32_t *d_out_idx, double *d_out_dist);
