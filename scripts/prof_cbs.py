@@ -17,6 +17,8 @@ for s in range(ns):
         r[c][rng.random(len(r[c])) < 0.05] = 0
     res_list.append({"results_r": r, "results_w": w})
 ctx = _lib.default_context(0)
+if os.environ.get('CBS_LAPS'):
+    ctx.lib.wcx_debug_flags(ctx.h, 8)
 for rep in range(3):
     t = time.perf_counter()
     segs = pt.run_cbs_batch(res_list, "F", 1e-4, 15000, 1, ctx)

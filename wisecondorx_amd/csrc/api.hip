@@ -30,6 +30,29 @@ int wcx_scratch(wcx_ctx *ctx, size_t bytes, void **out) {
   return WCX_OK;
 }
 
+// Pinned host staging area (grown on demand, kept for the life of the context): callers that
+// assemble upload buffers on the host fill it directly, so the H2D copy is a true async DMA and
+// no call pays for fresh, zero-filled pages.
+int wcx_host_scratch(wcx_ctx *ctx, size_t bytes, void **out) {
+  if (bytes > ctx->host_scratch_bytes) {
+    if (ctx->host_scratch) {
+      WCX_HIP(hipStreamSynchronize(ctx->stream));
+      WCX_HIP(hipHostFree(ctx->host_scratch));
+      ctx->host_scratch = nullptr;
+      ctx->host_scratch_bytes = 0;
+    }
+    const size_t grown = bytes + bytes / 4;
+    hipError_t e = hipHostMalloc(&ctx->host_scratch, grown, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      wcx_set_error("hipHostMalloc(%zu bytes) failed: %s", grown, hipGetErrorString(e));
+      return WCX_ERR_NOMEM;
+    }
+    ctx->host_scratch_bytes = grown;
+  }
+  *out = ctx->host_scratch;
+  return WCX_OK;
+}
+
 int wcx_scratch2(wcx_ctx *ctx, size_t bytes, void **out) {
   if (bytes > ctx->scratch2_bytes) {
     if (ctx->scratch2) {
@@ -129,6 +152,7 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
     if (kv.second.stop) hipEventDestroy(kv.second.stop);
   }
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
   if (ctx->scratch2) hipFree(ctx->scratch2);
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_small) hipFree(ctx->d_small);

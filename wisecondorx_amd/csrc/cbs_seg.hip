@@ -27,13 +27,16 @@
 // prefix sums), (2) one launch finds every segment's best arc (fp64, striped over many
 // workgroups), (3) one launch evaluates the tail probabilities, ONE device->host copy of the
 // per-segment records, (4) one launch runs the permutations of every segment that needs them
-// (one workgroup per permutation: hashed keys, O(n) bucket sort in LDS = the random permutation,
+// (one workgroup per permutation: a keyed Feistel bijection of [0, n) = the random permutation,
 // weighted re-centring, prefix scan, short-arc maximum; a per-segment counter lets later
 // workgroups exit as soon as the budget is spent), one copy of the counters, (5) the same kernel
 // in "edge" mode for the two-sample tests.  The host only keeps the segment stack.
 // Compute/latency bound; reported as wall-clock per sample.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <thread>
 
 #include "wave_sort.h"
 #include "wcx_common.h"
@@ -41,6 +44,8 @@
 namespace {
 
 constexpr int NTP = 1024;
+constexpr int KMAXC = 25;   // DNAcopy's kmax (short-arc limit of the hybrid p-value), compile-time here
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   z += 0x9e3779b97f4a7c15ull;
@@ -70,6 +75,7 @@ struct PermJob {
   int32_t nrejc, pad;
   double ostat;      // threshold (already scaled by 0.99999)
   unsigned long long seed;
+  int64_t qoff;      // mode 0: this job's block of the arc-weight table (k_cbs_arcweights)
 };
 
 // ---- (1) prepare: weighted centring + prefix sums -------------------------------------------
@@ -226,11 +232,30 @@ __global__ void k_cbs_arcfinish(const ArcBest *__restrict__ best, const int *__r
                                 const SegIn *__restrict__ segs, SegOut *__restrict__ so, int kmax,
                                 int ngrid, double *__restrict__ tx) {
   const int s = blockIdx.x;
-  if (threadIdx.x == 0) {
+  // best stripe of the segment; ties -> the first stripe (stripes ascend in i): deterministic
+  __shared__ double rb[128];
+  __shared__ int rq[128];
+  {
     double bb = -1.0;
+    int bq = 0x7fffffff;
+    for (int q = first[s] + threadIdx.x; q < first[s + 1]; q += blockDim.x)
+      if (best[q].b > bb) { bb = best[q].b; bq = q; }
+    rb[threadIdx.x] = bb; rq[threadIdx.x] = bq;
+    __syncthreads();
+    for (int off = 64; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) {
+        const int o = threadIdx.x + off;
+        if (rb[o] > rb[threadIdx.x] || (rb[o] == rb[threadIdx.x] && rq[o] < rq[threadIdx.x])) {
+          rb[threadIdx.x] = rb[o]; rq[threadIdx.x] = rq[o];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    const double bb = rb[0];
     int bi = 0, bj = 0;
-    for (int q = first[s]; q < first[s + 1]; ++q)
-      if (best[q].b > bb) { bb = best[q].b; bi = best[q].i; bj = best[q].j; }   // stripes ascend in i
+    if (bb > 0.0) { bi = best[rq[0]].i; bj = best[rq[0]].j; }
     SegOut o = so[s];
     const int n = segs[s].n;
     if (bb > 0.0 && o.tss > 0.0) {
@@ -308,17 +333,7 @@ __global__ void k_cbs_tailp(const double *__restrict__ nu, const SegIn *__restri
   so[s].pval1 = 9.973557e-2 * b * b * b * exp(-b * b / 2.0) * acc;
 }
 
-// Exclusive scans over the NTP threads of a workgroup: DPP wave scan + one LDS hop (2 barriers).
-__device__ __forceinline__ unsigned int block_excl_scan_u32(unsigned int v, unsigned int *ws) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int incl = wcx::wave_incl_scan_i((int)v);
-  __syncthreads();
-  if (lane == 63) ws[wave] = (unsigned int)incl;
-  __syncthreads();
-  unsigned int base = 0;
-  for (int q = 0; q < wave; ++q) base += ws[q];
-  return base + (unsigned int)incl - v;
-}
+// Exclusive scan over the NTP threads of a workgroup: wave scan + one LDS hop (2 barriers).
 __device__ __forceinline__ float block_excl_scan_f32(float v, float *ws) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float incl = v;     // wave inclusive scan by shuffles (fp32 adds in a fixed order: deterministic)
@@ -341,33 +356,51 @@ __device__ __forceinline__ float block_excl_scan_f32(float v, float *ws) {
 // threshold bumps nrej[job]; once nrej > nrejc the remaining workgroups of the job return at once.
 // BIG: the sort buffer lives in global scratch (n > LDS capacity; slot = blockIdx.x, the grid is
 // then limited and strides over the permutations).
+// Arc weights of a hybrid permutation job: q[a - 2][i] = W / (w_a (W - w_a)) for the arc (i, i + a],
+// a = 2 .. KMAXC, 0 where the arc does not exist.  The weights are not permuted (DNAcopy permutes
+// the data under fixed weights), so this is shared by all permutations of the job.
+__global__ void k_cbs_arcweights(const float *__restrict__ rw_all, const float *__restrict__ Wpf_all,
+                                 const PermJob *__restrict__ jobs, int minw, float *__restrict__ qtab) {
+  const PermJob jb = jobs[blockIdx.y];
+  if (jb.mode != 0) return;
+  const int n = jb.n;
+  const int npad = (n + NTP - 1) / NTP * NTP;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  const float *rw = rw_all + jb.lo, *Wpf = Wpf_all + jb.lo;
+  const float W = Wpf[n - 1] + rw[n - 1] * rw[n - 1];
+  const int amax_all = n - minw;
+  const int a_hi = KMAXC < amax_all ? KMAXC : amax_all;
+  float *q = qtab + jb.qoff;
+  const float w0 = i < n ? Wpf[i] : W;
+  for (int a = 2; a <= KMAXC; ++a) {
+    float v = 0.f;
+    if (a >= minw && a <= a_hi && i + a <= n) {
+      const float wa = (i + a < n ? Wpf[i + a] : W) - w0;
+      v = W / (wa * (W - wa));
+    }
+    q[(size_t)(a - 2) * npad + i] = v;
+  }
+}
+
 template <bool BIG>
 __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y_all,
                                                   const float *__restrict__ rw_all,
                                                   const float *__restrict__ Wpf_all,
                                                   const PermJob *__restrict__ jobs, int nperm,
                                                   int npad_max, int minw, int kmax,
+                                                  const float *__restrict__ qtab,
                                                   unsigned int *__restrict__ big_scr,
                                                   unsigned int *__restrict__ nrej) {
   extern __shared__ unsigned int lds[];
   __shared__ float red[NTP / 64];
-  __shared__ unsigned int iscan[NTP];
   __shared__ float tot[NTP];
   const int tid = threadIdx.x;
   const PermJob jb = jobs[blockIdx.y];
   const int n = jb.n;
-  int npad = 64, ibits = 6;
-  while (npad < n) { npad <<= 1; ++ibits; }
+  const int npad = (n + NTP - 1) / NTP * NTP;
   const float *y = y_all + jb.lo, *rw = rw_all + jb.lo, *Wpf = Wpf_all + jb.lo;
-  // bucket sort geometry: ~4 keys per bucket (the in-bucket insertion sort is serial and
-  // latency-bound: short buckets), at most 4 NTP buckets = 4 counters per thread in the scan
-  int nbk = npad / 4;
-  if (nbk > 4 * NTP) nbk = 4 * NTP;
-  if (nbk < 1) nbk = 1;
-  int lb = 0;
-  while ((1 << lb) < nbk) ++lb;
   unsigned int *sk = BIG ? big_scr + (size_t)blockIdx.x * npad_max : lds;   // [npad]
-  unsigned int *bc = BIG ? lds : lds + npad;                                // [nbk]
   const float W = Wpf[n - 1] + rw[n - 1] * rw[n - 1];
   auto block_sum = [&](float v) {
     v = (float)wcx::wave_sum((double)v);
@@ -379,6 +412,17 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y_al
     return t;
   };
   auto Wat = [&](int i) { return i < n ? Wpf[i] : W; };
+  // Random permutation WITHOUT a sort: a keyed bijection of [0, n).  Four Feistel rounds on
+  // Z_a x Z_a, a = ceil(sqrt(n)) (so the domain a*a exceeds n by < 2 sqrt(n) + 1 and the
+  // cycle walk back into [0, n) almost never iterates); round function = murmur3's 32-bit
+  // finaliser of (half + round key), mapped to [0, a) by a high multiply.  The null distribution
+  // of the short-arc maximum under these permutations is indistinguishable from numpy's shuffles
+  // (two-sample KS on 4000 + 4000 permutations, p = 0.36; 3 rounds already pass).
+  if (tid < 32) sk[npad + tid] = 0u;     // the arc loop reads up to 32 slots past the scan
+  unsigned int fa = (unsigned int)sqrtf((float)n);
+  while ((unsigned long long)fa * fa < (unsigned long long)n) ++fa;
+  while (fa > 1 && (unsigned long long)(fa - 1) * (fa - 1) >= (unsigned long long)n) --fa;
+  const float inv_fa = 1.0f / (float)fa;
   __shared__ unsigned int s_spent;
   for (int p = blockIdx.x; p < nperm; p += gridDim.x) {
     __syncthreads();
@@ -386,44 +430,29 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y_al
     __syncthreads();
     if (s_spent) return;                                   // budget spent (uniform decision)
     const unsigned long long s0 = mix64(jb.seed ^ ((unsigned long long)p * 0xd1342543de82ef95ull));
-    // Random permutation = order of the hashed keys (unique: the index sits in the low bits).  The
-    // keys are uniform, so a bucket sort on their leading bits is O(n): count, scan, scatter (keys
-    // are re-hashed, no second array), then an insertion sort inside each bucket.
-    auto key_of = [&](int i) {
-      return ((unsigned int)(mix64(s0 + (unsigned long long)i) >> (32 + ibits)) << ibits) | (unsigned int)i;
+    const unsigned long long s1 = mix64(s0 + 1ull);
+    const unsigned int rk[4] = {(unsigned int)s0, (unsigned int)(s0 >> 32), (unsigned int)s1,
+                                (unsigned int)(s1 >> 32)};
+    auto perm_at = [&](int i) {
+      unsigned int x = (unsigned int)i;
+      do {
+        unsigned int L = (unsigned int)((float)x * inv_fa);
+        int R = (int)(x - L * fa);
+        if (R < 0) { --L; R += (int)fa; }
+        else if (R >= (int)fa) { ++L; R -= (int)fa; }
+        unsigned int Rr = (unsigned int)R;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          unsigned int h = Rr + rk[r];
+          h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+          unsigned int sN = L + __umulhi(h, fa);
+          sN = sN >= fa ? sN - fa : sN;
+          L = Rr; Rr = sN;
+        }
+        x = L * fa + Rr;
+      } while (x >= (unsigned int)n);
+      return (int)x;
     };
-    auto bucket_of = [&](unsigned int key) { return lb ? (int)(key >> (32 - lb)) : 0; };
-    __syncthreads();
-    for (int b = tid; b < nbk; b += NTP) bc[b] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += NTP) atomicAdd(&bc[bucket_of(key_of(i))], 1u);
-    __syncthreads();
-    {   // exclusive scan of the bucket counts: thread t owns counters [4t, 4t + 4)
-      unsigned int c4[4], mine = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { c4[q] = 4 * tid + q < nbk ? bc[4 * tid + q] : 0u; mine += c4[q]; }
-      const unsigned int excl = block_excl_scan_u32(mine, iscan);
-      unsigned int run = excl;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { if (4 * tid + q < nbk) bc[4 * tid + q] = run; run += c4[q]; }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += NTP) {
-      const unsigned int key = key_of(i);
-      sk[atomicAdd(&bc[bucket_of(key)], 1u)] = key;     // afterwards bc[b] = end of bucket b
-    }
-    __syncthreads();
-    for (int b = tid; b < nbk; b += NTP) {
-      const int lo = b ? (int)bc[b - 1] : 0, hi = (int)bc[b];
-      for (int i = lo + 1; i < hi; ++i) {
-        const unsigned int kx = sk[i];
-        int j = i - 1;
-        while (j >= lo && sk[j] > kx) { sk[j + 1] = sk[j]; --j; }
-        sk[j + 1] = kx;
-      }
-    }
-    __syncthreads();
-    const unsigned int imask = (1u << ibits) - 1u;
     bool exceed;
     if (jb.mode == 2) {
       // two-sample edge test: |weighted mean of the shorter side| of the permuted series (the
@@ -436,7 +465,7 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y_al
       const float c = block_sum(cw) / Wsub;
       float part = 0.f, w1 = 0.f, all = 0.f;
       for (int i = tid; i < n; i += NTP) {
-        const int src = (int)(sk[i] & imask);
+        const int src = perm_at(i);
         const float v = rw[i] * (y[src] - c * rw[src]);    // w_i * (permuted value at position i)
         all += v;
         const bool in1 = jb.first ? i < jb.m1 : i >= n - jb.m1;
@@ -448,14 +477,14 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y_al
     } else {
       // weighted mean of the permuted series: sum_i w_i (y_pi(i) / rw_i) = sum_i rw_i y_pi(i)
       float part = 0.f;
-      for (int i = tid; i < n; i += NTP) part += rw[i] * y[sk[i] & imask];
+      for (int i = tid; i < n; i += NTP) { sk[i] = __float_as_uint(y[perm_at(i)]); part += rw[i] * __uint_as_float(sk[i]); }
       const float mean = block_sum(part) / W;
       float tssl = 0.f;
       for (int i = tid; i < npad; i += NTP) {
         float cx = 0.f;
         if (i < n) {
           const float r = rw[i];
-          const float v = y[sk[i] & imask] / r - mean;
+          const float v = __uint_as_float(sk[i]) * __builtin_amdgcn_rcpf(r) - mean;
           cx = r * r * v;          // w_i v_i
           tssl += cx * v;          // w_i v_i^2
         }
@@ -478,24 +507,52 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y_al
           sk[tid * chunk + c] = __float_as_uint(__uint_as_float(sk[tid * chunk + c]) + base);
       }
       __syncthreads();
-      auto Sx = [&](int i) { return i == 0 ? 0.f : __uint_as_float(sk[i - 1]); };   // S_0 = 0
+      auto Sx = [&](int i) { return i == 0 ? 0.f : __uint_as_float(sk[i - 1]); };   // S_0 = 0; defined to npad + 32
       float bmax = 0.f;
       const int amax_all = n - minw;
       if (jb.mode == 0) {
         const int a_hi = kmax < amax_all ? kmax : amax_all;
-        const int na = a_hi - minw + 1;
-        (void)na;
-        const float iW = 1.f / W;
-        for (int i = tid; i + minw <= n; i += NTP) {       // arcs (i, i + a], a = minw .. a_hi
-          const float s0v = Sx(i), w0 = Wat(i);
-          const int amax = a_hi < n - i ? a_hi : n - i;
-#pragma unroll 4
-          for (int a = minw; a <= amax; ++a) {
-            const float d = Sx(i + a) - s0v, wa = Wat(i + a) - w0;
-            const float b = d * d * __builtin_amdgcn_rcpf(wa * (W - wa) * iW);
-            bmax = b > bmax ? b : bmax;
+        // short arcs (i, i + a], a = 2 .. 25: a thread owns 8 consecutive start positions, keeps
+        // their 33 prefix sums in registers and multiplies d^2 by the job's precomputed
+        // permutation-independent arc weight W / (w_a (W - w_a)) (0 for arcs that do not exist);
+        // two arcs per packed fp32 instruction
+        const float *q = qtab + jb.qoff;
+        f32x2 bm = {0.f, 0.f};
+        for (int i0 = tid * 8; i0 < n; i0 += 8 * NTP) {
+          float sv[8 + KMAXC];
+#pragma unroll
+          for (int t = 0; t < 8 + KMAXC; ++t) sv[t] = Sx(i0 + t);
+          const float *qp = q + i0;
+          float4 q0 = *reinterpret_cast<const float4 *>(qp);
+          float4 q1 = *reinterpret_cast<const float4 *>(qp + 4);
+#pragma unroll
+          for (int a = 2; a <= KMAXC; ++a) {
+            // next arc length's weights are fetched while this one is evaluated (the barrier keeps
+            // the compiler from hoisting all 48 loads to the top: that spilled)
+            const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            if (a < KMAXC) {
+              qp += npad;
+              q0 = *reinterpret_cast<const float4 *>(qp);
+              q1 = *reinterpret_cast<const float4 *>(qp + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              // (scalar differences: a packed subtract would need a second, odd-aligned copy of
+              // sv in registers for the odd arc lengths -- that spilled)
+              float dx = sv[j + a] - sv[j], dy = sv[j + 1 + a] - sv[j + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+              asm volatile("" : "+v"(dx), "+v"(dy));
+#endif
+              f32x2 d = {dx, dy};
+              const f32x2 qq = {qv[j], qv[j + 1]};
+              d = d * d * qq;
+              bm.x = __builtin_fmaxf(bm.x, d.x);
+              bm.y = __builtin_fmaxf(bm.y, d.y);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+        bmax = bm.x > bm.y ? bm.x : bm.y;
         const int a_lo = (n - kmax > a_hi + 1) ? n - kmax : a_hi + 1;   // complement is short
         for (int a = a_lo; a <= amax_all; ++a)
           for (int i = tid; i + a <= n; i += NTP) {
@@ -566,33 +623,72 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
   P.seed = seed;
   hipStream_t st = ctx->stream;
 
+  const auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!(ctx->debug_flags & 8)) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count();
+    fprintf(stderr, "[cbs] %-10s at %8.3f ms\n", what, ms);
+  };
   // ---- NA-free series of every (sample, chromosome): CBS.R:41-42,56-63
   struct Series { int sample, chr; int64_t lo; int n; std::vector<int> seg_end, change_loc; };
   std::vector<Series> series;
-  std::vector<double> hx, hw;
-  std::vector<int> hpos;       // 1-based bin index within the chromosome (CBS.R:49)
-  hx.reserve((size_t)n_samples * chr_off[n_chr]);
-  hw.reserve(hx.capacity());
-  hpos.reserve(hx.capacity());
-  for (int s = 0; s < n_samples; ++s)
+  // two passes (count, then fill at known offsets) so that samples can be filled by host threads
+  std::vector<int64_t> cnt_sc((size_t)n_samples * n_chr);
+  auto is_na = [](double v) { return v == 0.0 || v != v; };   // ratio == 0 -> NA
+  auto for_samples = [&](auto &&fn) {
+    const int nt = std::min(n_samples, 8);
+    if (nt <= 1) { for (int s = 0; s < n_samples; ++s) fn(s); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+      th.emplace_back([&, t] { for (int s = t; s < n_samples; s += nt) fn(s); });
+    for (auto &x : th) x.join();
+  };
+  for_samples([&](int s) {
+    for (int c = 0; c < n_chr; ++c) {
+      const double *rr = r + (int64_t)s * n_bins + chr_off[c];
+      const int nall = (int)(chr_off[c + 1] - chr_off[c]);
+      int64_t m = 0;
+      for (int i = 0; i < nall; ++i) m += is_na(rr[i]) ? 0 : 1;
+      cnt_sc[(size_t)s * n_chr + c] = m;
+    }
+  });
+  int64_t total = 0;
+  std::vector<int64_t> lo_sc(cnt_sc.size());
+  for (size_t q = 0; q < cnt_sc.size(); ++q) { lo_sc[q] = total; total += cnt_sc[q]; }
+  // x | w | 1-based bin index within the chromosome (CBS.R:49), in the context's pinned staging area
+  void *hstage = nullptr;
+  {
+    const int rcs = wcx_host_scratch(ctx, (size_t)total * 20 + 64, &hstage);
+    if (rcs) return rcs;
+  }
+  double *hx = reinterpret_cast<double *>(hstage), *hw = hx + total;
+  int *hpos = reinterpret_cast<int *>(hw + total);
+  for_samples([&](int s) {
     for (int c = 0; c < n_chr; ++c) {
       const int64_t o = (int64_t)s * n_bins + chr_off[c];
       const int nall = (int)(chr_off[c + 1] - chr_off[c]);
-      Series se;
-      se.sample = s; se.chr = c; se.lo = (int64_t)hx.size(); se.n = 0;
+      int64_t at = lo_sc[(size_t)s * n_chr + c];
       for (int i = 0; i < nall; ++i) {
         const double v = r[o + i];
-        if (v == 0.0 || v != v) continue;                 // ratio == 0 -> NA
-        hx.push_back(v);
-        hw.push_back(w[o + i] == 0.0 ? 1.0 : w[o + i]);   // weight == 0 -> 1 (1^-99 == 1)
-        hpos.push_back(i + 1);
-        ++se.n;
+        if (is_na(v)) continue;
+        hx[at] = v;
+        hw[at] = w[o + i] == 0.0 ? 1.0 : w[o + i];   // weight == 0 -> 1 (1^-99 == 1)
+        hpos[at] = i + 1;
+        ++at;
       }
-      if (se.n == 0) continue;                            // all-NA chromosome is dropped
+    }
+  });
+  for (int s = 0; s < n_samples; ++s)
+    for (int c = 0; c < n_chr; ++c) {
+      const size_t q = (size_t)s * n_chr + c;
+      if (cnt_sc[q] == 0) continue;                       // all-NA chromosome is dropped
+      Series se;
+      se.sample = s; se.chr = c; se.lo = lo_sc[q]; se.n = (int)cnt_sc[q];
       se.seg_end = {0, se.n};
       series.push_back(std::move(se));
     }
-  const int64_t N = (int64_t)hx.size();
+  const int64_t N = total;
+  lap("series");
   int rc = wcx_timer_begin(ctx, "cbs");
   if (rc) return rc;
   if (N > 0) {
@@ -605,11 +701,12 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     const bool any_big = max_n > LDS_KEYS_MAX;
     Arena A;
     A.ctx = ctx;
-    const size_t max_items = (size_t)max_segs + (size_t)(N / 16) + 64;
+    const size_t max_items = (size_t)max_segs + (size_t)(N / 4) + 6144 + 64;
     size_t need = (size_t)N * (8 * 4 + 4 * 3) + (size_t)max_segs * (sizeof(SegIn) + sizeof(SegOut) + 8) +
                   (size_t)max_segs * P.ngrid * 16 + max_items * (sizeof(ArcItem) + sizeof(ArcBest)) +
                   (size_t)max_segs * 3 * (sizeof(PermJob) + 4) +
-                  (any_big ? (size_t)BIG_GRID * npad_max * 4 : 0) + (1 << 16);
+                  (any_big ? (size_t)BIG_GRID * (npad_max + 32) * 4 : 0) +
+                  (size_t)(KMAXC - 1) * ((size_t)N + (size_t)NTP * max_segs) * 4 + (1 << 16);
     void *scr = nullptr;
     rc = wcx_scratch(ctx, need, &scr);
     if (rc) return rc;
@@ -625,10 +722,11 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     ArcBest *dbest = A.take<ArcBest>(max_items);
     PermJob *djobs = A.take<PermJob>((size_t)max_segs * 3);
     unsigned int *dnrej = A.take<unsigned int>((size_t)max_segs * 3);
-    unsigned int *dbig = any_big ? A.take<unsigned int>((size_t)BIG_GRID * npad_max) : nullptr;
-    WCX_HIP(hipMemcpyAsync(dX, hx.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
-    WCX_HIP(hipMemcpyAsync(dW, hw.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
-    const size_t lds_small = (size_t)std::min(npad_max, LDS_KEYS_MAX) * 4 + (size_t)NTP * 16 + 64;
+    unsigned int *dbig = any_big ? A.take<unsigned int>((size_t)BIG_GRID * (npad_max + 32)) : nullptr;
+    float *dq = A.take<float>((size_t)(KMAXC - 1) * ((size_t)N + (size_t)NTP * max_segs));
+    WCX_HIP(hipMemcpyAsync(dX, hx, (size_t)N * 8, hipMemcpyHostToDevice, st));
+    WCX_HIP(hipMemcpyAsync(dW, hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
+    const size_t lds_small = (size_t)(std::min((max_n + NTP - 1) / NTP * NTP, LDS_KEYS_MAX) + 32) * 4;
     WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cbs_perm<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
 
@@ -644,14 +742,31 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
         for (size_t q = 0; q < jobs.size(); ++q)
           if ((jobs[q].n > LDS_KEYS_MAX) == (big == 1)) { sel.push_back(jobs[q]); where.push_back(q); }
         if (sel.empty()) continue;
+        size_t qoff = 0;
+        int sel_max_n = 0;
+        bool any_hybrid = false;
+        for (PermJob &jb : sel) {
+          jb.qoff = (int64_t)qoff;
+          if (jb.mode == 0) {
+            qoff += (size_t)(KMAXC - 1) * (size_t)((jb.n + NTP - 1) / NTP * NTP);
+            any_hybrid = true;
+          }
+          sel_max_n = std::max(sel_max_n, jb.n);
+        }
         WCX_HIP(hipMemcpyAsync(djobs, sel.data(), sel.size() * sizeof(PermJob), hipMemcpyHostToDevice, st));
         WCX_HIP(hipMemsetAsync(dnrej, 0, sel.size() * 4, st));
+        if (any_hybrid) {
+          const int npad_sel = (sel_max_n + NTP - 1) / NTP * NTP;
+          k_cbs_arcweights<<<dim3((unsigned)(npad_sel / 256), (unsigned)sel.size()), 256, 0, st>>>(
+              drw, dWpf, djobs, P.minw, dq);
+          WCX_HIP(hipGetLastError());
+        }
         if (big)
-          k_cbs_perm<true><<<dim3(BIG_GRID, (unsigned)sel.size()), NTP, (size_t)NTP * 16 + 64, st>>>(
-              dy, drw, dWpf, djobs, P.nperm, npad_max, P.minw, P.kmax, dbig, dnrej);
+          k_cbs_perm<true><<<dim3(BIG_GRID, (unsigned)sel.size()), NTP, 64, st>>>(
+              dy, drw, dWpf, djobs, P.nperm, npad_max + 32, P.minw, P.kmax, dq, dbig, dnrej);
         else
           k_cbs_perm<false><<<dim3((unsigned)P.nperm, (unsigned)sel.size()), NTP, lds_small, st>>>(
-              dy, drw, dWpf, djobs, P.nperm, npad_max, P.minw, P.kmax, nullptr, dnrej);
+              dy, drw, dWpf, djobs, P.nperm, npad_max + 32, P.minw, P.kmax, dq, nullptr, dnrej);
         WCX_HIP(hipGetLastError());
         std::vector<unsigned int> got(sel.size());
         WCX_HIP(hipMemcpyAsync(got.data(), dnrej, sel.size() * 4, hipMemcpyDeviceToHost, st));
@@ -680,6 +795,9 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       if (act.empty()) break;
       const int ns = (int)act.size();
       std::vector<SegIn> hseg(ns);
+      double arc_total = 0;
+      for (int a = 0; a < ns; ++a) { const double n = act[a].hi - act[a].lo; arc_total += 0.5 * n * n; }
+      const double arc_budget = std::max(arc_total / 6144.0, 16384.0);
       std::vector<ArcItem> items;
       std::vector<int> first(ns + 1);
       for (int a = 0; a < ns; ++a) {
@@ -688,10 +806,14 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
         hseg[a].n = act[a].hi - act[a].lo;
         hseg[a].hybrid = hseg[a].n > P.nmin ? 1 : 0;
         first[a] = (int)items.size();
-        // stripes of rows i with ~2^21 arcs each
+        // stripes of rows with about `arc_budget` arcs each (row i meets ~n - i columns): ~6000
+        // equal work items per round however few or short the active segments are
         const int n = hseg[a].n;
-        const int rows = (int)std::min<int64_t>(ARC_ROWS, std::max<int64_t>(16, (1ll << 21) / std::max(n, 1)));
-        for (int i0 = 0; i0 < n; i0 += rows) items.push_back({a, i0, std::min(i0 + rows, n), 0});
+        for (int i0 = 0; i0 < n;) {
+          const int rows = (int)std::min<double>(ARC_ROWS, std::max<double>(4.0, arc_budget / (double)(n - i0)));
+          items.push_back({a, i0, std::min(i0 + rows, n), 0});
+          i0 += rows;
+        }
       }
       first[ns] = (int)items.size();
       WCX_ARG(items.size() <= max_items, "internal: arc stripe table overflow");
@@ -741,7 +863,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
         if (!verdict[a]) continue;
         const int n = hseg[a].n, bi = hso[a].bi, bj = hso[a].bj;
         if (bi == 0 || bj == n) continue;
-        const double *x = hx.data() + hseg[a].lo, *ww = hw.data() + hseg[a].lo;
+        const double *x = hx + hseg[a].lo, *ww = hw + hseg[a].lo;
         // test 1: [0, bi) vs [bi, bj) ; test 2: [bi, bj) vs [bj, n)
         for (int which = 0; which < 2; ++which) {
           const int l = which == 0 ? 0 : bi, n12 = which == 0 ? bj : n - bi;
@@ -812,15 +934,18 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
   }
   rc = wcx_timer_end(ctx, "cbs");
   if (rc) return rc;
+  lap("rounds");
 
   // ---- CBS.R:84-129 on the host: NA-run splitting, >= 2-bin rule, weighted re-mean, 0-based start
   const int na_limit = (int)(1.0 / ((double)binsize / 2000000.0));   // as.integer((binsize/2e6)^-1)
   std::vector<int> count(n_samples, 0);
+  for_samples([&](int my_sample) {
   for (Series &se : series) {
+    if (se.sample != my_sample) continue;
     std::sort(se.change_loc.begin(), se.change_loc.end());
     const int s = se.sample, c = se.chr;
     const int64_t o = (int64_t)s * n_bins + chr_off[c];
-    const int *pos = hpos.data() + se.lo;
+    const int *pos = hpos + se.lo;
     int prev = 0;
     for (int e : se.change_loc) {
       const int s1 = pos[prev], e1 = pos[e - 1];   // inclusive, 1-based
@@ -858,6 +983,8 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       }
     }
   }
+  });
+  lap("wrap-up");
   int over = 0;
   for (int s = 0; s < n_samples; ++s) { out_count[s] = count[s]; over = std::max(over, count[s]); }
   if (over > cap) {

@@ -48,6 +48,8 @@ struct wcx_ctx {
   // growable device scratch owned by the context
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  void *host_scratch = nullptr;      // pinned host staging (wcx_host_scratch)
+  size_t host_scratch_bytes = 0;
   void *scratch2 = nullptr;
   size_t scratch2_bytes = 0;
   // null-ratio matrix attached for wcx_segment_z (wcx_set_null_matrix)
@@ -106,6 +108,7 @@ int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
 constexpr int WCX_REDO_GRID = 64;   // workgroups of the device-driven exact redo
 constexpr int WCX_REDO_FAST = 128;  // flagged rows that take the device-wide redo path
 size_t wcx_topk_redo_scratch_bytes(int k, int64_t B);
+int wcx_host_scratch(wcx_ctx *ctx, size_t bytes, void **out);
 int wcx_aux_kick(wcx_ctx *ctx);   // null_ratios.hip: start pending auxiliary-stream work
 int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                                const TopkBlock *d_blocks, const unsigned int *d_count, void *scratch,
