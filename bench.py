@@ -207,6 +207,7 @@ class Workload:
                  "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
                  "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": self.fb_rows,
                  "compactions": stats["compactions"], "appends": stats["appends"],
+                 "refined_pairs": stats["refined"],
                  "attainable_note": "the dense-f16 peak is not attainable on random data: a bare "
                                     "LDS-fed MFMA loop is power-limited to 1.27-1.48 PFLOP/s on this "
                                     "chip (profiles/r02/ubench_mfma.txt)"}

@@ -280,3 +280,39 @@ def test_ref_qc_matches_reference(g_pipe):
                                                rtol=1e-12)
     assert sorted(set(codes.values())) == [0, 1, 2]          # PASS, WARN and FAIL all reached
     assert ref_qc.qc_reference(os.path.join(GOLDEN, "no_such_file.npz")) == 2
+
+
+def test_post_process_fused_equals_the_step_by_step_path():
+    """post_process_fused == get_post_processed_result x3 + log_trans (the reference's sequence,
+    predict_control.py:49-63 + predict_tools.py:180-193), incl. zero / negative / inf / nan ratios,
+    ratio == 1 (log2 = 0: not shifted) and bins below minrefbins; its per-chromosome arrays are
+    views that _flatten returns without a copy."""
+    from types import SimpleNamespace
+    from wisecondorx_amd import predict_tools as pt
+    rng = np.random.default_rng(5)
+    bpc = [40, 25, 31, 17]
+    nb = sum(bpc)
+    mask = rng.random(nb) > 0.2
+    B = int(mask.sum())
+    r = np.exp(rng.normal(0, 0.1, B))
+    r[[0, 3, 5, 7, 9, 11]] = [0.0, -1.0, np.inf, np.nan, 1.0, 1e-300]
+    z = rng.normal(0, 1, B)
+    z[2] = np.nan
+    w = rng.uniform(0.5, 2, B)
+    n = rng.integers(100, 300, B).astype(float)
+    args = SimpleNamespace(minrefbins=150)
+    rem = {"mask": mask, "bins_per_chr": bpc}
+    ref = {"results_r": r, "results_z": z, "results_w": w}
+    for key in ref:
+        ref[key] = pt.get_post_processed_result(args, ref[key], n, rem)
+    pt.log_trans(ref, 0.0123)
+    got = pt.post_process_fused(args, r, z, w, n, 0.0123, rem)
+    for key in ref:
+        assert len(got[key]) == len(bpc)
+        for c in range(len(bpc)):
+            np.testing.assert_array_equal(got[key][c], ref[key][c])
+        flat = pt._flatten(got, key)
+        assert flat.base is got[key][0].base or flat is got[key][0].base    # no copy
+        np.testing.assert_array_equal(flat, np.concatenate(ref[key]))
+        np.testing.assert_array_equal(pt._flatten(got, key, 2), np.concatenate(ref[key][:2]))
+        np.testing.assert_array_equal(pt._flatten(ref, key), np.concatenate(ref[key]))

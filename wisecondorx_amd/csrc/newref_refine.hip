@@ -149,7 +149,8 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
                                                const int *__restrict__ perm, int k,
                                                int32_t *__restrict__ out_idx,
                                                double *__restrict__ out_dist,
-                                               ScreenGlobals *__restrict__ glob) {
+                                               ScreenGlobals *__restrict__ glob,
+                                               unsigned long long *__restrict__ stats) {
   extern __shared__ __align__(16) unsigned char rsm[];
   const int wave = threadIdx.x >> 6;
   const size_t per_wave = (size_t)(64 * RPITCH + Sp) * 8 + 64 * 4;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
       continue;
     }
     const int n = cnt_out[r] & 0x3fffffff;
+    if (wcx::lane_id() == 0) atomicAdd(&stats[5], (unsigned long long)n);   // pairs re-evaluated exactly
     if (n > 512) continue;     // k_refine_big
     const int64_t row = row_begin + r;
     int64_t cs = 0, ce = chr.cum[0];
@@ -251,7 +253,7 @@ int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTa
   WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_refine),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
   k_refine<<<gref, NT, rlds, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out,
-                                         flags, perm, k, d_out_idx, d_out_dist, glob);
+                                         flags, perm, k, d_out_idx, d_out_dist, glob, ctx->d_stats);
   const unsigned gbig = (unsigned)(n_rows < 2048 ? n_rows : 2048);
   k_refine_big<<<gbig, NT, 0, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl,
                                              cnt_out, flags, perm, k, d_out_idx, d_out_dist);

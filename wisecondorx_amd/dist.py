@@ -251,10 +251,7 @@ def predict_one_dev(backend, idx, dist, nr, d_x, B, k, chr_cum, rem_input, pt):
         lib.wcx_ref_free(ctx.h, h)
     z, r, n = zrn[0], zrn[1], zrn[2]
     with np.errstate(all="ignore"):
-        results = {"results_r": r, "results_z": z - m_z, "results_w": w / np.nanmean(w)}
-    for key in results:
-        results[key] = pt.get_post_processed_result(args, results[key], n, rem_input)
-    pt.log_trans(results, m_lr)
+        results = pt.post_process_fused(args, r, z - m_z, w / np.nanmean(w), n, m_lr, rem_input)
     pt.attach_null_matrix_dev(nr, rem_input["mask"], ctx)
     results["results_nr"] = pt.ATTACHED
     return pt.exec_cbs(rem_input, results, ctx)

@@ -182,6 +182,35 @@ def log_trans(results, log_r_median):
         results["results_r"][c], results["results_z"][c], results["results_w"][c] = r, z, w
 
 
+def post_process_fused(args, r, z, w, ref_sizes, log_r_median, rem_input):
+    """get_post_processed_result x3 + log_trans (predict_control.py:49-63, predict_tools.py:163-193)
+    in one vectorised pass over the masked vectors: same values, but the per-chromosome arrays are
+    views of three contiguous vectors (so run_cbs / get_z_score need no concatenation).
+    r, z, w, ref_sizes: masked-length vectors (z already shifted by m_z, w already scaled)."""
+    mask = np.asarray(rem_input["mask"], dtype=bool)
+    idx = rem_input.get("_mask_idx")
+    if idx is None or len(idx) != len(r):
+        idx = np.flatnonzero(mask)
+        rem_input["_mask_idx"] = idx
+    keep = np.asarray(ref_sizes) >= args.minrefbins
+    with np.errstate(all="ignore"):
+        lr = np.log2(np.where(keep, r, 0.0))
+    good = np.isfinite(lr)                       # log2 of 0 / negative / inf / nan ratios -> bin zeroed
+    lr = np.where(good, lr, 0.0)
+    nz = lr != 0
+    lr[nz] -= log_r_median
+    good &= keep
+    off = np.concatenate(([0], np.cumsum(rem_input["bins_per_chr"]))).astype(int)
+    n_chr = len(rem_input["bins_per_chr"])
+    results = {}
+    for key, vec in (("results_r", lr), ("results_z", np.where(good, z, 0.0)),
+                     ("results_w", np.where(good, w, 0.0))):
+        full = np.zeros(len(mask))
+        full[idx] = vec
+        results[key] = [full[off[c]:off[c + 1]] for c in range(n_chr)]
+    return results
+
+
 _BED_CHR = {"X": 23, "Y": 24}
 
 
@@ -212,9 +241,27 @@ def apply_blacklist(rem_input, results):
             results[key][c][lo:hi] = 0
 
 
-def _flatten(results, key):
-    return np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=float)
-                                                for c in results[key]]))
+def _flatten(results, key, n_chr=None):
+    """Per-chromosome arrays -> one contiguous float64 vector.  When the pieces already are
+    consecutive views of one contiguous array (post_process_fused builds them that way) that array
+    is returned as is: no copy."""
+    parts = results[key][:n_chr] if n_chr is not None else results[key]
+    base = getattr(parts[0], "base", None) if len(parts) else None
+    if (isinstance(base, np.ndarray) and base.ndim == 1 and base.dtype == np.float64
+            and base.flags.c_contiguous):
+        base_addr = base.__array_interface__["data"][0]
+        addr = parts[0].__array_interface__["data"][0]
+        total = 0
+        for part in parts:
+            if (not isinstance(part, np.ndarray) or part.base is not base or part.dtype != np.float64
+                    or part.ndim != 1 or part.strides != (8,)
+                    or part.__array_interface__["data"][0] != addr + 8 * total):
+                break
+            total += len(part)
+        else:
+            start = (addr - base_addr) // 8
+            return base[start:start + total]
+    return np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=float) for c in parts]))
 
 
 def _chr_offsets(results):
@@ -292,10 +339,8 @@ def run_cbs(results, ref_gender, alpha, binsize, seed, ctx=None):
     ctx = ctx or _lib.default_context()
     n_chr = 24 if ref_gender == "M" else 23            # CBS.R:30-34
     n_chr = min(n_chr, len(results["results_r"]))
-    r = np.ascontiguousarray(np.concatenate(
-        [np.asarray(results["results_r"][c], dtype=float) for c in range(n_chr)]))
-    w = np.ascontiguousarray(np.concatenate(
-        [np.asarray(results["results_w"][c], dtype=float) for c in range(n_chr)]))
+    r = _flatten(results, "results_r", n_chr)
+    w = _flatten(results, "results_w", n_chr)
     n = [len(results["results_r"][c]) for c in range(n_chr)]
     off, off_p = _lib.i64_array(np.concatenate(([0], np.cumsum(n))))
     cap = 4096
@@ -331,8 +376,8 @@ def run_cbs_batch(results_list, ref_gender, alpha, binsize, seed, ctx=None):
     r = np.empty((ns, n_bins))
     w = np.empty((ns, n_bins))
     for i, res in enumerate(results_list):
-        r[i] = np.concatenate([np.asarray(res["results_r"][c], dtype=float) for c in range(n_chr)])
-        w[i] = np.concatenate([np.asarray(res["results_w"][c], dtype=float) for c in range(n_chr)])
+        r[i] = _flatten(res, "results_r", n_chr)
+        w[i] = _flatten(res, "results_w", n_chr)
     cap = 4096
     seg = np.empty((ns, cap, 4))
     cnt = np.zeros(ns, dtype=np.int32)
