@@ -655,8 +655,15 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_prep");
   if (rc) return rc;
-  rc = wcx_aux_kick(ctx);   // pending null-sample ranking: beside the MFMA-bound sweep
-  if (rc) return rc;
+  // pending null-sample ranking (auxiliary stream): 0 = start beside the sweep, 1 = beside the
+  // refine.  Measured (15 kb, S = 500 / 100): the step takes the same time either way (73.2 / 73.1 ms;
+  // serial: 73.6), but beside the sweep the sort's HBM streaming costs the power-limited MFMA loop
+  // 6 % (33.4 vs 31.6 ms), beside the refine it costs the refine 2 ms -- so it goes there.
+  const int kick_at = env_int("WCX_RANK_KICK", 1);
+  if (kick_at == 0) {
+    rc = wcx_aux_kick(ctx);
+    if (rc) return rc;
+  }
   rc = wcx_timer_begin(ctx, "topk_screen");
   if (rc) return rc;
 
@@ -725,6 +732,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_screen");
   if (rc) return rc;
+  if (kick_at == 1) {
+    rc = wcx_aux_kick(ctx);
+    if (rc) return rc;
+  }
   rc = wcx_timer_begin(ctx, "topk_refine");
   if (rc) return rc;
   rc = wcx_refine_launch(ctx, Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out, flags, perm,

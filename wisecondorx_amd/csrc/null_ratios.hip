@@ -348,16 +348,15 @@ int wcx_null_rank_prepare_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   ctx->rank_ids.assign(sample_ids, sample_ids + n_ids);
   ctx->rank_X = dXs;
   ctx->rank_B = B;
-  ctx->rank_pending = true;   // started by wcx_aux_kick: behind the search's prep, beside its screen
+  ctx->rank_pending = true;   // started by wcx_aux_kick (inside the search)
   return WCX_OK;
 }
 
 }  // extern "C"
 
 // Starts the pending ranking on the auxiliary stream, behind the main stream's current position.
-// The search calls this once its (HBM-bound) prep kernels are enqueued, so that the (HBM-bound)
-// radix sort runs beside the MFMA-bound screen instead of beside the prep; wcx_null_ratios_dev
-// calls it as a catch-all.
+// The search calls this between its sweep and its refine (see wcx_topk_screen_launch for the
+// measurements behind that choice); wcx_null_ratios_dev calls it as a catch-all.
 int wcx_aux_kick(wcx_ctx *ctx) {
   if (!ctx->rank_pending) return WCX_OK;
   ctx->rank_pending = false;
