@@ -45,7 +45,7 @@ def screen_source_sha():
     return h.hexdigest()[:16]
 
 
-def make_workload(binsize, n_samples, seed=0):
+def make_workload(binsize, n_samples, seed=0, device=0):
     """Synthetic cohort -> masked, depth-normalised, PCA-corrected X (host, untimed)."""
     from wisecondorx_amd import prep
     from wisecondorx_amd.synth import Cohort
@@ -53,7 +53,9 @@ def make_workload(binsize, n_samples, seed=0):
     samples, genders = co.cohort(n_samples, seed0=100 + seed)
     mask, bpc = prep.get_mask(samples)
     from wisecondorx_amd import _lib
-    p = prep.prepare(samples, "A", mask, bpc, ctx=_lib.default_context(0))   # PCA stage on the GPU
+    # PCA stage on THIS rank's GPU (the library selects its context's device on every call, and
+    # torch follows the runtime's current device: a rank must never touch another rank's device)
+    p = prep.prepare(samples, "A", mask, bpc, ctx=_lib.default_context(device))
     test = co.sample(777 + seed, "F", cnv=[(3, 100, 100 + max(4, int(4e7 // binsize)), 1.5)])
     return co, p, test
 
@@ -116,7 +118,7 @@ class Workload:
         from wisecondorx_amd.newref_tools import _get_part
         self.torch, self.wd, self.pt = torch, wd, predict_tools
         self.rank, self.world, self.args = rank, world, args
-        co, p, test = make_workload(args.binsize, n_samples)
+        co, p, test = make_workload(args.binsize, n_samples, device=dev_index)
         self.p = p
         X = p["X"]                                   # (B, S) Fortran order
         self.Xs_host = np.ascontiguousarray(X.T)     # [S][B]
