@@ -63,3 +63,22 @@ def test_search_fuzz(seed):
             want = O.null_ratios(X, oi, s, e, ids)
         got = nt.get_null_ratios(X, idx, s, e, ids)
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13, equal_nan=True)
+
+
+def test_search_fuzz_sampled_prepass(monkeypatch):
+    """The sampled threshold pre-pass (normally only for B >= 32768) forced onto the small fuzz
+    shapes with deliberately unsafe sample ranks: estimates fail for some rows, which must be
+    flagged by the final cut and redone exactly on the device -- results stay bit-identical."""
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd import newref_tools as nt
+    flagged = 0
+    for seed, (sf, r) in zip(range(24), [(4, 10), (4, 40), (8, 25), (16, 12), (2, 60), (4, 3)] * 4):
+        monkeypatch.setenv("WCX_SCREEN_SAMPLE", str(sf))
+        monkeypatch.setenv("WCX_SCREEN_CUT_R", str(r))
+        X, cum, k, s, e = _case(seed)
+        oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, s, e, k)
+        idx, dist = nt.get_ref_for_rows(X, cum, k, s, e, mode=2)
+        flagged += _lib.default_context().topk_stats()["fallback_rows"]
+        assert np.array_equal(idx, oi), "indices differ (seed {}, SF {}, r {})".format(seed, sf, r)
+        assert np.array_equal(dist, od), "distances differ (seed {}, SF {}, r {})".format(seed, sf, r)
+    assert flagged > 0, "the forced pre-pass never produced a flagged row: path not exercised"
