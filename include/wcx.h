@@ -209,6 +209,9 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
 int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples, int64_t n_bins,
                   const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
                   double *out_seg, int cap, int *out_count);
+/* Diagnostics of the CBS calls on this context since its creation: out[0] = hybrid tests decided
+ * by the short-arc bound (their permutations were not run), out[1..3] reserved. */
+int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]);
 /* Replaces overall_tools.get_z_score (overall_tools.py:88-119).  nr double[n_bins][m]
  * (rows of masked bins ignored; pad ragged rows with NaN), seg as produced by wcx_cbs;
  * out_z double[n_seg] (NaN where undefined), out_nnull double[n_seg] (may be NULL) = number of

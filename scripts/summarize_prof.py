@@ -20,6 +20,25 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
 DST = os.path.join(ROOT, "profiles", "r02")
 
 
+def short_name(full):
+    """`void (anonymous namespace)::k_foo<5>(args...)` -> `k_foo<5>`; library kernels keep the tail of
+    their qualified name."""
+    n = full.replace("(anonymous namespace)::", "")
+    if n.startswith("void "):
+        n = n[5:]
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):                      # argument list = first '(' outside <...>
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    n = n[:cut].strip()
+    return n if len(n) <= 70 else "..." + n[-67:]
+
+
 def main():
     sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 2      # warmup 1 + steps 1
     import bench
@@ -38,7 +57,7 @@ def main():
             for f in glob.glob(os.path.join(SRC, "pmc%d_S%d" % (n, S), "**", "p_counter_collection.csv"),
                                recursive=True):
                 for r in csv.DictReader(open(f)):
-                    name = r["Kernel_Name"].split("(")[0][-60:]
+                    name = short_name(r["Kernel_Name"])
                     if "k_screen<" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]:
                         name = "k_screen"
                     agg[name][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -132,3 +132,37 @@ def test_cbs_long_chromosomes(pt, n_big):
     assert abs(c0[3][0] - (n_big - 900)) <= 3 and c0[3][1] == n_big and abs(c0[3][2] + 0.35) < 0.03
     assert len([1 for c, s, e, r in segs if c == 1]) == 1 and len([1 for c, s, e, r in segs if c == 2]) == 1
     assert pt.run_cbs(res, "F", 1e-4, 5000, 3) == segs  # deterministic in the seed
+
+
+def test_cbs_short_arc_bound_is_an_exact_shortcut(pt):
+    """Hybrid tests whose observed statistic exceeds what ANY permutation can reach with a short arc
+    are decided without running their permutations (short_arc_bound in cbs_seg.hip).  The
+    segmentation must be identical with the shortcut disabled (debug flag 32), and the shortcut
+    must actually fire on long aberrations while weak ones still go through the permutations."""
+    from wisecondorx_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(11)
+    n_per_chr = [3000, 2500, 2000, 1500] + [400] * 19
+    cases = []
+    for trial in range(4):
+        res = _noise_results(rng, n_per_chr, sd=0.08)
+        res["results_r"][0][500:1700] += 0.58            # long, strong: bound shortcut
+        res["results_r"][1][300:330] += 0.25             # short, moderate: permutations decide
+        res["results_r"][2][1000:1400] -= 0.1            # long, weak
+        res["results_r"][3 + trial][50:60] += 0.35
+        for c in range(23):
+            res["results_r"][c][rng.random(n_per_chr[c]) < 0.03] = 0
+        cases.append(res)
+    before = ctx.cbs_stats()["bound_shortcuts"]
+    with_shortcut = [pt.run_cbs(res, "F", 1e-4, 100000, 3, ctx) for res in cases]
+    fired = ctx.cbs_stats()["bound_shortcuts"] - before
+    ctx.lib.wcx_debug_flags(ctx.h, 32)
+    try:
+        without = [pt.run_cbs(res, "F", 1e-4, 100000, 3, ctx) for res in cases]
+        assert ctx.cbs_stats()["bound_shortcuts"] - before == fired     # none while disabled
+    finally:
+        ctx.lib.wcx_debug_flags(ctx.h, 0)
+    assert with_shortcut == without
+    assert fired >= 4
+    segs0 = sorted(s for s in with_shortcut[0] if s[0] == 0)
+    assert len(segs0) == 3 and abs(segs0[1][1] - 500) <= 2 and abs(segs0[1][2] - 1700) <= 2

@@ -64,6 +64,7 @@ SIGNATURES = {
     "wcx_nanmedian2_dev": (C.c_int, [vp, vp, vp, c_i64, vp, vp]),
     "wcx_cbs": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64, vp,
                           C.c_int, C.POINTER(C.c_int)]),
+    "wcx_cbs_stats": (C.c_int, [vp, c_i64p]),
     "wcx_cbs_batch": (C.c_int, [vp, vp, vp, C.c_int, c_i64, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64,
                                 vp, C.c_int, vp]),
     "wcx_set_null_matrix": (C.c_int, [vp, vp, c_i64, C.c_int]),
@@ -164,6 +165,11 @@ class Context:
 
     def kernel_ms(self, name):
         return float(self.lib.wcx_last_kernel_ms(self.h, name.encode()))
+
+    def cbs_stats(self):
+        out = (C.c_int64 * 4)()
+        check(self.lib.wcx_cbs_stats(self.h, out))
+        return {"bound_shortcuts": out[0]}
 
     def topk_stats(self):
         out = (C.c_int64 * 16)()

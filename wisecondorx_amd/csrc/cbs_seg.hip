@@ -36,6 +36,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <functional>
+#include <vector>
 #include <thread>
 
 #include "wave_sort.h"
@@ -583,6 +585,50 @@ __global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y_al
   }
 }
 
+// Upper bound of the permutation statistic of the hybrid test (the maximum over arcs of at most
+// kmax points, or whose complement has at most kmax points) over ALL permutations of the series,
+// from O(n) sums and the kmax largest |y|.  With y_j = r_j (x_j - mean), r_j = sqrt(w_j), a
+// permutation pi puts y_pi(i) at position i (weights stay): part = sum r_i y_pi(i),
+// tss' = sum y^2 - part^2 / W, arc sum d = sum_arc r_i y_pi(i) - (part / W) w_arc.
+//   |part| <= sqrt(sum (r_i - rbar)^2 sum y^2) + rbar |sum y|                      (Cauchy-Schwarz)
+//   |d|    <= r_max Y_a + |part| a w_max / W,   Y_a = the a largest |y|
+//   w_arc (W - w_arc) >= min over the end points of [a w_min, a w_max]             (concave)
+// A strongly significant segment (a long aberration) has an observed statistic far above this
+// bound; its 10 000 permutations cannot produce a single exceedance and are not run.
+static double short_arc_bound(const double *x, const double *w, int n, int minw, int kmax) {
+  double W = 0, sx = 0;
+  for (int i = 0; i < n; ++i) { W += w[i]; sx += w[i] * x[i]; }
+  const double mean = sx / W;
+  double sy = 0, syy = 0, sr = 0, wmin = w[0], wmax = w[0];
+  std::vector<double> ay((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const double r = sqrt(w[i]), y = r * (x[i] - mean);
+    sy += y; syy += y * y; sr += r;
+    wmin = std::min(wmin, w[i]); wmax = std::max(wmax, w[i]);
+    ay[(size_t)i] = fabs(y);
+  }
+  const double rbar = sr / n;
+  double srr = 0;
+  for (int i = 0; i < n; ++i) { const double e = sqrt(w[i]) - rbar; srr += e * e; }
+  const double part = sqrt(srr * syy) + rbar * fabs(sy);
+  const double tss_min = syy - part * part / W;
+  const int a_hi = std::min(kmax, n - minw);
+  if (a_hi < minw || !(tss_min > 0)) return HUGE_VAL;
+  std::partial_sort(ay.begin(), ay.begin() + a_hi, ay.end(), std::greater<double>());
+  const double rmax = sqrt(wmax);
+  double Y = 0, bmax = 0;
+  for (int a = 1; a <= a_hi; ++a) {
+    Y += ay[(size_t)a - 1];
+    if (a < minw) continue;
+    if (a * wmax >= W) return HUGE_VAL;
+    const double d = rmax * Y + part * a * wmax / W;
+    const double den = std::min(a * wmin * (W - a * wmin), a * wmax * (W - a * wmax)) / W;
+    bmax = std::max(bmax, d * d / den);
+  }
+  if (!(tss_min > bmax)) return HUGE_VAL;
+  return bmax / ((tss_min - bmax) / (n - 2.0));
+}
+
 // ------------------------------------------------------------------ host side
 struct CbsParams {
   double alpha;
@@ -834,6 +880,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       std::vector<PermJob> jobs;
       std::vector<int> job_of(ns, -1);
       std::vector<int> verdict(ns, 0);     // 0 = no change, 1 = significant
+      int n_shortcut = 0;
       for (int a = 0; a < ns; ++a) {
         if (!hso[a].valid) continue;
         double pval2 = P.alpha;
@@ -846,6 +893,14 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
         jb.m1 = 0; jb.first = 0; jb.pad = 0;
         jb.nrejc = (int)(pval2 * P.nperm);
         jb.ostat = 0.99999 * hso[a].ostat;
+        if (jb.mode == 0 && !(ctx->debug_flags & 32) &&
+            short_arc_bound(hx + jb.lo, hw + jb.lo, jb.n, P.minw, P.kmax) * 1.05 < jb.ostat) {
+          // no permutation of this series can reach the observed statistic with an arc of <= kmax
+          // points: the exceedance count is 0 without running the nperm permutations
+          verdict[a] = 1;
+          ++n_shortcut;
+          continue;
+        }
         jb.seed = P.seed ^ ((++test_id) * 0x2545f4914f6cdd1dull);
         job_of[a] = (int)jobs.size();
         jobs.push_back(jb);
@@ -854,6 +909,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       if (rc) return rc;
       for (int a = 0; a < ns; ++a)
         if (job_of[a] >= 0) verdict[a] = hnrej[job_of[a]] <= (unsigned int)jobs[job_of[a]].nrejc ? 1 : 0;
+      ctx->cbs_shortcuts += n_shortcut;
 
       // interior arcs: each of the two change-points needs its own two-sample test
       std::vector<PermJob> ejobs;
@@ -991,6 +1047,12 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     wcx_set_error("wcx_cbs: %d segments exceed the caller's capacity %d", over, cap);
     return WCX_ERR_ARG;
   }
+  return WCX_OK;
+}
+
+int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]) {
+  WCX_ARG(ctx && out, "NULL argument");
+  out[0] = ctx->cbs_shortcuts; out[1] = out[2] = out[3] = 0;
   return WCX_OK;
 }
 
