@@ -158,6 +158,7 @@ int wcx_ref_free(wcx_ctx *ctx, wcx_ref *ref);
 int wcx_cutoff(wcx_ctx *ctx, const wcx_ref *ref, int repeats, double *cutoff);
 /* Replaces predict_tools.get_weights (predict_tools.py:152-155): out[B]. */
 int wcx_weights(wcx_ctx *ctx, const wcx_ref *ref, double *out);
+int wcx_weights_dev(wcx_ctx *ctx, const wcx_ref *ref, double *d_out);
 /* Replaces predict_tools.normalize_repeat (predict_tools.py:94-142) for a batch of
  * n_samples projected sample vectors x double[n_samples][B]: three masked passes, rows from
  * `ct` (first row of chromosome index `cp`).  Outputs per sample: z,r,n double[B-ct];
@@ -169,6 +170,17 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref, const double *d_
                               int n_samples, double cutoff, int64_t ct, int cp,
                               double *d_out_z, double *d_out_r, double *d_out_n,
                               double *d_out_mlr, double *d_out_mz);
+
+/* Replaces, for the device-resident outputs of wcx_predict_normalize_dev of ONE sample without a
+ * gonosomal pass, main.py:246-250 (z - m_z, w / nanmean(w)), predict_control.get_post_processed_result
+ * for r, z, w (predict_control.py:49-63: bins with fewer than minrefbins reference bins -> 0, inflate
+ * to the unmasked length) and predict_tools.log_trans (predict_tools.py:180-193).  d_pos int32[B] =
+ * position of masked bin i in the unmasked vector.  out_r (log2 ratios), out_z, out_w: HOST
+ * double[n_bins] (pinned memory makes the copies asynchronous DMA); synchronises the stream. */
+int wcx_post_process_dev(wcx_ctx *ctx, const double *d_z, const double *d_r, const double *d_n,
+                         const double *d_w, int64_t B, const double *d_m_lr, const double *d_m_z,
+                         double minrefbins, const int32_t *d_pos, int64_t n_bins, double *out_r,
+                         double *out_z, double *out_w);
 
 /* ---- row-sharded predict (multi-GPU) --------------------------------------
  * A handle made by wcx_ref_wrap_rows_dev holds only rows [row0,row0+nrows) of indexes/distances

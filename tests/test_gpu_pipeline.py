@@ -160,3 +160,52 @@ def test_statistics_file_matches_reference(tmp_path):
         np.testing.assert_allclose([float(v) for v in fa[1:]], [float(v) for v in fb[1:]], rtol=1e-9)
     for suffix in ("_bins.bed", "_segments.bed", "_aberrations.bed", "_regions.bed"):
         assert open(rem["args"].outid + suffix).read() == str(g["file" + suffix.replace(".", "_")])
+
+
+def test_predict_one_dev_equals_the_host_path():
+    """dist.predict_one_dev (what bench.py and the replica predict of a multi-GPU build run: cut-off,
+    weights, three passes, wcx_post_process_dev, CBS, segment z -- nothing but three result vectors
+    leaves the device) against the step-by-step host mirror of predict_control.normalize +
+    get_post_processed_result + log_trans + exec_cbs on the same reference."""
+    import torch
+    import bench
+    from wisecondorx_amd import _lib, dist as wd, predict_tools as pt
+    co, p, test = bench.make_workload(100000, 40)
+    X = p["X"]
+    cum = np.asarray(p["masked_bins_per_chr_cum"], dtype=np.int64)
+    B, S, k = int(cum[-1]), X.shape[1], 100
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx)
+    Xrow = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+    ids = np.arange(S, dtype=np.int32)
+    idx, dist, nr, _ = wd.newref_sharded(Xrow, B, cum, k, ids, be, 0, 1)
+    x = pt.project_pc(pt.coverage_normalize_and_mask(test, p, ""), p, "")
+    d_x = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    args = argparse.Namespace(minrefbins=30, alpha=1e-4, seed=3, maskrepeats=5)
+    rem = {"args": args, "mask": p["mask"], "bins_per_chr": p["bins_per_chr"], "binsize": 100000,
+           "ref_gender": "F"}
+    rows = wd.predict_one_dev(be, idx, dist, nr, d_x, B, k, cum, rem, pt)
+    rows_again = wd.predict_one_dev(be, idx, dist, nr, d_x, B, k, cum, rem, pt)   # cached buffers
+    assert rows == rows_again
+
+    ref = dict(p)
+    ref.update({"indexes": idx.cpu().numpy(), "distances": dist.cpu().numpy(),
+                "null_ratios": nr.cpu().numpy()})
+    cache = {}
+    cutoff = pt.get_optimal_cutoff(ref, 5, cache)
+    w = pt.get_weights(ref, "", cache)
+    z, r, n, mlr, mz = pt.normalize_repeat(x, ref, cutoff, 0, 0, "", cache)
+    res = {"results_r": r, "results_z": z - mz, "results_w": w / np.nanmean(w)}
+    for key in res:
+        res[key] = pt.get_post_processed_result(args, res[key], n, rem)
+    pt.log_trans(res, mlr)
+    off = np.concatenate(([0], np.cumsum(p["bins_per_chr"]))).astype(int)
+    nr_full = pt.inflate_results(ref["null_ratios"], rem)
+    res["results_nr"] = [nr_full[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+    want = pt.exec_cbs(rem, res, _lib.default_context(0))
+    assert len(rows) == len(want) and len(rows) >= 23
+    for a, b in zip(rows, want):
+        assert a[:3] == b[:3]
+        np.testing.assert_allclose([float(a[3]), a[4]], [float(b[3]), b[4]], rtol=1e-9, atol=1e-9)
+    assert any(abs(s[4] - np.log2(1.5)) < 0.1 for s in rows)          # the planted gain is called

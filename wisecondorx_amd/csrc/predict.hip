@@ -528,6 +528,53 @@ int wcx_nanmedian_rows_launch(wcx_ctx *ctx, const double *d_a, int64_t n, int64_
   return WCX_OK;
 }
 
+namespace {
+
+// mean of the non-NaN entries (np.nanmean) of w[0..n), one workgroup
+__global__ __launch_bounds__(1024) void k_nanmean1(const double *__restrict__ w, int64_t n,
+                                                   double *__restrict__ out) {
+  __shared__ double ss[16];
+  __shared__ double sc[16];
+  double s = 0.0, c = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double v = w[i];
+    if (v == v) { s += v; c += 1.0; }
+  }
+  s = wcx::wave_sum(s);
+  c = wcx::wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < 16; ++q) { a += ss[q]; b += sc[q]; }
+    out[0] = a / b;
+  }
+}
+
+// get_post_processed_result x3 + log_trans (predict_control.py:49-63, predict_tools.py:163-193)
+// for the autosomal results of one sample, on the masked vectors; full = r | z | w over the
+// unmasked bins (pre-zeroed: masked-out bins stay 0).  z is shifted by m_z and w scaled by its
+// nanmean first (main.py:246-250 for a sample without gonosomal pass).
+__global__ __launch_bounds__(256) void k_post_process(
+    const double *__restrict__ z, const double *__restrict__ r, const double *__restrict__ nref,
+    const double *__restrict__ w, int64_t B, const double *__restrict__ m_lr,
+    const double *__restrict__ m_z, const double *__restrict__ wmean, double minrefbins,
+    const int32_t *__restrict__ pos, int64_t n_bins, double *__restrict__ full) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  const bool keep = nref[i] >= minrefbins;
+  double lr = log2(keep ? r[i] : 0.0);
+  const bool good = (lr - lr == 0.0);                      // finite
+  lr = good ? lr : 0.0;
+  if (lr != 0.0) lr -= m_lr[0];
+  const int64_t p = pos[i];
+  full[p] = lr;
+  full[n_bins + p] = good ? z[i] - m_z[0] : 0.0;
+  full[2 * n_bins + p] = good ? w[i] / wmean[0] : 0.0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int wcx_ref_wrap_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, int64_t B, int k,
@@ -608,6 +655,43 @@ int wcx_cutoff(wcx_ctx *ctx, const wcx_ref *ref, int repeats, double *cutoff) {
   if (rc) return rc;
   WCX_HIP(hipMemcpyAsync(cutoff, state, 8, hipMemcpyDeviceToHost, ctx->stream));
   WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return WCX_OK;
+}
+
+int wcx_weights_dev(wcx_ctx *ctx, const wcx_ref *ref, double *d_out) {
+  WCX_ARG(ctx && ref && d_out, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  int rc = wcx_timer_begin(ctx, "weights");
+  if (rc) return rc;
+  const unsigned grid = (unsigned)((ref->nrows + 3) / 4 < 8192 ? (ref->nrows + 3) / 4 + 1 : 8192);
+  k_weights<<<grid, NT, 0, ctx->stream>>>(ref->d_dist, ref->nrows, ref->k, d_out);
+  WCX_HIP(hipGetLastError());
+  return wcx_timer_end(ctx, "weights");
+}
+
+int wcx_post_process_dev(wcx_ctx *ctx, const double *d_z, const double *d_r, const double *d_n,
+                         const double *d_w, int64_t B, const double *d_m_lr, const double *d_m_z,
+                         double minrefbins, const int32_t *d_pos, int64_t n_bins, double *out_r,
+                         double *out_z, double *out_w) {
+  WCX_ARG(ctx && d_z && d_r && d_n && d_w && d_m_lr && d_m_z && d_pos && out_r && out_z && out_w,
+          "NULL argument");
+  WCX_ARG(B > 0 && n_bins >= B, "bad sizes");
+  WCX_HIP(hipSetDevice(ctx->device));
+  void *scr = nullptr;
+  int rc = wcx_scratch2(ctx, (size_t)n_bins * 24 + 256, &scr);
+  if (rc) return rc;
+  double *full = reinterpret_cast<double *>(scr);           // r | z | w, each n_bins
+  double *d_wmean = full + 3 * n_bins;
+  hipStream_t st = ctx->stream;
+  WCX_HIP(hipMemsetAsync(full, 0, (size_t)n_bins * 24, st));
+  k_nanmean1<<<1, 1024, 0, st>>>(d_w, B, d_wmean);
+  k_post_process<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(d_z, d_r, d_n, d_w, B, d_m_lr, d_m_z,
+                                                             d_wmean, minrefbins, d_pos, n_bins, full);
+  WCX_HIP(hipGetLastError());
+  WCX_HIP(hipMemcpyAsync(out_r, full, (size_t)n_bins * 8, hipMemcpyDeviceToHost, st));
+  WCX_HIP(hipMemcpyAsync(out_z, full + n_bins, (size_t)n_bins * 8, hipMemcpyDeviceToHost, st));
+  WCX_HIP(hipMemcpyAsync(out_w, full + 2 * n_bins, (size_t)n_bins * 8, hipMemcpyDeviceToHost, st));
+  WCX_HIP(hipStreamSynchronize(st));
   return WCX_OK;
 }
 

@@ -220,38 +220,58 @@ def gather_reference3(idx_local, dist_local, nr_local, n_rows, world, backend=No
 
 def predict_one_dev(backend, idx, dist, nr, d_x, B, k, chr_cum, rem_input, pt):
     """predict of ONE sample against a reference resident on this device (main.py:191-279 for the
-    autosomal pass): cut-off, weights, normalize_repeat on the device tables; post-processing on
-    the host (O(B)); CBS + segment z on the device with the null ratios inflated in place.
-    Returns the reference's result rows [chr, start, end, z, ratio]."""
+    autosomal pass): cut-off, weights, normalize_repeat, post-processing (minrefbins, inflation,
+    log2 transform: wcx_post_process_dev) on the device; the three result vectors come back into
+    pinned host buffers (they are what the tables are written from); CBS + segment z on the device
+    with the null ratios inflated in place.
+    Returns the reference's result rows [chr, start, end, z, ratio].  The per-chromosome arrays of
+    the results live in buffers owned by `backend` and are valid until its next call."""
     import numpy as np
     import torch
     from . import _lib
     ctx = backend.ctx
     lib = ctx.lib
+    dev = d_x.device
     cum, cum_p = _lib.i64_array(chr_cum)
+    args = rem_input["args"]
+    mask = np.asarray(rem_input["mask"], dtype=bool)
+    n_bins = len(mask)
+    cache = getattr(backend, "_predict_bufs", None)
+    if cache is None or cache["key"] != (B, n_bins, id(rem_input["mask"])):
+        cache = {"key": (B, n_bins, id(rem_input["mask"])),
+                 "pos": torch.from_numpy(np.flatnonzero(mask).astype(np.int32)).to(dev),
+                 "host": torch.empty((3, n_bins), dtype=torch.float64).pin_memory(),
+                 "out": torch.empty((4, B), dtype=torch.float64, device=dev),
+                 "med": torch.empty(2, dtype=torch.float64, device=dev)}
+        if cache["pos"].numel() != B:
+            raise ValueError("mask selects {} bins, the reference has {}".format(cache["pos"].numel(), B))
+        backend._predict_bufs = cache
+    out, med, host = cache["out"], cache["med"], cache["host"]
     h = _lib.vp()
     _lib.check(lib.wcx_ref_wrap_dev(ctx.h, idx.data_ptr(), dist.data_ptr(), B, k, cum_p, len(cum),
                                     _lib.C.byref(h)))
     try:
-        args = rem_input["args"]
         cutoff = _lib.C.c_double()
         _lib.check(lib.wcx_cutoff(ctx.h, h, int(args.maskrepeats), _lib.C.byref(cutoff)))
-        w = np.empty(B)
-        _lib.check(lib.wcx_weights(ctx.h, h, _lib.ptr(w)))
-        out = torch.empty((3, B), dtype=torch.float64, device=d_x.device)
-        med = torch.empty(2, dtype=torch.float64, device=d_x.device)
+        _lib.check(lib.wcx_weights_dev(ctx.h, h, out[3].data_ptr()))
         _lib.check(lib.wcx_predict_normalize_dev(ctx.h, h, d_x.data_ptr(), 1, cutoff.value, 0, 0,
                                                  out[0].data_ptr(), out[1].data_ptr(),
                                                  out[2].data_ptr(), med[0:].data_ptr(),
                                                  med[1:].data_ptr()))
-        ctx.sync()
-        zrn = out.cpu().numpy()
-        m_lr, m_z = (float(v) for v in med.cpu())
+        _lib.check(lib.wcx_post_process_dev(ctx.h, out[0].data_ptr(), out[1].data_ptr(),
+                                            out[2].data_ptr(), out[3].data_ptr(), B,
+                                            med[0:].data_ptr(), med[1:].data_ptr(),
+                                            float(args.minrefbins), cache["pos"].data_ptr(), n_bins,
+                                            host[0].data_ptr(), host[1].data_ptr(),
+                                            host[2].data_ptr()))
     finally:
         lib.wcx_ref_free(ctx.h, h)
-    z, r, n = zrn[0], zrn[1], zrn[2]
-    with np.errstate(all="ignore"):
-        results = pt.post_process_fused(args, r, z - m_z, w / np.nanmean(w), n, m_lr, rem_input)
+    off = np.concatenate(([0], np.cumsum(rem_input["bins_per_chr"]))).astype(int)
+    n_chr = len(rem_input["bins_per_chr"])
+    results = {}
+    for row, key in enumerate(("results_r", "results_z", "results_w")):
+        full = host[row].numpy()
+        results[key] = [full[off[c]:off[c + 1]] for c in range(n_chr)]
     pt.attach_null_matrix_dev(nr, rem_input["mask"], ctx)
     results["results_nr"] = pt.ATTACHED
     return pt.exec_cbs(rem_input, results, ctx)
