@@ -659,7 +659,9 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // refine.  Measured (15 kb, S = 500 / 100): the step takes the same time either way (73.2 / 73.1 ms;
   // serial: 73.6), but beside the sweep the sort's HBM streaming costs the power-limited MFMA loop
   // 6 % (33.4 vs 31.6 ms), beside the refine it costs the refine 2 ms -- so it goes there.
-  const int kick_at = env_int("WCX_RANK_KICK", 1);
+  // (a short refine -- few samples -- cannot hide the 2.4 ms sort: S = 100 is 0.8 ms faster with
+  // the sort beside the sweep)
+  const int kick_at = env_int("WCX_RANK_KICK", S >= 256 ? 1 : 0);
   if (kick_at == 0) {
     rc = wcx_aux_kick(ctx);
     if (rc) return rc;
