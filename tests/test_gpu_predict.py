@@ -151,3 +151,45 @@ def test_row_sharded_primitives_equal_batched_path(pt):
     assert np.array_equal(nB.cpu().numpy(), on)
     be.free_ref(h0)
     be.free_ref(h1)
+
+
+def test_post_process_dev_matches_host_post_processing():
+    """wcx_post_process_dev + wcx_weights_dev against get_post_processed_result x3 + log_trans on
+    the host (predict_control.py:49-63, predict_tools.py:180-193): zero / negative / inf / nan
+    ratios, ratio == 1, bins below minrefbins, NaN z and NaN weights."""
+    import argparse
+    import torch
+    from wisecondorx_amd import _lib, predict_tools as pt
+    rng = np.random.default_rng(21)
+    n_bins = 5000
+    mask = rng.random(n_bins) > 0.15
+    B = int(mask.sum())
+    r = np.exp(rng.normal(0, 0.1, B))
+    r[[0, 3, 5, 7, 9, 11]] = [0.0, -1.0, np.inf, np.nan, 1.0, 1e-300]
+    z = rng.normal(0, 1, B)
+    z[2] = np.nan
+    w = rng.uniform(0.5, 2, B)
+    w[4] = np.nan
+    n = rng.integers(100, 300, B).astype(float)
+    m_lr, m_z = 0.0123, -0.2
+    args = argparse.Namespace(minrefbins=150)
+    bpc = [1200, 800, 3000]
+    rem = {"mask": mask, "bins_per_chr": bpc}
+    want = {"results_r": r, "results_z": z - m_z, "results_w": w / np.nanmean(w)}
+    for key in want:
+        want[key] = pt.get_post_processed_result(args, want[key], n, rem)
+    pt.log_trans(want, m_lr)
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(a).to(dev) for a in (z, r, n, w)]
+    med = torch.tensor([m_lr, m_z], dtype=torch.float64, device=dev)
+    pos = torch.from_numpy(np.flatnonzero(mask).astype(np.int32)).to(dev)
+    host = torch.empty((3, n_bins), dtype=torch.float64).pin_memory()
+    _lib.check(ctx.lib.wcx_post_process_dev(ctx.h, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                                            d[3].data_ptr(), B, med[0:].data_ptr(), med[1:].data_ptr(),
+                                            150.0, pos.data_ptr(), n_bins, host[0].data_ptr(),
+                                            host[1].data_ptr(), host[2].data_ptr()))
+    got = host.numpy()
+    for row, key in enumerate(("results_r", "results_z", "results_w")):
+        np.testing.assert_allclose(got[row], np.concatenate(want[key]), rtol=1e-12, atol=1e-15,
+                                   equal_nan=True, err_msg=key)
