@@ -69,7 +69,9 @@ __global__ __launch_bounds__(64 * WPB, BOUND) void k(const half8 *F, float *out,
 
 template <int NK, int CTG, int WPB, int STAGE, int BOUND>
 void run(const char *name, const half8 *F, float *out, int wg_per_cu, int n_groups) {
-  const int iters = 2000, grid = 256 * wg_per_cu;
+  const int iters = 2000;
+  int grid = 256 * wg_per_cu;
+  if (const char *e = getenv("UB_GRID")) grid = atoi(e);   // fewer workgroups than slots: power headroom?
   size_t lds = (size_t)(STAGE == 3 ? 3 : 2) * CTG * NK * 1024;
   hipFuncSetAttribute(reinterpret_cast<const void *>(k<NK, CTG, WPB, STAGE, BOUND>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -99,6 +101,7 @@ int main() {
     hipMemcpy(F, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   }
 #define R(NK, CTG, WPB, ST, BD, W) run<NK, CTG, WPB, ST, BD>("NK=" #NK " CTG=" #CTG " WPB=" #WPB " stage=" #ST, F, out, W, (int)(chunk / (CTG * NK * 1024)))
+  if (getenv("UB_GRID")) { R(32, 1, 4, 2, 2, 2); R(7, 2, 4, 3, 3, 3); return 0; }
   R(32, 1, 4, 0, 2, 2); R(32, 1, 4, 1, 2, 2); R(32, 1, 4, 2, 2, 2);
   R(32, 1, 8, 0, 2, 1); R(32, 1, 8, 1, 2, 1); R(32, 1, 8, 2, 2, 1); R(32, 1, 8, 3, 2, 1);
   R(32, 2, 8, 2, 2, 1);
