@@ -63,10 +63,14 @@ def coverage_normalize_and_mask(sample, ref_file, ap):
 def project_pc(sample_data, ref_file, ap):
     """predict_tools.py:56-65 with the scikit-learn<=1.4.2 transform the reference pins
     (setup.cfg:42): x / (((x - mean) . C^T) . C + mean)."""
-    comp = ref_file["pca_components{}".format(ap)]
+    comp = np.asarray(ref_file["pca_components{}".format(ap)])       # (n_comp, B)
     mean = ref_file["pca_mean{}".format(ap)]
-    t = np.dot(np.array([sample_data]) - mean, comp.T)
-    reconstructed = (np.dot(t, comp) + mean)[0]
+    # (skinny products without BLAS: a threaded GEMV on 5 x B operands costs tens of ms in thread
+    # wake-ups; einsum + five axpys take ~1 ms)
+    t = np.einsum("cb,b->c", comp, np.asarray(sample_data) - mean)
+    reconstructed = np.array(mean, dtype=float, copy=True)
+    for c in range(comp.shape[0]):
+        reconstructed += t[c] * comp[c]
     return sample_data / reconstructed
 
 
