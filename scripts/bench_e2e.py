@@ -88,11 +88,17 @@ def main():
     ph.wrap(predict_output, "generate_output_tables", "tables")
     outid = os.path.join(a.workdir, "out")
     t0 = time.perf_counter()
-    cli.main(["--loglevel", "warning", "predict", test_file, ref_file, outid, "--bed",
-                    "--seed", "1"])
+    predict_error = None
+    try:
+        cli.main(["--loglevel", "warning", "predict", test_file, ref_file, outid, "--bed",
+                  "--seed", "1"])
+    except SystemExit as e:     # e.g. a reference whose gonosomal pass dropped autosomal bins
+        predict_error = "predict exited ({})".format(e.code)
     t_predict = time.perf_counter() - t0
-    seg = sum(1 for _ in open(outid + "_segments.bed")) - 1
-    ab = sum(1 for _ in open(outid + "_aberrations.bed")) - 1
+    seg = ab = None
+    if predict_error is None:
+        seg = sum(1 for _ in open(outid + "_segments.bed")) - 1
+        ab = sum(1 for _ in open(outid + "_aberrations.bed")) - 1
     out = {
         "workload": "CLI newref ({} samples, {} bp bins, refsize {}) + predict of 1 sample".format(
             a.samples, a.binsize, a.refsize),
@@ -102,6 +108,8 @@ def main():
         "synth_and_write_samples_s": t_synth,
         "reference_npz_bytes": os.path.getsize(ref_file), "segments": seg, "aberrations": ab,
     }
+    if predict_error:
+        out["predict_error"] = predict_error
     print(json.dumps(out))
     shutil.rmtree(a.workdir, ignore_errors=True)
 

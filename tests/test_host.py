@@ -212,6 +212,33 @@ def test_pca_distance_filter_fires_and_skews_masks():
     assert g["A_mask"][:n_aut].sum() == g["F_mask"][:n_aut].sum() + 1      # the skew
 
 
+def test_frozen_autosomal_mask_in_gonosomal_passes():
+    """The product default (main.build_sub_reference): on the same cohort the F / M passes keep the
+    autosomal part of the mask of the finished A reference -- the one autosomal bin the reference's
+    F pass drops stays, so predict can align autosomal and gonosomal results."""
+    from conftest import GOLDEN, sample_from_counts
+    from wisecondorx_amd import prep
+    from wisecondorx_amd.overall_tools import gender_correct
+    g = np.load(os.path.join(GOLDEN, "prep_filter.npz"), allow_pickle=False)
+    bpc = g["cohort_bpc"]
+    genders = np.array([str(x) for x in g["cohort_genders"]])
+    samples = np.array([gender_correct(sample_from_counts(c, bpc), gd)
+                        for c, gd in zip(g["cohort_counts"], genders)])
+    total_mask, bins_per_chr = prep.get_mask(samples)
+    total_mask = total_mask & prep.get_mask(samples[genders == "F"])[0] \
+        & prep.get_mask(samples[genders == "M"])[0]
+    n_aut = int(np.sum(bins_per_chr[:22]))
+    pa = prep.prepare(samples, "A", total_mask, bins_per_chr)
+    assert np.array_equal(pa["mask"], g["A_mask"])                     # the A pass is unchanged
+    for gender in ("F", "M"):
+        p = prep.prepare(samples[genders == gender], gender, total_mask, bins_per_chr, frozen=n_aut)
+        assert np.array_equal(p["mask"][:n_aut], pa["mask"])
+        assert np.array_equal(p["masked_bins_per_chr"][:22], pa["masked_bins_per_chr"])
+        # whatever the reference's pass removed beyond the autosomes is still removed
+        ref_removed = g[gender + "_removed"]
+        assert not p["mask"][ref_removed[ref_removed >= n_aut]].any()
+
+
 def _tables_case(tmp_path):
     """results / rem_input exactly as the reference's tool_test handed them to its
     generate_output_tables (tests/golden/tables.npz; exec_R stubbed, see make_golden.py)."""

@@ -88,7 +88,14 @@ def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, context
     """One of the A / F / M passes: tool_newref_prep + tool_newref_main + tool_newref_post
     (newref_control.py:24-189) without the temp-file round trips."""
     from . import newref_tools
-    p = prep.prepare(samples, gender, total_mask, bins_per_chr, ctx=contexts[0])   # PCA on the device
+    # PCA on the device.  In the gonosomal passes the autosomal part of the mask is frozen: the
+    # reference lets their PCA-distance filter drop autosomal bins the A reference still holds and
+    # then misaligns the merged result at predict time (see prep.prepare); --reference-mask-skew
+    # restores that behaviour.
+    frozen = 0
+    if gender != "A" and not getattr(args, "reference_mask_skew", False):
+        frozen = int(np.sum(bins_per_chr[:22]))
+    p = prep.prepare(samples, gender, total_mask, bins_per_chr, ctx=contexts[0], frozen=frozen)
     X = p.pop("X")
     cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
     n_parts = len(contexts)
@@ -322,6 +329,9 @@ def build_parser():
                    help="Scale samples to this binsize, multiples of existing binsize only")
     p.add_argument("--cpus", type=int, default=1, help="Accepted for compatibility (ignored)")
     p.add_argument("--gpus", type=int, default=1, help="Number of MI355X devices to split the rows over")
+    p.add_argument("--reference-mask-skew", action="store_true",
+                   help="Let the PCA-distance filter of the gonosomal passes drop autosomal bins, like "
+                        "upstream WisecondorX (such references cannot be aligned at predict time)")
     p.set_defaults(func=tool_newref)
 
     p = sub.add_parser("gender", description="Returns the gender of a .npz resulting from convert",

@@ -120,10 +120,15 @@ def pca_distance_filter(pca_corrected_data):
     return dist_to_med > cutoff, cutoff
 
 
-def prepare(samples, gender, mask, bins_per_chr, ctx=None):
+def prepare(samples, gender, mask, bins_per_chr, ctx=None, frozen=0):
     """The numerical part of newref_control.tool_newref_prep (newref_control.py:24-66).
     NOTE: like the reference, this mutates `mask` IN PLACE when the PCA-distance filter
-    fires (newref_control.py:48-54).  ctx: a device context -> the PCA stage runs on the GPU."""
+    fires (newref_control.py:48-54).  ctx: a device context -> the PCA stage runs on the GPU.
+    frozen > 0: the first `frozen` bins (the autosomes, in a gonosomal pass) keep their mask -- the
+    filter of that pass may only drop later bins.  The reference lets the F / M pass drop
+    autosomal bins the finished A reference still holds and then misaligns silently at predict
+    time (main.py:242-275 inflates the merged vector with mask.F / mask.M); frozen = 0 reproduces
+    that."""
     last_chr = {"A": 22, "F": 23}.get(gender, 24)
     bins_per_chr = list(bins_per_chr[:last_chr])
     mask = mask[:int(np.sum(bins_per_chr))]
@@ -134,6 +139,12 @@ def prepare(samples, gender, mask, bins_per_chr, ctx=None):
     else:
         X, pca = train_pca(masked_data)
         bad, cutoff = pca_distance_filter(X)
+    if np.any(bad) and frozen:
+        kept = bad & (np.where(mask)[0] < frozen)
+        if np.any(kept):
+            logging.info("Keeping {} anomalous autosomal bins (PCA distance): the autosomal reference "
+                         "of this file already holds them".format(int(np.sum(kept))))
+            bad = bad & ~kept
     if np.any(bad):
         logging.info("Removing {} anomalous bins based on PCA distance (cutoff={:.4f})".format(
             int(np.sum(bad)), cutoff))
