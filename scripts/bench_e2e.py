@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--workdir", default="/tmp/wcx_e2e")
     a = ap.parse_args()
 
+    os.environ.setdefault("WCX_NO_TORCH_PRELOAD", "1")     # like `python -m wisecondorx_amd.main`
     from wisecondorx_amd import main as cli, newref_tools, npz_io, predict_tools, prep, synth
     from wisecondorx_amd import predict_output
 
@@ -62,7 +63,7 @@ def main():
     t_synth = time.perf_counter() - t0
 
     ph = Phases()
-    ph.wrap(npz_io, "load_sample", "load_samples")
+    ph.wrap(npz_io, "load_sample", "load_samples_thread_sum")   # 8 loader threads: summed, not wall
     ph.wrap(prep, "get_mask", "masks")
     ph.wrap(prep, "prepare", "prep_pca")
     ph.wrap(newref_tools, "get_reference_parts", "gpu_search_nullratios")

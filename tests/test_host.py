@@ -75,6 +75,37 @@ def test_npz_roundtrip(tmp_path):
     assert not back["is_nipt"] and float(back["trained_cutoff"]) == 0.004
 
 
+def test_reference_npz_fast_writer_and_reader(tmp_path):
+    """save_npz writes its own ZIP (stored big members, CRCs from worker threads, positional
+    writes): the archive must pass zipfile's CRC check, load with plain np.load exactly like the
+    reference's files, keep Fortran order, and load_reference (direct reads of the stored members)
+    must return the same arrays and dtypes."""
+    import zipfile
+    from wisecondorx_amd import npz_io
+    rng = np.random.default_rng(3)
+    ref = {"binsize": 15000, "indexes": rng.integers(0, 1000, (40000, 60)).astype(np.int32),
+           "distances": rng.random((40000, 60)),
+           "null_ratios.F": np.asfortranarray(rng.random((30000, 40))),
+           "mask": rng.random(50000) > 0.1, "is_nipt": False, "trained_cutoff": 0.25,
+           "pca_mean": rng.random(1000), "meta": np.array({"a": 1}, dtype=object)}
+    p = npz_io.save_npz(str(tmp_path / "ref"), ref)
+    assert p.endswith(".npz")
+    with zipfile.ZipFile(p) as zf:
+        assert zf.testzip() is None
+        kinds = {i.filename: i.compress_type for i in zf.infolist()}
+    assert kinds["distances.npy"] == zipfile.ZIP_STORED and kinds["mask.npy"] == zipfile.ZIP_DEFLATED
+    plain = np.load(p, encoding="latin1", allow_pickle=True)
+    fast = npz_io.load_reference(p)
+    assert set(plain.files) == set(ref) == set(fast)
+    for k, v in ref.items():
+        if k == "meta":
+            assert plain[k].item() == {"a": 1} and fast[k].item() == {"a": 1}
+            continue
+        for got in (plain[k], fast[k]):
+            assert got.dtype == np.asarray(v).dtype and np.array_equal(got, np.asarray(v)), k
+    assert fast["null_ratios.F"].flags.f_contiguous and plain["null_ratios.F"].flags.f_contiguous
+
+
 def test_convert_filters_match_reference_loop(monkeypatch):
     """convert (pysam absent here): the vectorised duplicate / MAPQ / proper-pair filters against
     a straight per-read loop with the reference's branching (convert_tools.py:75-104), on fake
@@ -210,6 +241,29 @@ def test_pca_distance_filter_fires_and_skews_masks():
         np.testing.assert_allclose(p["pca_mean"], g[gender + "_pca_mean"], rtol=1e-13, atol=0)
     assert len(g["A_removed"]) == 9 and len(g["F_removed"]) == 1
     assert g["A_mask"][:n_aut].sum() == g["F_mask"][:n_aut].sum() + 1      # the skew
+
+
+def test_normalize_and_mask_sample_major_is_bit_identical():
+    """normalize_and_mask_t (what prepare feeds the GPU PCA stage) == normalize_and_mask
+    (newref_tools.py:110-129) transposed, bit for bit, incl. samples shorter than the longest."""
+    from wisecondorx_amd import prep
+    rng = np.random.default_rng(8)
+    lens = {str(c): int(rng.integers(30, 90)) for c in range(1, 25)}
+    samples = []
+    for i in range(7):
+        s = {k: rng.integers(0, 400, n).astype(np.int32) for k, n in lens.items()}
+        if i == 2:
+            s["5"] = s["5"][:-4]
+            s["23"] = s["23"][:-1]
+        samples.append(s)
+    samples = np.array(samples)
+    mask, bpc = prep.get_mask(samples)
+    mask = mask & (rng.random(len(mask)) > 0.2)
+    for last in (22, 23, 24):
+        m = mask[:int(np.sum(bpc[:last]))]
+        a = prep.normalize_and_mask(samples, range(1, last + 1), m)
+        b = prep.normalize_and_mask_t(samples, range(1, last + 1), m)
+        assert b.flags.c_contiguous and np.array_equal(a, b.T)
 
 
 def test_frozen_autosomal_mask_in_gonosomal_passes():

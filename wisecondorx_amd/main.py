@@ -103,9 +103,10 @@ def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, context
     parts = newref_tools.get_reference_parts(X, cum, args.refsize, n_parts, sample_ids, contexts)
     out = dict(p)
     out["binsize"] = args.binsize
-    out["indexes"] = np.concatenate([q[0] for q in parts])
-    out["distances"] = np.concatenate([q[1] for q in parts])
-    out["null_ratios"] = np.concatenate([q[2] for q in parts])
+    cat = (lambda seq: seq[0]) if len(parts) == 1 else np.concatenate     # (no 0.8 GB copy for one part)
+    out["indexes"] = cat([q[0] for q in parts])
+    out["distances"] = cat([q[1] for q in parts])
+    out["null_ratios"] = cat([q[2] for q in parts])
     return out
 
 
@@ -120,11 +121,15 @@ def tool_newref(args):
 
     samples = []
     logging.info("Importing data ...")
-    for infile in args.infiles:
-        logging.info("Loading: {}".format(infile))
+    def load_one(infile):                       # (unzip + unpickle release the GIL for most of it)
         sample, binsize = npz_io.load_sample(infile)
-        logging.info("Binsize: {}".format(int(binsize)))
-        samples.append(scale_sample(sample, binsize, args.binsize))
+        return scale_sample(sample, binsize, args.binsize), int(binsize)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        for infile, (sample, binsize) in zip(args.infiles, ex.map(load_one, args.infiles)):
+            logging.info("Loading: {}".format(infile))
+            logging.info("Binsize: {}".format(binsize))
+            samples.append(sample)
     samples = np.array(samples)
     genders, trained_cutoff = train_gender_model(args, samples)
 
@@ -378,4 +383,10 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
+    # the command line never touches torch: skip _lib's torch preload (1 s of import time).  Only
+    # here -- a process that calls main() as a function may use torch later, and then torch's
+    # bundled HIP runtime has to be the first one loaded (see _lib.load).
+    import os
+    if "torch" not in sys.modules:
+        os.environ.setdefault("WCX_NO_TORCH_PRELOAD", "1")
     main()

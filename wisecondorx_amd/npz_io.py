@@ -1,30 +1,159 @@
 """Sample / reference .npz I/O in the reference's formats (SURVEY.md §8b "File formats").
 
 Reference .npz files written here load with plain `np.load(..., allow_pickle=True)` exactly like
-the reference's, but the large arrays (indexes / distances / null_ratios, ~0.7 GB at 15 kb) are
-stored uncompressed inside the zip: single-thread zlib on them costs ~1 min per write in the
-reference (np.savez_compressed, newref_control.py:145,176,237) and would dominate the GPU run.
+the reference's (`newref_control.py:145,176,237` write them with np.savez_compressed), but the
+large arrays (indexes / distances / null_ratios, 2.5 GB at 15 kb) are STORED, not deflated:
+single-thread zlib on them costs minutes.  Writing and reading them is the biggest item of the
+CLI's wall-clock once the search runs on the GPU, so both go around `zipfile` for the big members:
+
+  save_npz        lays the archive out up front (stored members have known sizes), computes the
+                  CRC-32 of the big members on worker threads (zlib releases the GIL) and writes
+                  them with positional writes from those threads; small members are deflated.
+                  The result is an ordinary ZIP (ZIP64 records when needed).
+  load_reference  reads stored `.npy` members straight into their arrays (readinto from worker
+                  threads, no CRC pass); anything else goes through np.load.
 """
 import io
+import os
+import struct
 import zipfile
+import zlib
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-_BIG = 8 << 20
+_BIG = 8 << 20            # stored by the direct writer / read by the direct reader
+_DEFLATE_MAX = 1 << 20    # anything larger is mostly incompressible doubles: stored as is
+_THREADS = 8
+_DOS_TIME, _DOS_DATE = 0, (1980 - 1980) << 9 | 1 << 5 | 1      # 1980-01-01 00:00, like np.savez
+
+
+def _npy_header(arr):
+    """The bytes np.save puts before the raw data of `arr` (format 1.0, or 2.0 for huge headers)."""
+    d = np.lib.format.header_data_from_array_1_0(arr)
+    buf = io.BytesIO()
+    try:
+        np.lib.format.write_array_header_1_0(buf, d)
+    except ValueError:
+        buf = io.BytesIO()
+        np.lib.format.write_array_header_2_0(buf, d)
+    return buf.getvalue()
+
+
+def _raw_view(arr):
+    """The array's bytes in the order the header announces (C or Fortran), without a copy."""
+    if arr.flags.c_contiguous:
+        return memoryview(arr).cast("B")
+    return memoryview(arr.T).cast("B")          # F-contiguous: header says fortran_order=True
+
+
+def _crc_chunks(mv, nparts):
+    """Chunk boundaries of a byte view for parallel work."""
+    n = len(mv)
+    step = max(1 << 20, -(-n // nparts))
+    return [(o, min(o + step, n)) for o in range(0, n, step)]
 
 
 def save_npz(path, arrays, compress_small=True):
     if not str(path).endswith(".npz"):
         path = str(path) + ".npz"
-    with zipfile.ZipFile(path, "w", allowZip64=True) as zf:
-        for name, val in arrays.items():
-            arr = np.asanyarray(val)
+    # ---- plan: every member as (name, header bytes, payload view | deflated bytes, method)
+    members = []
+    for name, val in arrays.items():
+        arr = np.asanyarray(val)
+        fname = (name + ".npy").encode("utf-8")
+        big = (arr.nbytes >= _BIG and arr.dtype != object and not arr.dtype.hasobject
+               and (arr.flags.c_contiguous or arr.flags.f_contiguous))
+        if big:
+            members.append({"name": fname, "head": _npy_header(arr), "raw": _raw_view(arr), "method": 0})
+        else:
             buf = io.BytesIO()
             np.lib.format.write_array(buf, arr, allow_pickle=True)
-            data = buf.getbuffer()
-            ctype = zipfile.ZIP_DEFLATED if (compress_small and arr.nbytes < _BIG) else zipfile.ZIP_STORED
-            zf.writestr(zipfile.ZipInfo(name + ".npy"), data, compress_type=ctype)
+            data = buf.getvalue()
+            if compress_small and len(data) < _DEFLATE_MAX:
+                co = zlib.compressobj(zlib.Z_DEFAULT_COMPRESSION, zlib.DEFLATED, -15)
+                comp = co.compress(data) + co.flush()
+                members.append({"name": fname, "head": b"", "raw": memoryview(comp), "method": 8,
+                                "usize": len(data), "crc": zlib.crc32(data)})
+            else:
+                members.append({"name": fname, "head": b"", "raw": memoryview(data), "method": 0})
+    # ---- layout (stored members have known sizes: nothing depends on the CRCs yet)
+    off = 0
+    for m in members:
+        m.setdefault("usize", len(m["head"]) + len(m["raw"]))
+        m["csize"] = len(m["head"]) + len(m["raw"])
+        m["offset"] = off
+        m["z64"] = m["usize"] >= 0xFFFFFFFF or m["csize"] >= 0xFFFFFFFF
+        m["lhdr_len"] = 30 + len(m["name"]) + (20 if m["z64"] else 0)
+        m["data_off"] = off + m["lhdr_len"]
+        off = m["data_off"] + m["csize"]
+    cd_off = off
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        with ThreadPoolExecutor(max_workers=_THREADS) as ex:
+            # payload writes (positional, in pieces) and the CRC-32 of each stored member run side
+            # by side on the worker threads (zlib and os.pwrite release the GIL)
+            futs, crcs = [], []
+            for m in members:
+                if "crc" not in m:
+                    crcs.append((m, ex.submit(_crc_of, m["head"], m["raw"])))
+                base = m["data_off"] + len(m["head"])
+                for a, b in _crc_chunks(m["raw"], _THREADS):
+                    futs.append(ex.submit(_pwrite_all, fd, m["raw"][a:b], base + a))
+            for m, fut in crcs:
+                m["crc"] = fut.result()
+            # ---- headers and central directory
+            cd = b""
+            for m in members:
+                # ZIP64 extra field of the local header: uncompressed, compressed size
+                extra = struct.pack("<HHQQ", 1, 16, m["usize"], m["csize"]) if m["z64"] else b""
+                lhdr = struct.pack("<IHHHHHIIIHH", 0x04034b50, 45 if m["z64"] else 20, 0, m["method"],
+                                   _DOS_TIME, _DOS_DATE, m["crc"],
+                                   0xFFFFFFFF if m["z64"] else m["csize"],
+                                   0xFFFFFFFF if m["z64"] else m["usize"], len(m["name"]),
+                                   len(extra)) + m["name"] + extra
+                assert len(lhdr) == m["lhdr_len"]
+                os.pwrite(fd, lhdr + m["head"], m["offset"])
+                fields = []
+                if m["z64"]:
+                    fields += [m["usize"], m["csize"]]
+                if m["offset"] >= 0xFFFFFFFF:
+                    fields.append(m["offset"])
+                extra = struct.pack("<HH" + "Q" * len(fields), 1, 8 * len(fields), *fields) if fields else b""
+                cd += struct.pack("<IHHHHHHIIIHHHHHII", 0x02014b50, 45, 45 if fields else 20, 0,
+                                  m["method"], _DOS_TIME, _DOS_DATE, m["crc"],
+                                  0xFFFFFFFF if m["z64"] else m["csize"],
+                                  0xFFFFFFFF if m["z64"] else m["usize"], len(m["name"]), len(extra),
+                                  0, 0, 0, 0o600 << 16,
+                                  0xFFFFFFFF if m["offset"] >= 0xFFFFFFFF else m["offset"]) \
+                    + m["name"] + extra
+            tail = b""
+            if len(members) >= 0xFFFF or cd_off >= 0xFFFFFFFF or len(cd) >= 0xFFFFFFFF:
+                tail += struct.pack("<IQHHIIQQQQ", 0x06064b50, 44, 45, 45, 0, 0, len(members),
+                                    len(members), len(cd), cd_off)
+                tail += struct.pack("<IIQI", 0x07064b50, 0, cd_off + len(cd), 1)
+            tail += struct.pack("<IHHHHIIH", 0x06054b50, 0, 0, min(len(members), 0xFFFF),
+                                min(len(members), 0xFFFF), min(len(cd), 0xFFFFFFFF),
+                                min(cd_off, 0xFFFFFFFF), 0)
+            os.pwrite(fd, cd + tail, cd_off)
+            for f in futs:
+                f.result()
+    finally:
+        os.close(fd)
     return path
+
+
+def _pwrite_all(fd, view, offset):
+    done = 0
+    while done < len(view):
+        done += os.pwrite(fd, view[done:done + (64 << 20)], offset + done)
+
+
+def _crc_of(head, raw):
+    crc = zlib.crc32(head)
+    for o in range(0, len(raw), 256 << 20):
+        crc = zlib.crc32(raw[o:o + (256 << 20)], crc)
+    return crc
 
 
 def load_sample(path):
@@ -38,6 +167,56 @@ def save_sample(path, sample, binsize, quality=None):
     np.savez_compressed(path, binsize=binsize, sample=sample, quality=quality or {})
 
 
+def _read_into(path, offset, view):
+    with open(path, "rb", buffering=0) as fh:
+        fh.seek(offset)
+        done = 0
+        while done < len(view):
+            n = fh.readinto(view[done:done + (64 << 20)])
+            if not n:
+                raise IOError("short read in {}".format(path))
+            done += n
+
+
 def load_reference(path):
-    npz = np.load(path, encoding="latin1", allow_pickle=True)
-    return {k: npz[k] for k in npz.files}
+    """All members of a reference .npz as a dict.  Stored (uncompressed) numeric members are read
+    straight into their arrays by worker threads; the rest (small deflated or pickled members)
+    goes through np.load."""
+    out, direct = {}, []
+    with zipfile.ZipFile(path) as zf, open(path, "rb") as fh:
+        for info in zf.infolist():
+            if not info.filename.endswith(".npy"):
+                continue
+            key = info.filename[:-4]
+            if info.compress_type != zipfile.ZIP_STORED or info.file_size < _BIG:
+                continue
+            fh.seek(info.header_offset)
+            lh = fh.read(30)
+            nlen, elen = struct.unpack("<HH", lh[26:30])
+            data_off = info.header_offset + 30 + nlen + elen
+            fh.seek(data_off)
+            version = np.lib.format.read_magic(fh)
+            if version == (1, 0):
+                shape, fortran, dtype = np.lib.format.read_array_header_1_0(fh)
+            elif version == (2, 0):
+                shape, fortran, dtype = np.lib.format.read_array_header_2_0(fh)
+            else:
+                continue
+            if dtype.hasobject:
+                continue
+            arr = np.empty(shape, dtype=dtype, order="F" if fortran else "C")
+            direct.append((key, arr, fh.tell()))
+    with ThreadPoolExecutor(max_workers=_THREADS) as ex:
+        futs = []
+        for key, arr, off in direct:
+            view = _raw_view(arr)
+            for a, b in _crc_chunks(view, _THREADS):
+                futs.append(ex.submit(_read_into, path, off + a, view[a:b]))
+            out[key] = arr
+        npz = np.load(path, encoding="latin1", allow_pickle=True)
+        for k in npz.files:
+            if k not in out:
+                out[k] = npz[k]
+        for f in futs:
+            f.result()
+    return out

@@ -43,6 +43,37 @@ def normalize_and_mask(samples, chrs, mask):
     return all_data[mask, :]
 
 
+def normalize_and_mask_t(samples, chrs, mask):
+    """normalize_and_mask in the layout the PCA stage wants: (samples x masked bins), sample-major.
+    Bit-identical values (each count divided by the sample's total over the chromosomes of the
+    pass -- an exact integer sum in any order -- masked bins dropped), but every sample is written
+    as one contiguous row: no (bins x samples) matrix with strided column writes, no transpose
+    copy afterwards.  0.3 s instead of 1 s per pass at 15 kb x 500 samples."""
+    chrs = list(chrs)
+    lens = [max(len(s[str(c)]) for s in samples) for c in chrs]
+    off = np.concatenate(([0], np.cumsum(lens))).astype(int)
+    mask = np.asarray(mask[:off[-1]], dtype=bool)
+    keep = [np.flatnonzero(mask[off[j]:off[j + 1]]) for j in range(len(chrs))]
+    moff = np.concatenate(([0], np.cumsum([len(k) for k in keep]))).astype(int)
+    out = np.empty((len(samples), moff[-1]), dtype=float)
+    for i, s in enumerate(samples):
+        total = 0.0
+        row = out[i]
+        for j, c in enumerate(chrs):
+            v = np.asarray(s[str(c)])
+            total += float(v.sum(dtype=np.float64))
+            k = keep[j]
+            nv = len(v)
+            if nv >= lens[j]:
+                row[moff[j]:moff[j + 1]] = v[k]
+            else:                                   # shorter than the longest sample: zero padded
+                inside = k < nv
+                row[moff[j]:moff[j + 1]] = 0.0
+                row[moff[j]:moff[j + 1]][inside] = v[k[inside]]
+        row /= total
+    return out
+
+
 class PCAModel:
     """The two attributes predict needs (reference .npz keys pca_components / pca_mean)."""
 
@@ -74,12 +105,16 @@ def train_pca(ref_data, pcacomp=5):
     return corrected.T, PCAModel(comps, mean)
 
 
-def train_pca_gpu(ref_data, ctx, pcacomp=5, want_dist=False):
+def train_pca_gpu(ref_data, ctx, pcacomp=5, want_dist=False, sample_major=False):
     """train_pca on the MI355X (libwcx_hip.so: wcx_pca_begin / wcx_pca_finish): Gram matrix,
     components, reconstruction and ratio on the device, the S x S eigenproblem here (LAPACK).
-    Same return values as train_pca (+ the filter's dist_to_med profile if want_dist)."""
+    Same return values as train_pca (+ the filter's dist_to_med profile if want_dist).
+    sample_major: ref_data already is the (S, B) matrix of normalize_and_mask_t."""
     from . import _lib
-    t_data = np.ascontiguousarray(ref_data.T, dtype=np.float64)          # (S, B) sample-major
+    if sample_major:
+        t_data = np.ascontiguousarray(ref_data, dtype=np.float64)
+    else:
+        t_data = np.ascontiguousarray(ref_data.T, dtype=np.float64)      # (S, B) sample-major
     S, B = t_data.shape
     mean = np.empty(B)
     gram = np.empty((S, S))
@@ -132,11 +167,12 @@ def prepare(samples, gender, mask, bins_per_chr, ctx=None, frozen=0):
     last_chr = {"A": 22, "F": 23}.get(gender, 24)
     bins_per_chr = list(bins_per_chr[:last_chr])
     mask = mask[:int(np.sum(bins_per_chr))]
-    masked_data = normalize_and_mask(samples, range(1, last_chr + 1), mask)
     if ctx is not None:
-        X, pca, d2m = train_pca_gpu(masked_data, ctx, want_dist=True)
+        masked_t = normalize_and_mask_t(samples, range(1, last_chr + 1), mask)
+        X, pca, d2m = train_pca_gpu(masked_t, ctx, want_dist=True, sample_major=True)
         bad, cutoff = filter_from_dist(d2m)
     else:
+        masked_data = normalize_and_mask(samples, range(1, last_chr + 1), mask)
         X, pca = train_pca(masked_data)
         bad, cutoff = pca_distance_filter(X)
     if np.any(bad) and frozen:
@@ -149,8 +185,11 @@ def prepare(samples, gender, mask, bins_per_chr, ctx=None, frozen=0):
         logging.info("Removing {} anomalous bins based on PCA distance (cutoff={:.4f})".format(
             int(np.sum(bad)), cutoff))
         mask[np.where(mask)[0][bad]] = False
-        masked_data = normalize_and_mask(samples, range(1, last_chr + 1), mask)
-        X, pca = train_pca_gpu(masked_data, ctx) if ctx is not None else train_pca(masked_data)
+        if ctx is not None:
+            masked_t = normalize_and_mask_t(samples, range(1, last_chr + 1), mask)
+            X, pca = train_pca_gpu(masked_t, ctx, sample_major=True)
+        else:
+            X, pca = train_pca(normalize_and_mask(samples, range(1, last_chr + 1), mask))
     off = np.concatenate(([0], np.cumsum(bins_per_chr)))
     masked_bins_per_chr = [int(np.sum(mask[off[i]:off[i + 1]])) for i in range(len(bins_per_chr))]
     masked_bins_per_chr_cum = np.cumsum(masked_bins_per_chr).tolist()
