@@ -158,6 +158,12 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
   if (ctx->d_small) hipFree(ctx->d_small);
   if (ctx->d_nullm) hipFree(ctx->d_nullm);
   if (ctx->d_pca) hipFree(ctx->d_pca);
+  if (ctx->sweep_stream) {
+    hipStreamSynchronize(ctx->sweep_stream);
+    hipStreamDestroy(ctx->sweep_stream);
+    hipEventDestroy(ctx->ev_sweep0);
+    hipEventDestroy(ctx->ev_sweep1);
+  }
   if (ctx->aux_stream) {
     hipStreamSynchronize(ctx->aux_stream);
     hipStreamDestroy(ctx->aux_stream);

@@ -701,22 +701,45 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   a.blocks = d_blocks; a.sl = sl; a.cnt = cnt_out; a.flags = flags; a.g_state = g_state;
   a.stats = ctx->d_stats; a.row_begin = row_begin; a.n_rows_all = n_rows;
   a.k = k; a.dbg = ctx->debug_flags; a.n_seg = n_seg; a.n_blocks = (int)blocks.size();
-  const unsigned grid = (unsigned)(blocks.size() * n_seg);
+  // Every chunk launch ends with a partly filled last round of workgroups (1423 blocks on 512
+  // slots = 2.78 rounds at 15 kb).  With more than one round of blocks the target blocks are split
+  // in two halves that sweep the same chunks on two streams: when one half's launch drains, the
+  // other half's workgroups fill the freed slots -- the per-launch tails overlap instead of adding
+  // up.  (Blocks are independent: all per-target state is addressed through ScreenBlock::row0.)
+  int n_streams = ((int)blocks.size() > slots && n_seg == 1) ? 2 : 1;
+  n_streams = env_int("WCX_SCREEN_STREAMS", n_streams);
+  if (n_streams != 2 || n_seg != 1 || blocks.size() < 2) n_streams = 1;
+  hipStream_t st2 = st;
+  if (n_streams == 2) {
+    if (!ctx->sweep_stream) {
+      WCX_HIP(hipStreamCreateWithFlags(&ctx->sweep_stream, hipStreamNonBlocking));
+      WCX_HIP(hipEventCreateWithFlags(&ctx->ev_sweep0, hipEventDisableTiming));
+      WCX_HIP(hipEventCreateWithFlags(&ctx->ev_sweep1, hipEventDisableTiming));
+    }
+    st2 = ctx->sweep_stream;
+    WCX_HIP(hipEventRecord(ctx->ev_sweep0, st));          // prep and state resets are done
+    WCX_HIP(hipStreamWaitEvent(st2, ctx->ev_sweep0, 0));
+  }
+  const int half0 = n_streams == 2 ? (int)(blocks.size() + 1) / 2 : (int)blocks.size();
   bool first = true;
   auto launch = [&](int64_t g0, int64_t g1, int cut_k, int cut_mode, int trig, int end_cut) {
     a.g_start = g0; a.g_count = (int)(g1 - g0);
     a.cut_k = cut_k; a.cut_mode = cut_mode; a.trig = trig; a.end_cut = end_cut;
     a.first = first ? 1 : 0;
     first = false;
-    const int e = screen_dispatch(cfg, a, grid, lds, st);
-    if (e < 0) {
-      wcx_set_error("screen kernel configuration nk=%d ctg=%d tt=%d wpb=%d lb=%d ring=%d is not instantiated",
-                    cfg.nk, cfg.ctg, cfg.tt, cfg.wpb, cfg.lb, cfg.ring);
-      return (int)WCX_ERR_UNSUPPORTED;
-    }
-    if (e != 0) {
-      wcx_set_error("screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-      return (int)WCX_ERR_HIP;
+    for (int h = 0; h < n_streams; ++h) {
+      a.blocks = d_blocks + (h ? half0 : 0);
+      a.n_blocks = h ? (int)blocks.size() - half0 : half0;
+      const int e = screen_dispatch(cfg, a, (unsigned)(a.n_blocks * n_seg), lds, h ? st2 : st);
+      if (e < 0) {
+        wcx_set_error("screen kernel configuration nk=%d ctg=%d tt=%d wpb=%d lb=%d ring=%d is not instantiated",
+                      cfg.nk, cfg.ctg, cfg.tt, cfg.wpb, cfg.lb, cfg.ring);
+        return (int)WCX_ERR_UNSUPPORTED;
+      }
+      if (e != 0) {
+        wcx_set_error("screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        return (int)WCX_ERR_HIP;
+      }
     }
     return (int)WCX_OK;
   };
@@ -748,6 +771,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
         k_merge_segments<<<gm, NT, 0, st>>>(info, glob, rowpos, row_begin, n_rows, searched, sl,
                                             cnt_out, flags, g_state, s0, s0 + step, k, gamma,
                                             step * 2 >= n_seg ? 1 : 0);
+  }
+  if (n_streams == 2) {                                   // the second half joins the main stream
+    WCX_HIP(hipEventRecord(ctx->ev_sweep1, st2));
+    WCX_HIP(hipStreamWaitEvent(st, ctx->ev_sweep1, 0));
   }
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_screen");

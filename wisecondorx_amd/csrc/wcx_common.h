@@ -60,6 +60,8 @@ struct wcx_ctx {
   // null-sample ranking done ahead on an auxiliary stream (wcx_null_rank_prepare_dev)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_main = nullptr, ev_rank = nullptr;
+  hipStream_t sweep_stream = nullptr;        // second stream of the screen sweep (see wcx_topk_screen_launch)
+  hipEvent_t ev_sweep0 = nullptr, ev_sweep1 = nullptr;
   void *d_rank = nullptr;
   size_t rank_bytes = 0;
   const double *rank_X = nullptr;
