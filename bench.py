@@ -210,6 +210,10 @@ class Workload:
                  "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": self.fb_rows,
                  "compactions": stats["compactions"], "appends": stats["appends"],
                  "refined_pairs": stats["refined"],
+                 "kernel_ms_note": "wall time of one whole sweep (HIP events on the launch stream, second "
+                                   "stream joined by an event); the target blocks sweep in two halves "
+                                   "on two concurrent streams, so rocprofv3's average launch duration x "
+                                   "launches per sweep / 2 is the figure to compare with",
                  "attainable_note": "the dense-f16 peak is not attainable on random data: a bare "
                                     "LDS-fed MFMA loop is power-limited to 1.27-1.48 PFLOP/s on this "
                                     "chip (profiles/r02/ubench_mfma.txt)"}
