@@ -106,6 +106,28 @@ def test_reference_npz_fast_writer_and_reader(tmp_path):
     assert fast["null_ratios.F"].flags.f_contiguous and plain["null_ratios.F"].flags.f_contiguous
 
 
+def test_reference_npz_zip64_records(tmp_path, monkeypatch):
+    """The ZIP64 branch of save_npz (members / offsets beyond 4 GB: 5 kb-bin references) with the
+    threshold lowered so that a small archive takes it: ZIP64 extra fields in the local and
+    central headers, ZIP64 end-of-central-directory record + locator -- readable by zipfile,
+    np.load and load_reference."""
+    import zipfile
+    from wisecondorx_amd import npz_io
+    monkeypatch.setattr(npz_io, "_Z64", 1 << 20)
+    monkeypatch.setattr(npz_io, "_BIG", 1 << 18)
+    rng = np.random.default_rng(4)
+    ref = {"a": rng.random((300, 500)), "b": rng.integers(0, 9, (900, 400)).astype(np.int32),
+           "c": rng.random(70000), "small": np.arange(5), "flag": True}
+    p = npz_io.save_npz(str(tmp_path / "z64.npz"), ref)
+    with zipfile.ZipFile(p) as zf:
+        assert zf.testzip() is None
+        assert {i.filename for i in zf.infolist()} == {k + ".npy" for k in ref}
+    plain = np.load(p, allow_pickle=True)
+    fast = npz_io.load_reference(p)
+    for k, v in ref.items():
+        assert np.array_equal(plain[k], np.asarray(v)) and np.array_equal(fast[k], np.asarray(v)), k
+
+
 def test_convert_filters_match_reference_loop(monkeypatch):
     """convert (pysam absent here): the vectorised duplicate / MAPQ / proper-pair filters against
     a straight per-read loop with the reference's branching (convert_tools.py:75-104), on fake

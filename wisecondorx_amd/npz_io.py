@@ -25,6 +25,7 @@ import numpy as np
 _BIG = 8 << 20            # stored by the direct writer / read by the direct reader
 _DEFLATE_MAX = 1 << 20    # anything larger is mostly incompressible doubles: stored as is
 _THREADS = 8
+_Z64 = 0xFFFFFFFF           # sizes / offsets from here on go into ZIP64 extra fields
 _DOS_TIME, _DOS_DATE = 0, (1980 - 1980) << 9 | 1 << 5 | 1      # 1980-01-01 00:00, like np.savez
 
 
@@ -83,7 +84,7 @@ def save_npz(path, arrays, compress_small=True):
         m.setdefault("usize", len(m["head"]) + len(m["raw"]))
         m["csize"] = len(m["head"]) + len(m["raw"])
         m["offset"] = off
-        m["z64"] = m["usize"] >= 0xFFFFFFFF or m["csize"] >= 0xFFFFFFFF
+        m["z64"] = m["usize"] >= _Z64 or m["csize"] >= _Z64
         m["lhdr_len"] = 30 + len(m["name"]) + (20 if m["z64"] else 0)
         m["data_off"] = off + m["lhdr_len"]
         off = m["data_off"] + m["csize"]
@@ -117,7 +118,7 @@ def save_npz(path, arrays, compress_small=True):
                 fields = []
                 if m["z64"]:
                     fields += [m["usize"], m["csize"]]
-                if m["offset"] >= 0xFFFFFFFF:
+                if m["offset"] >= _Z64:
                     fields.append(m["offset"])
                 extra = struct.pack("<HH" + "Q" * len(fields), 1, 8 * len(fields), *fields) if fields else b""
                 cd += struct.pack("<IHHHHHHIIIHHHHHII", 0x02014b50, 45, 45 if fields else 20, 0,
@@ -125,16 +126,17 @@ def save_npz(path, arrays, compress_small=True):
                                   0xFFFFFFFF if m["z64"] else m["csize"],
                                   0xFFFFFFFF if m["z64"] else m["usize"], len(m["name"]), len(extra),
                                   0, 0, 0, 0o600 << 16,
-                                  0xFFFFFFFF if m["offset"] >= 0xFFFFFFFF else m["offset"]) \
+                                  0xFFFFFFFF if m["offset"] >= _Z64 else m["offset"]) \
                     + m["name"] + extra
             tail = b""
-            if len(members) >= 0xFFFF or cd_off >= 0xFFFFFFFF or len(cd) >= 0xFFFFFFFF:
+            if len(members) >= 0xFFFF or cd_off >= _Z64 or len(cd) >= _Z64:
                 tail += struct.pack("<IQHHIIQQQQ", 0x06064b50, 44, 45, 45, 0, 0, len(members),
                                     len(members), len(cd), cd_off)
                 tail += struct.pack("<IIQI", 0x07064b50, 0, cd_off + len(cd), 1)
             tail += struct.pack("<IHHHHIIH", 0x06054b50, 0, 0, min(len(members), 0xFFFF),
-                                min(len(members), 0xFFFF), min(len(cd), 0xFFFFFFFF),
-                                min(cd_off, 0xFFFFFFFF), 0)
+                                min(len(members), 0xFFFF),
+                                0xFFFFFFFF if len(cd) >= _Z64 else len(cd),
+                                0xFFFFFFFF if cd_off >= _Z64 else cd_off, 0)
             os.pwrite(fd, cd + tail, cd_off)
             for f in futs:
                 f.result()
