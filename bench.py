@@ -215,8 +215,9 @@ class Workload:
                                    "on two concurrent streams, so rocprofv3's average launch duration x "
                                    "launches per sweep / 2 is the figure to compare with",
                  "attainable_note": "the dense-f16 peak is not attainable on random data: a bare "
-                                    "LDS-fed MFMA loop is power-limited to 1.27-1.48 PFLOP/s on this "
-                                    "chip (profiles/r02/ubench_mfma.txt)"}
+                                    "LDS-fed MFMA loop with DMA staging and no epilogue is power-limited "
+                                    "to 1.1-1.35 PFLOP/s on this chip, box to box (1.9-2.0 on all-zero "
+                                    "operands; profiles/r02/ubench_mfma.txt)"}
             if any(stats["phase_cycles"]):          # only with --debug-flags 4
                 r["phase_cycles"] = stats["phase_cycles"]
         else:
@@ -299,16 +300,20 @@ def main():
 
     # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (bench.py cannot read
     # counters itself); only valid for the kernel sources it was recorded with
-    if screen_ms >= 0 and world == 1 and os.path.exists(TRAFFIC_JSON):
+    def add_traffic(rf, S):
+        if not (world == 1 and os.path.exists(TRAFFIC_JSON)):
+            return
         tj = json.load(open(TRAFFIC_JSON))
-        key = "S{}".format(w.S)
+        key = "S{}".format(S)
         if tj.get("kernel_sha") == screen_source_sha() and key in tj.get("workloads", {}) \
                 and (args.binsize, args.refsize) == (15000, 300):
             e = tj["workloads"][key]
-            roofline["traffic"] = e["fetch_bytes_per_sweep_corrected_x2"] + e["write_bytes_per_sweep"]
-            roofline["traffic_source"] = "profiles/r02/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
-                                         "WRITE_SIZE; bytes per screen sweep; kernel_sha {})".format(
-                                             tj["kernel_sha"])
+            rf["traffic"] = e["fetch_bytes_per_sweep_corrected_x2"] + e["write_bytes_per_sweep"]
+            rf["traffic_source"] = "profiles/r02/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
+                                   "WRITE_SIZE; bytes per screen sweep; kernel_sha {})".format(
+                                       tj["kernel_sha"])
+    if screen_ms >= 0:
+        add_traffic(roofline, w.S)
 
     out = {
         "metric": "newref+predict throughput @{}kb bins (bins x refs per second)".format(
@@ -337,7 +342,9 @@ def main():
             and args.samples != 100:
         w2 = Workload(args, 100, torch, dev, dev_index, rank, world)
         dt2 = run_steps(w2, args.steps, args.warmup, SPINUP_STEPS, barrier)
-        r2, _ = w2.roofline()
+        r2, sm2 = w2.roofline()
+        if sm2 >= 0:
+            add_traffic(r2, w2.S)
         out["secondary"] = {"workload": "BASELINE configs[2]: 15 kb x 100 samples, same step",
                             "ms_per_step": dt2 / args.steps * 1e3,
                             "value": w2.pairs_total / (dt2 / args.steps),
