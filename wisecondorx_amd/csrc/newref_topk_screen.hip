@@ -278,8 +278,8 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
   if (row >= 0)
     for (int j4 = 0; j4 < Sp / 4; ++j4) {
       const double4 q = xrow[j4];
-      bad |= !(fabs(q.x) < HUGE_VAL) | !(fabs(q.y) < HUGE_VAL) | !(fabs(q.z) < HUGE_VAL) |
-             !(fabs(q.w) < HUGE_VAL);
+      bad = bad || !(fabs(q.x) < HUGE_VAL) || !(fabs(q.y) < HUGE_VAL) || !(fabs(q.z) < HUGE_VAL) ||
+            !(fabs(q.w) < HUGE_VAL);
     }
   const bool zero = row < 0 || bad;          // padding / NaN-inf rows: all-zero image
   double n2 = 0.0, e2 = 0.0;
