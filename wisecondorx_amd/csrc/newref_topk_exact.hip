@@ -57,6 +57,7 @@ __device__ void bitonic_sort_lds(double *sd, int *si, int n) {
 __global__ __launch_bounds__(NT) void k_topk_exact(
     const double *__restrict__ Xs, int64_t B, int S, const TopkBlock *__restrict__ blocks,
     const unsigned int *__restrict__ n_blocks_dev, unsigned int first_blk,
+    const int32_t *__restrict__ rowlist,
     int k, int C, double *__restrict__ scr_d, int *__restrict__ scr_i, int64_t row_begin,
     int32_t *__restrict__ out_idx, double *__restrict__ out_dist,
     unsigned long long *__restrict__ stats) {
@@ -76,6 +77,9 @@ __global__ __launch_bounds__(NT) void k_topk_exact(
   unsigned long long n_compact = 0;
   for (unsigned int bi = first_blk + blockIdx.x; bi < n_blk; bi += gridDim.x) {
   const TopkBlock blk = blocks[bi];
+  // rowlist != nullptr (redo of many flagged rows): blk.row0 is an offset into `rowlist`, whose
+  // entries are the (scattered) target rows of this tile -- all of one chromosome
+  auto trow = [&](int n) -> int64_t { return rowlist ? (int64_t)rowlist[blk.row0 + n] : blk.row0 + n; };
   const int64_t orow0 = blk.row0 - row_begin;                       // output row of local row 0
   const int64_t srow0 = n_blocks_dev ? (int64_t)blockIdx.x * TM : orow0;   // scratch row
 
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(NT) void k_topk_exact(
       for (int t = tid; t < keep; t += NT) { scr_d[base + t] = sd[t]; scr_i[base + t] = si[t]; }
       if (tid == 0) { cnt[r] = keep; tau[r] = (n >= k) ? sd[k - 1] : 1e10; }
     } else {
-      const int64_t ob = (orow0 + r) * (int64_t)k;
+      const int64_t ob = (rowlist ? trow(r) - row_begin : orow0 + r) * (int64_t)k;
       for (int t = tid; t < k; t += NT) {
         out_idx[ob + t] = t < keep ? si[t] : -1;
         out_dist[ob + t] = t < keep ? sd[t] : 1e10;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(NT) void k_topk_exact(
           const bool cval = (g0 + n) < hi;
           for (int jj = tid >> 6; jj < jn; jj += 4) {
             const double *row = Xs + (int64_t)(j0 + jj) * B;
-            st[jj * TM + n] = tval ? row[blk.row0 + n] : 0.0;
+            st[jj * TM + n] = tval ? row[trow(n)] : 0.0;
             sc[jj * TN + n] = cval ? row[g0 + n] : 0.0;
           }
         }
@@ -198,8 +202,8 @@ __global__ __launch_bounds__(NT) void k_redo_dist(const double *__restrict__ Xs,
                                                   const TopkBlock *__restrict__ blocks,
                                                   const unsigned int *__restrict__ n_blocks_dev,
                                                   unsigned long long *__restrict__ keys) {
-  unsigned int n = *n_blocks_dev;
-  if (n > (unsigned)WCX_REDO_FAST) n = WCX_REDO_FAST;
+  const unsigned int n = *n_blocks_dev;
+  if (n > (unsigned)WCX_REDO_FAST) return;          // many rows: the tiled redo takes all of them
   const int64_t nchunk = (B + NT - 1) / NT;
   for (int64_t w = blockIdx.x; w < (int64_t)n * nchunk; w += gridDim.x) {
     const unsigned int slot = (unsigned int)(w / nchunk);
@@ -231,8 +235,8 @@ __global__ __launch_bounds__(RS_NT) void k_redo_select(int64_t B, const TopkBloc
   __shared__ unsigned int wtot[RS_NT / 64];
   __shared__ unsigned long long s_prefix;
   __shared__ unsigned int s_rem, s_cnt;
-  unsigned int n = *n_blocks_dev;
-  if (n > (unsigned)WCX_REDO_FAST) n = WCX_REDO_FAST;
+  const unsigned int n = *n_blocks_dev;
+  if (n > (unsigned)WCX_REDO_FAST) return;
   const int tid = threadIdx.x;
   for (unsigned int slot = blockIdx.x; slot < n; slot += gridDim.x) {
     const TopkBlock blk = blocks[slot];
@@ -378,18 +382,21 @@ int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   rc = wcx_timer_begin(ctx, "topk");
   if (rc) return rc;
   k_topk_exact<<<(unsigned)blocks.size(), NT, lds, ctx->stream>>>(
-      dXs, B, S, d_blocks, nullptr, 0u, k, C, scr_d, scr_i, row_begin, d_out_idx, d_out_dist, d_stats);
+      dXs, B, S, d_blocks, nullptr, 0u, nullptr, k, C, scr_d, scr_i, row_begin, d_out_idx, d_out_dist, d_stats);
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk");
   if (rc) return rc;
   return WCX_OK;
 }
 
-// Device-driven redo (no host round trip): `d_blocks[0 .. *d_count)` was written by the screen's
-// k_collect_redo (normally *d_count = 0 and every launch returns at once).  The first
-// WCX_REDO_FAST rows take the device-wide path (k_redo_dist + k_redo_select, ~1 ms for a handful of
-// rows); anything beyond that goes to a fixed grid of WCX_REDO_GRID workgroups of the blocked exact
-// kernel.  `scratch` must hold wcx_topk_redo_scratch_bytes(k, B) bytes.
+// Device-driven redo (no host round trip): `d_blocks[0 .. *d_count)` (one-row blocks) was written
+// by the screen's k_collect_redo (normally *d_count = 0 and every launch returns at once).  Up to
+// WCX_REDO_FAST rows take the device-wide path (k_redo_dist + k_redo_select, ~0.1 ms per row).
+// More rows (data the fp16 screen cannot resolve, e.g. a tenth of the rows being high-variance
+// outliers) were grouped by chromosome into tiles of <= 64 rows (`d_tiles`, `d_rowlist`, see
+// k_redo_plan): a fixed grid of WCX_REDO_GRID workgroups of the blocked exact kernel strides over
+// the tiles, each tile sweeping the candidates once for its 64 gathered rows.
+// `scratch` must hold wcx_topk_redo_scratch_bytes(k, B) bytes.
 static size_t redo_blocked_bytes(int k) {
   int C = 1024;
   while (C < k + TN) C <<= 1;
@@ -401,8 +408,10 @@ size_t wcx_topk_redo_scratch_bytes(int k, int64_t B) {
 }
 
 int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
-                               const TopkBlock *d_blocks, const unsigned int *d_count, void *scratch,
-                               int64_t row_begin, int k, int32_t *d_out_idx, double *d_out_dist) {
+                               const TopkBlock *d_blocks, const unsigned int *d_count,
+                               const TopkBlock *d_tiles, const unsigned int *d_ntiles,
+                               const int32_t *d_rowlist, void *scratch, int64_t row_begin, int k,
+                               int32_t *d_out_idx, double *d_out_dist) {
   int C = 1024;
   while (C < k + TN) C <<= 1;
   if (C > 8192) {
@@ -428,9 +437,9 @@ int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S
                                        (size_t)WCX_REDO_GRID * TM * C * 8);
   WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_topk_exact),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_topk_exact<<<WCX_REDO_GRID, NT, lds, ctx->stream>>>(dXs, B, S, d_blocks, d_count,
-                                                        (unsigned)WCX_REDO_FAST, k, C, scr_d, scr_i,
-                                                        row_begin, d_out_idx, d_out_dist, nullptr);
+  k_topk_exact<<<WCX_REDO_GRID, NT, lds, ctx->stream>>>(dXs, B, S, d_tiles, d_ntiles, 0u, d_rowlist, k, C,
+                                                        scr_d, scr_i, row_begin, d_out_idx, d_out_dist,
+                                                        nullptr);
   WCX_HIP(hipGetLastError());
   return WCX_OK;
 }

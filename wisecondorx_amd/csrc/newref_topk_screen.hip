@@ -414,23 +414,63 @@ __global__ __launch_bounds__(NT) void k_merge_segments(
 }
 
 // Rows the screen could not finish (shortlist overflow, unproven estimate) -> redo list for the
-// exact kernel, built on the device: no host round trip.
+// exact kernels, built on the device: no host round trip.
+//   ctr[0] = number of flagged rows, ctr[1] = number of tiles, ctr[2 + c] = flagged rows of
+//   chromosome c, ctr[34 + c] = fill cursor of chromosome c in the row list.
 __global__ __launch_bounds__(NT) void k_collect_redo(int64_t row_begin, int64_t n_rows,
                                                      const unsigned char *__restrict__ searched,
                                                      const unsigned int *__restrict__ flags,
                                                      ChrTab chr, TopkBlock *__restrict__ redo,
-                                                     unsigned int *__restrict__ n_redo,
+                                                     unsigned int *__restrict__ ctr,
                                                      unsigned long long *__restrict__ stats) {
   const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
   if (r >= n_rows || !searched[r] || !flags[r]) return;
   const int64_t row = row_begin + r;
   int64_t cs = 0, ce = chr.cum[0];
-  for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
-  const unsigned int slot = atomicAdd(n_redo, 1u);
+  int c = 0;
+  for (int q = 1; q < chr.n_chr && row >= ce; ++q) { cs = ce; ce = chr.cum[q]; c = q; }
+  const unsigned int slot = atomicAdd(&ctr[0], 1u);
   TopkBlock b;
   b.row0 = row; b.nrows = 1; b.pad = 0; b.cs = cs; b.ce = ce;
-  redo[slot] = b;
+  redo[slot] = b;                       // one-row blocks: the device-wide path for a handful of rows
+  atomicAdd(&ctr[2 + c], 1u);
   atomicAdd(&stats[3], 1ull);
+}
+
+// More than WCX_REDO_FAST flagged rows: tiles of <= 64 rows of one chromosome for the blocked exact
+// kernel (tile.row0 = offset into the row list).  One thread; at most n_rows / 64 + n_chr tiles.
+__global__ void k_redo_plan(ChrTab chr, unsigned int *__restrict__ ctr, TopkBlock *__restrict__ tiles) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (ctr[0] <= (unsigned int)WCX_REDO_FAST) { ctr[1] = 0; return; }
+  unsigned int off = 0, t = 0;
+  int64_t cs = 0;
+  for (int c = 0; c < chr.n_chr; ++c) {
+    const int64_t ce = chr.cum[c];
+    const unsigned int cnt = ctr[2 + c];
+    ctr[34 + c] = off;
+    for (unsigned int q = 0; q < cnt; q += 64) {
+      TopkBlock b;
+      b.row0 = off + q; b.nrows = (int)(cnt - q < 64 ? cnt - q : 64); b.pad = 0; b.cs = cs; b.ce = ce;
+      tiles[t++] = b;
+    }
+    off += cnt;
+    cs = ce;
+  }
+  ctr[1] = t;
+}
+
+__global__ __launch_bounds__(NT) void k_redo_fill(int64_t row_begin, int64_t n_rows,
+                                                  const unsigned char *__restrict__ searched,
+                                                  const unsigned int *__restrict__ flags, ChrTab chr,
+                                                  unsigned int *__restrict__ ctr,
+                                                  int32_t *__restrict__ rowlist) {
+  if (ctr[0] <= (unsigned int)WCX_REDO_FAST) return;
+  const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (r >= n_rows || !searched[r] || !flags[r]) return;
+  const int64_t row = row_begin + r;
+  int c = 0;
+  for (int q = 1; q < chr.n_chr && row >= chr.cum[q - 1]; ++q) c = q;
+  rowlist[atomicAdd(&ctr[34 + c], 1u)] = (int32_t)row;
 }
 
 }  // namespace
@@ -596,7 +636,9 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_srch = carve((size_t)n_rows);
   const size_t o_blk = carve(blocks.size() * sizeof(ScreenBlock));
   const size_t o_redo = carve((size_t)n_rows * sizeof(TopkBlock));
-  const size_t o_nredo = carve(256);
+  const size_t o_nredo = carve(512);                                   // counters, see k_collect_redo
+  const size_t o_rtile = carve(((size_t)n_rows / 64 + 64) * sizeof(TopkBlock));
+  const size_t o_rlist = carve((size_t)n_rows * 4);
   const size_t o_rscr = carve(wcx_topk_redo_scratch_bytes(k, B));
   void *scr = nullptr;
   int rc = wcx_scratch(ctx, off, &scr);
@@ -623,13 +665,15 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   ScreenBlock *d_blocks = reinterpret_cast<ScreenBlock *>(base + o_blk);
   TopkBlock *d_redo = reinterpret_cast<TopkBlock *>(base + o_redo);
   unsigned int *d_nredo = reinterpret_cast<unsigned int *>(base + o_nredo);
+  TopkBlock *d_rtile = reinterpret_cast<TopkBlock *>(base + o_rtile);
+  int32_t *d_rlist = reinterpret_cast<int32_t *>(base + o_rlist);
 
   hipStream_t st = ctx->stream;
   WCX_HIP(hipMemsetAsync(glob, 0, sizeof(ScreenGlobals), st));
   WCX_HIP(hipMemsetAsync(cnt_out, 0, (size_t)n_seg * n_rows * 4, st));
   WCX_HIP(hipMemsetAsync(flags, 0, (size_t)n_seg * n_rows * 4, st));
   WCX_HIP(hipMemsetAsync(searched, 0, (size_t)n_rows, st));
-  WCX_HIP(hipMemsetAsync(d_nredo, 0, 256, st));
+  WCX_HIP(hipMemsetAsync(d_nredo, 0, 512, st));
   WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, st));
   rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
   if (rc) return rc;
@@ -794,9 +838,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // redo list and its length never leave the device
   k_collect_redo<<<(unsigned)((n_rows + NT - 1) / NT), NT, 0, st>>>(row_begin, n_rows, searched, flags,
                                                                    tab, d_redo, d_nredo, ctx->d_stats);
+  k_redo_plan<<<1, 64, 0, st>>>(tab, d_nredo, d_rtile);
+  k_redo_fill<<<(unsigned)((n_rows + NT - 1) / NT), NT, 0, st>>>(row_begin, n_rows, searched, flags, tab,
+                                                                d_nredo, d_rlist);
   WCX_HIP(hipGetLastError());
-  rc = wcx_topk_exact_redo_launch(ctx, dXs, B, S, d_redo, d_nredo, base + o_rscr, row_begin, k,
-                                  d_out_idx, d_out_dist);
+  rc = wcx_topk_exact_redo_launch(ctx, dXs, B, S, d_redo, d_nredo, d_rtile, d_nredo + 1, d_rlist,
+                                  base + o_rscr, row_begin, k, d_out_idx, d_out_dist);
   if (rc) return rc;
   return wcx_timer_end(ctx, "topk");
 }

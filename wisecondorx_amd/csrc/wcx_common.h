@@ -108,14 +108,16 @@ struct TopkBlock {
 int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                           const std::vector<TopkBlock> &blocks, int64_t row_begin,
                           int64_t n_rows, int k, int32_t *d_out_idx, double *d_out_dist);
-constexpr int WCX_REDO_GRID = 64;   // workgroups of the device-driven exact redo
+constexpr int WCX_REDO_GRID = 128;  // workgroups of the device-driven tiled exact redo
 constexpr int WCX_REDO_FAST = 128;  // flagged rows that take the device-wide redo path
 size_t wcx_topk_redo_scratch_bytes(int k, int64_t B);
 int wcx_host_scratch(wcx_ctx *ctx, size_t bytes, void **out);
 int wcx_aux_kick(wcx_ctx *ctx);   // null_ratios.hip: start pending auxiliary-stream work
 int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
-                               const TopkBlock *d_blocks, const unsigned int *d_count, void *scratch,
-                               int64_t row_begin, int k, int32_t *d_out_idx, double *d_out_dist);
+                               const TopkBlock *d_blocks, const unsigned int *d_count,
+                               const TopkBlock *d_tiles, const unsigned int *d_ntiles,
+                               const int32_t *d_rowlist, void *scratch, int64_t row_begin, int k,
+                               int32_t *d_out_idx, double *d_out_dist);
 bool wcx_screen_supported(int64_t B, int S, int k);
 int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                            const int64_t *chr_cum, int n_chr,
