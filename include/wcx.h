@@ -158,6 +158,7 @@ int wcx_ref_free(wcx_ctx *ctx, wcx_ref *ref);
 int wcx_cutoff(wcx_ctx *ctx, const wcx_ref *ref, int repeats, double *cutoff);
 /* Replaces predict_tools.get_weights (predict_tools.py:152-155): out[B]. */
 int wcx_weights(wcx_ctx *ctx, const wcx_ref *ref, double *out);
+/* The same with the result left on the device (d_out double[B]), asynchronous on the stream. */
 int wcx_weights_dev(wcx_ctx *ctx, const wcx_ref *ref, double *d_out);
 /* Replaces predict_tools.normalize_repeat (predict_tools.py:94-142) for a batch of
  * n_samples projected sample vectors x double[n_samples][B]: three masked passes, rows from
