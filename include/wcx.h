@@ -225,6 +225,21 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
 /* Diagnostics of the CBS calls on this context since its creation: out[0] = hybrid tests decided
  * by the short-arc bound (their permutations were not run), out[1..3] reserved. */
 int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]);
+/* Per-test records of the LAST wcx_cbs / wcx_cbs_batch call on this context, kept when
+ * wcx_debug_flags(ctx, 128) was set before it (what tests/test_gpu_cbs_oracle.py compares with the
+ * NumPy oracle).  One record = 20 doubles: sample, chromosome, lo, hi (segment in the chromosome's
+ * NA-free series), n, best arc bi, bj, t^2, tail p (NaN if n <= 200), delta, why (1 constant /
+ * invalid, 2 t <= 0.1, 3 t >= 7, 4 tail p > alpha, 5 permutations, 6 short-arc bound), budget nrejc,
+ * exceedances nrej and permutations np at the stop (-1 without permutations), significant,
+ * change-points kept, then (kept, nrej; -1 = t^2 > 25 rule, -2 = no test) of the two edge tests.
+ * *count receives the number of records available; at most cap_records are copied. */
+int wcx_cbs_trace(wcx_ctx *ctx, double *out, int cap_records, int *count);
+/* The sequential stopping boundary of the permutation tests (Venkatraman & Olshen 2007; DNAcopy's
+ * getbdry(eta, nperm, max.ones), called from segment() -- the DNAcopy call of CBS.R:73 -- with
+ * eta = 0.05, nperm = 10000, max.ones = floor(nperm * alpha) + 1): out int32[max_ones (max_ones + 1) / 2],
+ * block j (length j, offset j (j - 1) / 2) = stopping points of a test that tolerates j - 1
+ * exceedances.  Host-only, no device needed. */
+int wcx_cbs_getbdry(double eta, int nperm, int max_ones, int32_t *out);
 /* Replaces overall_tools.get_z_score (overall_tools.py:88-119).  nr double[n_bins][m]
  * (rows of masked bins ignored; pad ragged rows with NaN), seg as produced by wcx_cbs;
  * out_z double[n_seg] (NaN where undefined), out_nnull double[n_seg] (may be NULL) = number of

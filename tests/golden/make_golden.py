@@ -490,7 +490,19 @@ def golden_config1():
     save("config1.npz", **out)
 
 
+def golden_cbs_bdry():
+    """NOT a reference output (DNAcopy is not in the reference repository): the sequential-boundary
+    table of the CBS ORACLE (oracle/cbs_oracle.getbdry, scipy hypergeometric CDF, ~50 s) for
+    alpha = 0.01, stored so that tests need not re-derive it.  tests/test_oracle_cbs.py re-derives
+    its first blocks and checks the product's own derivation (wcx_cbs_getbdry) against all of it."""
+    from oracle import cbs_oracle as CO
+    tab = np.array(CO.getbdry(0.05, 10000, 101), dtype=np.int32)
+    save("cbs_bdry.npz", eta=0.05, nperm=10000, max_ones=101, table=tab)
+
+
 if __name__ == "__main__":
+    if "bdry" in sys.argv[1:]:
+        golden_cbs_bdry()
     which = sys.argv[1:] or ["search", "pipeline", "prep_filter", "config1", "tables"]
     if "tables" in which:
         golden_tables()

@@ -136,9 +136,11 @@ def test_cbs_long_chromosomes(pt, n_big):
 
 def test_cbs_short_arc_bound_is_an_exact_shortcut(pt):
     """Hybrid tests whose observed statistic exceeds what ANY permutation can reach with a short arc
-    are decided without running their permutations (short_arc_bound in cbs_seg.hip).  The
-    segmentation must be identical with the shortcut disabled (debug flag 32), and the shortcut
-    must actually fire on long aberrations while weak ones still go through the permutations."""
+    are decided without running their permutations (short_arc_bound in cbs_seg.hip).  Run with
+    DNAcopy's t >= 7 rule disabled (debug flag 2), so that long aberrations reach the permutation
+    stage at all: the segmentation must be identical with the bound disabled as well (flag 32), and
+    the bound must actually fire on long aberrations while weak ones still go through the
+    permutations."""
     from wisecondorx_amd import _lib
     ctx = _lib.default_context()
     rng = np.random.default_rng(11)
@@ -153,16 +155,18 @@ def test_cbs_short_arc_bound_is_an_exact_shortcut(pt):
         for c in range(23):
             res["results_r"][c][rng.random(n_per_chr[c]) < 0.03] = 0
         cases.append(res)
+    default = [pt.run_cbs(res, "F", 1e-4, 100000, 3, ctx) for res in cases]
     before = ctx.cbs_stats()["bound_shortcuts"]
-    with_shortcut = [pt.run_cbs(res, "F", 1e-4, 100000, 3, ctx) for res in cases]
-    fired = ctx.cbs_stats()["bound_shortcuts"] - before
-    ctx.lib.wcx_debug_flags(ctx.h, 32)
+    ctx.lib.wcx_debug_flags(ctx.h, 2)
     try:
+        with_shortcut = [pt.run_cbs(res, "F", 1e-4, 100000, 3, ctx) for res in cases]
+        fired = ctx.cbs_stats()["bound_shortcuts"] - before
+        ctx.lib.wcx_debug_flags(ctx.h, 2 | 32)
         without = [pt.run_cbs(res, "F", 1e-4, 100000, 3, ctx) for res in cases]
         assert ctx.cbs_stats()["bound_shortcuts"] - before == fired     # none while disabled
     finally:
         ctx.lib.wcx_debug_flags(ctx.h, 0)
-    assert with_shortcut == without
+    assert with_shortcut == without == default
     assert fired >= 4
     segs0 = sorted(s for s in with_shortcut[0] if s[0] == 0)
     assert len(segs0) == 3 and abs(segs0[1][1] - 500) <= 2 and abs(segs0[1][2] - 1700) <= 2

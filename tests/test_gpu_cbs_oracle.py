@@ -1,0 +1,257 @@
+"""a16 parity proper: the device CBS (wisecondorx_amd/csrc/cbs_seg.hip through wcx_cbs / wcx_cbs_batch)
+against the NumPy oracle (oracle/cbs_oracle.py) on a fuzz of > 200 series -- n from 4 to 40 000,
+weights, NA runs, planted / borderline / absent effects, heavy tails, alpha in {1e-4, 1e-3, 1e-2} --
+asserting IDENTICAL change-points, identical decisions of every single test (why it stopped, best
+arc, exceedance count nrej and stopping point np under the sequential boundary, edge tests) and the
+reference-owned CBS.R wrapper output.  DNAcopy itself stays unpinned (no R here): this pins the device
+code to an independent statement of the same algorithm, not to DNAcopy's binaries."""
+import multiprocessing as mp
+import os
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import cbs_oracle as CO
+from oracle import wcx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+WHY = {1: "constant", 2: "t<=0.1", 3: "t>=7", 4: "tailp", 5: "perm", 6: "perm"}
+
+
+def _series(rng, n, big):
+    """One chromosome: (log2 ratios with 0 = missing, weights)."""
+    sd = rng.choice([0.03, 0.06, 0.12])
+    kind = int(rng.integers(0, 10))
+    x = rng.normal(0, sd, n)
+    if kind == 5 and not big:
+        x = rng.standard_t(3, n) * sd * 0.6                         # heavy tails / outliers
+    wkind = int(rng.integers(0, 4))
+    w = (np.ones(n) if wkind == 0 else rng.uniform(0.5, 2.0, n) if wkind == 1
+         else np.exp(rng.normal(0, 0.5, n)) if wkind == 2 else rng.uniform(0.8, 1.2, n))
+
+    def plant(t_target):
+        if n < 12:
+            return
+        L = int(rng.integers(2, max(3, n // 3)))
+        s = int(rng.integers(0, n - L))
+        delta = t_target * sd / np.sqrt(L * (1.0 - L / n))
+        x[s:s + L] += rng.choice([-1, 1]) * delta
+
+    if kind in (1, 2, 5):
+        # borderline effects only where the oracle's permutations stay affordable
+        plant(rng.uniform(3.0, 6.5) if not big else rng.choice([0.0, 12.0]))
+    elif kind == 3:
+        plant(rng.uniform(7.0, 15.0))
+        if not big:
+            plant(rng.uniform(3.5, 6.0))
+    elif kind == 4 and n > 30:
+        s = int(rng.integers(1, n - 5))
+        x[s:] += rng.choice([-1, 1]) * rng.uniform(3.0 if not big else 9.0, 10.0) * sd / np.sqrt(min(s, n - s))
+    elif kind == 6 and n > 40:
+        plant(rng.uniform(4.0, 9.0) if not big else 10.0)
+        a = int(rng.integers(0, n - 20))
+        x[a:a + int(rng.integers(3, min(60, n // 2)))] = 0.0          # an NA run (0 = missing)
+        x[rng.random(n) < 0.04] = 0.0
+    elif kind == 7:
+        x[rng.random(n) < 0.3] = 0.0
+    elif kind == 8:
+        w[rng.random(n) < 0.1] = 0.0                                 # weight 0 -> 1 (CBS.R:42)
+        plant(rng.uniform(3.0, 7.0) if not big else 0.0)
+    return x, w
+
+
+def _case(seed, sizes):
+    rng = np.random.default_rng(seed)
+    r, w = [], []
+    for n in sizes:
+        x, ww = _series(rng, int(n), n > 4000)
+        r.append(x)
+        w.append(ww)
+    return {"results_r": r, "results_w": w}
+
+
+def _sizes(rng, big=()):
+    s = list(rng.integers(4, 201, 6)) + list(rng.integers(201, 400, 4)) + \
+        list(rng.integers(400, 1500, 7)) + list(rng.integers(1500, 4000, 6))
+    s = s[:23 - len(big)] + list(big)
+    rng.shuffle(s)
+    assert len(s) == 23
+    return [int(v) for v in s]
+
+
+def _cases():
+    rng = np.random.default_rng(2024)
+    out = []
+    for i, alpha in enumerate([1e-4, 1e-4, 1e-4, 1e-3, 1e-3, 1e-3, 1e-2, 1e-2, 1e-2]):
+        big = () if i % 3 else (int(rng.integers(6000, 17000)),)
+        out.append((100 + i, alpha, _sizes(rng, big), 15000 if i % 2 else 100000, 5 + i))
+    out.append((200, 1e-4, _sizes(rng, (20000, 40000)), 5000, 1))   # beyond the LDS capacity
+    return out
+
+
+@pytest.fixture(scope="module")
+def pt():
+    from wisecondorx_amd import predict_tools
+    return predict_tools
+
+
+@pytest.fixture(scope="module")
+def bdry():
+    t = np.load(os.path.join(GOLDEN, "cbs_bdry.npz"))["table"]
+    CO.load_boundary_table(t)
+    return [int(v) for v in t]
+
+
+@pytest.fixture(scope="module")
+def pool():
+    n = max(2, min(96, (os.cpu_count() or 4) - 2))
+    with ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("spawn")) as ex:
+        yield ex
+
+
+def _oracle(pool, res, alpha, binsize, seed, table, strict=False):
+    """The oracle over all chromosomes (process pool) + the CBS.R wrapper: segments and traces."""
+    jobs = []
+    for c in range(23):
+        y = np.array(res["results_r"][c], dtype=float)
+        w = np.array(res["results_w"][c], dtype=float)
+        y[y == 0] = np.nan
+        w[w == 0] = 1.0
+        if np.all(np.isnan(y)):
+            continue
+        jobs.append((c, y, w, alpha, seed, strict, table))
+    done = {c: (segs, tr) for c, segs, tr in pool.map(CO.segment_series, jobs)}
+    segs = O.cbs_r_wrapper(res["results_r"], res["results_w"], "F", alpha, binsize, seed,
+                           lambda c, y, w, a, st: done[c][0])
+    trace = [r for c in sorted(done) for r in done[c][1]]
+    return segs, trace
+
+
+def _compare_traces(dev, orc, ctxt):
+    """Every test of every segment: same arc, same reason, same counts."""
+    by_key = {(r["chr"], r["lo"], r["hi"]): r for r in orc}
+    assert len(dev) == len(by_key), ctxt
+    n_perm = n_edge = 0
+    for d in dev:
+        key = (int(d[1]), int(d[2]), int(d[3]))
+        o = by_key[key]
+        msg = "{} test {}".format(ctxt, key)
+        why = int(d[10])
+        assert WHY[why] == o.get("why"), msg
+        if why == 1:
+            continue
+        # (0, j] and (j, n] are complementary arcs: the same statistic up to rounding, the same single
+        # change-point j -- compared in the canonical form (0, j]
+        canon = lambda bi, bj, n: (0, bi) if bj == n else (bi, bj)
+        assert canon(int(d[5]), int(d[6]), int(d[4])) == canon(o["bi"], o["bj"], o["n"]), msg
+        np.testing.assert_allclose(d[7], o["ostat"], rtol=1e-9, err_msg=msg)
+        if o["hybrid"] and why in (4, 5, 6):
+            np.testing.assert_allclose(d[8], o["pval1"], rtol=1e-7, err_msg=msg)
+            np.testing.assert_allclose(d[9], o["delta"], rtol=1e-12, err_msg=msg)
+        if why == 5:
+            n_perm += 1
+            assert (int(d[11]), int(d[12]), int(d[13])) == (o["nrejc"], o["nrej"], o["np"]), msg
+        if why == 6:                                         # decided by the short-arc bound: the
+            assert o["nrej"] == 0 and o.get("significant")   # oracle RAN them and saw no exceedance
+        assert bool(d[14]) == bool(o.get("significant")), msg
+        assert int(d[15]) == len(o["cpt"]), msg
+        if "edge" in o:
+            for e in range(2):
+                keep_o, nrej_o = o["edge"][e]
+                assert bool(d[16 + 2 * e]) == keep_o, msg
+                if keep_o:
+                    n_edge += 1
+                    assert int(d[17 + 2 * e]) == nrej_o, msg  # -1 = t^2 > 25 rule in both
+    return n_perm, n_edge
+
+
+def _run_device(pt, ctx, res, alpha, binsize, seed, flags=128):
+    ctx.lib.wcx_debug_flags(ctx.h, flags)
+    try:
+        segs = pt.run_cbs(res, "F", alpha, binsize, seed, ctx)
+        return segs, ctx.cbs_trace()
+    finally:
+        ctx.lib.wcx_debug_flags(ctx.h, 0)
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: "seed{}_alpha{:g}".format(c[0], c[1]))
+def test_device_cbs_equals_oracle(pt, pool, bdry, case):
+    from wisecondorx_amd import _lib
+    ctx = _lib.default_context()
+    cseed, alpha, sizes, binsize, seed = case
+    res = _case(cseed, sizes)
+    segs, dtrace = _run_device(pt, ctx, res, alpha, binsize, seed)
+    osegs, otrace = _oracle(pool, res, alpha, binsize, seed, bdry)
+    assert [s[:3] for s in segs] == [s[:3] for s in osegs], "breakpoints differ"
+    np.testing.assert_allclose([s[3] for s in segs], [s[3] for s in osegs], rtol=1e-12)
+    n_perm, n_edge = _compare_traces(dtrace, otrace, "case {}".format(cseed))
+    print("case {} alpha {:g}: {} segments, {} tests, {} by permutations, {} edge tests kept".format(
+        cseed, alpha, len(segs), len(dtrace), n_perm, n_edge))
+
+
+def test_fuzz_exercises_every_path(pt, bdry):
+    """The fuzz above is only worth something if it reaches the permutation machinery: over all
+    cases the device must have decided tests by permutations (significant and not), by the
+    sequential boundary BEFORE the last permutation, by the tail probability, by both shortcuts, and
+    run edge tests with a real count."""
+    from wisecondorx_amd import _lib
+    ctx = _lib.default_context()
+    why = {k: 0 for k in range(7)}
+    early_sig = nonsig = sig_perm = edge_counted = n_series = 0
+    for cseed, alpha, sizes, binsize, seed in _cases():
+        res = _case(cseed, sizes)
+        n_series += len(sizes)
+        _, tr = _run_device(pt, ctx, res, alpha, binsize, seed)
+        for d in tr:
+            why[int(d[10])] += 1
+            if int(d[10]) == 5:
+                if d[14]:
+                    sig_perm += 1
+                    early_sig += d[13] < 10000
+                else:
+                    nonsig += 1
+            edge_counted += (d[17] >= 0) + (d[19] >= 0)
+    print(why, early_sig, nonsig, sig_perm, edge_counted, n_series)
+    assert n_series >= 200
+    assert why[2] + why[4] > 100 and why[3] >= 20 and why[5] >= 40
+    assert sig_perm >= 10 and nonsig >= 10 and early_sig >= 5 and edge_counted >= 5
+
+
+def test_shortcuts_do_not_change_the_segmentation(pt, pool, bdry):
+    """DNAcopy's two shortcuts as recalled (t >= 7 with >= 10 points: split without a p-value;
+    t^2 > 25 with >= 10 points: edge kept without permutations) -- with both disabled (debug flag 2 /
+    strict oracle) every such test goes through its permutations.  Same change-points on this data,
+    device == oracle in strict mode too."""
+    from wisecondorx_amd import _lib
+    ctx = _lib.default_context()
+    cseed, alpha, sizes, binsize, seed = _cases()[1]
+    res = _case(cseed, sizes)
+    segs, _ = _run_device(pt, ctx, res, alpha, binsize, seed)
+    strict_segs, strict_trace = _run_device(pt, ctx, res, alpha, binsize, seed, flags=128 | 2)
+    assert not any(int(d[10]) == 3 for d in strict_trace)
+    assert segs == strict_segs
+    osegs, otrace = _oracle(pool, res, alpha, binsize, seed, bdry, strict=True)
+    assert [s[:3] for s in strict_segs] == [s[:3] for s in osegs]
+    _compare_traces(strict_trace, otrace, "strict")
+
+
+def test_batch_equals_single_and_is_seed_keyed(pt):
+    """The permutation key depends on (seed, chromosome, segment) only: a sample's segmentation is
+    the same alone, at any position of a batch, and on a second run; another seed gives another
+    stream (borderline tests may then differ, the exceedance counts do)."""
+    from wisecondorx_amd import _lib
+    ctx = _lib.default_context()
+    sizes = [300, 900, 150, 2500, 60] + [220] * 18
+    samples = [_case(300 + i, sizes) for i in range(5)]
+    single = [pt.run_cbs(s, "F", 1e-3, 100000, 9, ctx) for s in samples]
+    assert pt.run_cbs_batch(samples, "F", 1e-3, 100000, 9, ctx) == single
+    assert pt.run_cbs_batch(samples[::-1], "F", 1e-3, 100000, 9, ctx) == single[::-1]
+    _, t9 = _run_device(pt, ctx, samples[0], 1e-3, 100000, 9)
+    _, t9b = _run_device(pt, ctx, samples[0], 1e-3, 100000, 9)
+    _, t10 = _run_device(pt, ctx, samples[0], 1e-3, 100000, 10)
+    assert np.array_equal(t9, t9b, equal_nan=True)
+    perm9, perm10 = t9[t9[:, 10] == 5], t10[t10[:, 10] == 5]
+    assert len(perm9) and not (len(perm9) == len(perm10) and np.array_equal(perm9[:, 12:14], perm10[:, 12:14]))

@@ -65,6 +65,8 @@ SIGNATURES = {
     "wcx_cbs": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64, vp,
                           C.c_int, C.POINTER(C.c_int)]),
     "wcx_cbs_stats": (C.c_int, [vp, c_i64p]),
+    "wcx_cbs_trace": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "wcx_cbs_getbdry": (C.c_int, [C.c_double, C.c_int, C.c_int, vp]),
     "wcx_weights_dev": (C.c_int, [vp, vp, vp]),
     "wcx_post_process_dev": (C.c_int, [vp, vp, vp, vp, vp, c_i64, vp, vp, C.c_double, vp, c_i64, vp, vp, vp]),
     "wcx_cbs_batch": (C.c_int, [vp, vp, vp, C.c_int, c_i64, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64,
@@ -172,6 +174,16 @@ class Context:
         out = (C.c_int64 * 4)()
         check(self.lib.wcx_cbs_stats(self.h, out))
         return {"bound_shortcuts": out[0]}
+
+    def cbs_trace(self):
+        """Per-test records of the last CBS call (needs wcx_debug_flags(h, 128) before it); rows of
+        20 doubles, see include/wcx.h."""
+        n = C.c_int()
+        check(self.lib.wcx_cbs_trace(self.h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 20))
+        if n.value:
+            check(self.lib.wcx_cbs_trace(self.h, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def topk_stats(self):
         out = (C.c_int64 * 16)()

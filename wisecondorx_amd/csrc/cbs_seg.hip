@@ -5,40 +5,65 @@
 // (NA masking, weight fix-up CBS.R:41-42, dropping all-NA chromosomes :56-63, splitting segments
 // over long NA runs :84-113, weighted re-mean :122-127, 0-based starts :129) is reproduced
 // exactly.  The segmentation itself lives in Bioconductor DNAcopy 1.76.0 (conda.yml:14), which is
-// NOT part of the reference repository and cannot run here (no R): PARITY UNPINNED.  It is
-// restated from the published algorithm with DNAcopy's defaults (Olshen et al. 2004;
-// Venkatraman & Olshen 2007) and from the structure of DNAcopy's changepoints code as recalled:
-//   * weighted max-arc statistic over all arcs with >= min.width = 2 points on each side;
-//   * n > nmin = 200: "hybrid" p-value = Siegmund tail approximation for the arcs longer than
-//     kmax = 25 + permutation reference distribution (nperm = 10 000) of the short-arc maximum;
-//     otherwise the full permutation distribution; the observed statistic is compared as
-//     0.99999 * ostat; the permutations stop as soon as the exceedance budget
-//     floor(p2 * nperm) is spent (not significant);
-//   * an interior arc yields two change-points, each kept only if its own two-sample permutation
-//     test (weighted means of the shorter side, nperm permutations; skipped as "clearly
-//     significant" when t^2 > 25 with >= 10 points) has p <= alpha; undo.splits = "none".
-// Deviations that make breakpoint parity impossible even with R available: the permutation
-// stream (counter-based hash here, R's Mersenne-Twister there) and DNAcopy's sequential stopping
-// boundary for SIGNIFICANT tests (getbdry; at alpha = 1e-4 it can only save the last ~13 % of the
-// permutations and never changes a decision by more than its error budget eta = 0.05 allows).
+// NOT part of the reference repository and cannot run here (no R): PARITY UNPINNED against DNAcopy.
+// What it IS checked against: the test suite's NumPy CBS oracle, an independent statement of the same
+// algorithm (Olshen et al. 2004; Venkatraman & Olshen 2007; the decision flow of DNAcopy's
+// changepoints() / wfindcpt / wtpermp / tailp / getbdry as recalled) -- identical change-points,
+// exceedance counts and stopping points on a fuzz set (tests/test_gpu_cbs_oracle.py).
+//
+// Decision flow of one test of a segment with n points (weights w, series centred on its weighted
+// mean; "[D]" = DNAcopy behaviour as recalled, unverifiable offline):
+//   * n < 2 min.width (= 4), or max - min <= 1.49e-8 [D: all.equal(diff(range), 0)]: no change;
+//   * observed statistic: max over arcs (i, j], min.width <= j - i <= n - min.width, of
+//     bss = (S_j - S_i)^2 / (w_a (W - w_a) / W); t^2 = bss / ((tss - bss) / (n - 2)), with
+//     tss <= bss + 1e-4 replaced by bss + 1 [D]; all in fp64;
+//   * t <= 0.1: no change [D]; t >= 7 with >= 10 points on the shorter side of the arc: change
+//     without a p-value [D];
+//   * n > nmin = 200 ("hybrid"): p1 = Siegmund tail approximation for the arcs holding a weight
+//     fraction in [delta, 1 - delta], delta = min weight of any arc of kmax + 1 points / W [D:
+//     getmncwt]; p1 > alpha: no change; else nperm = 10 000 permutations of the maximum over arcs
+//     of <= kmax = 25 points (or whose complement has <= kmax points) against 0.99999 t^2 with the
+//     exceedance budget nrejc = int((alpha - p1) nperm); n <= nmin: all arcs, budget int(alpha nperm);
+//   * the permutations are consumed IN ORDER under the sequential boundary of Venkatraman & Olshen
+//     (getbdry(eta = 0.05, nperm, floor(nperm alpha) + 1) [D]): not significant as soon as the
+//     exceedances pass the budget, significant as soon as permutation number np reaches
+//     boundary[exceedances so far];
+//   * an interior arc gives two change-points, each kept only if its two-sample permutation test
+//     (weighted mean of the shorter side; t^2 > 25 with >= 10 points: kept without permutations [D])
+//     has p <= alpha; undo.splits = "none".
+// Permuted series [D: wxperm]: y = sqrt(w) (x - mean) is exchangeable under H0; position i receives
+// y[pi(i)] / sqrt(w_i), i.e. the weighted value v_i = sqrt(w_i) y[pi(i)].  Their total T is not 0
+// (unlike the unweighted case), and an arc and its complement only carry the same statistic for a
+// centred series: the permuted series is re-centred on its weighted mean (v_i - (T / W) w_i) and
+// its total sum of squares is tss - T^2 / W (sum v^2 / w = sum y^2 is permutation invariant).
+// Whether DNAcopy re-centres is not recalled with certainty; without it the arcs whose complement
+// is short pick up T^2 ~ n var(sqrt w) and swamp the statistic.  pi = keyed Feistel bijection
+// (specification: DESIGN.md section 6; key = f(seed, chromosome, segment, kind of test) --
+// independent of batch position and scheduling).
 //
 // GPU mapping -- LEVEL-SYNCHRONOUS and BATCHED: all chromosomes of all samples of a call advance
 // together.  Per round: (1) one launch prepares every active segment (weighted centring, fp64
 // prefix sums), (2) one launch finds every segment's best arc (fp64, striped over many
 // workgroups), (3) one launch evaluates the tail probabilities, ONE device->host copy of the
-// per-segment records, (4) one launch runs the permutations of every segment that needs them
-// (one workgroup per permutation: a keyed Feistel bijection of [0, n) = the random permutation,
-// weighted re-centring, prefix scan, short-arc maximum; a per-segment counter lets later
-// workgroups exit as soon as the budget is spent), one copy of the counters, (5) the same kernel
-// in "edge" mode for the two-sample tests.  The host only keeps the segment stack.
+// per-segment records, (4) the permutation tests of all segments: one workgroup per permutation.
+// The hybrid statistic is SCREENED in fp32 -- arc sums are local prefix sums of <= 33 raw values in
+// registers, so their error is bounded by a per-job constant; a permutation whose statistic lies
+// within that bound of the threshold is flagged and re-evaluated in fp64 by k_cbs_perm_exact --
+// every exceedance is recorded as a BIT (job, permutation), the host walks the bits in order under
+// the sequential rule.  A workgroup skips its permutation when the exceedances recorded in EARLIER
+// 256-permutation chunks already pass the budget (the sequential rule can then never reach it).
+// Permutations run in two stages, [0, 512) then the rest for the undecided tests.  (5) the edge
+// tests (fp64, one wave per permutation).  The host only keeps the segment stack.
 // Compute/latency bound; reported as wall-clock per sample.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <functional>
-#include <vector>
+#include <map>
+#include <mutex>
 #include <thread>
+#include <vector>
 
 #include "wave_sort.h"
 #include "wcx_common.h"
@@ -46,15 +71,66 @@
 namespace {
 
 constexpr int NTP = 1024;
-constexpr int KMAXC = 25;   // DNAcopy's kmax (short-arc limit of the hybrid p-value), compile-time here
+constexpr int KMAXC = 25;    // DNAcopy's kmax (short-arc limit of the hybrid p-value), compile-time here
+constexpr int QC_W = 32;     // complement-arc weight table: [KMAXC + 1][QC_W]
+constexpr int PCHUNK = 256;  // permutations per skip-counter chunk
+constexpr int NCH = 64;      // chunk counters per job (nperm <= 16384)
+constexpr int STAGE_A = 512; // permutations of the first stage
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
   return z ^ (z >> 31);
 }
+
+// Random permutation WITHOUT a sort: a keyed bijection of [0, n).  Four Feistel rounds on
+// Z_a x Z_a, a = ceil(sqrt(n)) (so the domain a*a exceeds n by < 2 sqrt(n) + 1 and the cycle walk
+// back into [0, n) almost never iterates); round function = murmur3's 32-bit finaliser of
+// (half + round key), mapped to [0, a) by a high multiply.
+struct Feistel {
+  unsigned int fa, n, rk[4];
+  float inv_fa;
+  __device__ __forceinline__ void init(int n_, unsigned long long key, int p) {
+    n = (unsigned int)n_;
+    fa = (unsigned int)sqrtf((float)n_);
+    while ((unsigned long long)fa * fa < (unsigned long long)n) ++fa;
+    while (fa > 1 && (unsigned long long)(fa - 1) * (fa - 1) >= (unsigned long long)n) --fa;
+    inv_fa = 1.0f / (float)fa;
+    const unsigned long long s0 = mix64(key ^ ((unsigned long long)p * 0xd1342543de82ef95ull));
+    const unsigned long long s1 = mix64(s0 + 1ull);
+    rk[0] = (unsigned int)s0; rk[1] = (unsigned int)(s0 >> 32);
+    rk[2] = (unsigned int)s1; rk[3] = (unsigned int)(s1 >> 32);
+  }
+  __device__ __forceinline__ int at(int i) const {
+    unsigned int x = (unsigned int)i;
+    do {
+      unsigned int L;
+      int R;
+      if (n < (1u << 22)) {          // x < fa^2 < 2^23: (float)x is exact, the quotient is off by <= 1
+        L = (unsigned int)((float)x * inv_fa);
+        R = (int)(x - L * fa);
+        if (R < 0) { --L; R += (int)fa; }
+        else if (R >= (int)fa) { ++L; R -= (int)fa; }
+      } else {
+        L = x / fa;
+        R = (int)(x - L * fa);
+      }
+      unsigned int Rr = (unsigned int)R;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        unsigned int h = Rr + rk[r];
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        unsigned int sN = L + __umulhi(h, fa);
+        sN = sN >= fa ? sN - fa : sN;
+        L = Rr; Rr = sN;
+      }
+      x = L * fa + Rr;
+    } while (x >= n);
+    return (int)x;
+  }
+};
 
 // One active segment [lo, hi) of the concatenated (NA-free) data of all series of the call.
 struct SegIn {
@@ -64,57 +140,91 @@ struct SegIn {
 };
 // What the host needs back to decide.
 struct SegOut {
-  double tss, W, ostat, pval1;
-  int32_t bi, bj;   // best arc (bi, bj], 0 <= bi < bj <= n
+  double tss, W, mean, ostat, pval1, delta;
+  double range, wmin, wmax, ymax;   // max - min of x; smallest / largest weight; largest |sqrt(w) (x - mean)|
+  int32_t bi, bj;             // best arc (bi, bj], 0 <= bi < bj <= n
   int32_t valid, pad;
 };
-// A permutation job: the segmentation test of a segment, or one two-sample edge test.
+// A permutation test: the segmentation test of a segment (mode 0 hybrid, 1 all arcs) or one
+// two-sample edge test (mode 2).
 struct PermJob {
-  int64_t lo;        // first element of the (sub)series
-  int32_t n;
-  int32_t mode;      // 0 = max short-arc statistic (hybrid), 1 = max over all arcs, 2 = edge test
-  int32_t m1, first; // edge test: size of the shorter side; 1 = it is the first m1 positions
-  int32_t nrejc, pad;
-  double ostat;      // threshold (already scaled by 0.99999)
-  unsigned long long seed;
-  int64_t qoff;      // mode 0: this job's block of the arc-weight table (k_cbs_arcweights)
+  int64_t lo;            // first element of the (sub)series
+  int32_t n, mode;
+  int32_t m1, budget;    // edge: size of the shorter side; exceedances the test tolerates
+  int32_t slot, pad;     // row of the bit / counter tables
+  double thr;            // 0.99999 t^2                       (edge: 0.99999 |mean_short - xbar|)
+  double tss;            // observed tss of the segment       (edge: xbar)
+  double W;              // total weight                      (edge: weight of the shorter side)
+  // fp32 screen of the hybrid statistic (sqrt(bss) units): exceedance <=> bss >= cthr * tss', tss' =
+  // tss - T^2 / W (T = total of the permuted weighted series); D = bound of the fp32 error of
+  // sqrt(bss), eT |T| = bound of the error of tss' from T's rounding.  A permutation within these
+  // bounds of the threshold, or of the tss' <= bss + 1e-4 rule, is flagged for the fp64 kernel.
+  double cthr, D, eT;
+  unsigned long long key;
+  int64_t qoff;          // mode 0: this job's block of the arc-weight table (k_cbs_arcweights)
 };
 
+// ---- block reductions (NT threads, NT / 64 waves; every thread gets the result) -------------
+template <int NT, typename Op>
+__device__ __forceinline__ double block_reduce_d(double v, double *red, Op op, double ident) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;     // v is already wave-reduced
+  __syncthreads();
+  double r = ident;
+  for (int q = 0; q < NT / 64; ++q) r = op(r, red[q]);
+  return r;
+}
+template <int NT>
+__device__ __forceinline__ double block_sum_d(double v, double *red) {
+  return block_reduce_d<NT>(wcx::wave_sum(v), red, [](double a, double b) { return a + b; }, 0.0);
+}
+template <int NT>
+__device__ __forceinline__ double block_max_d(double v, double *red) {
+  return block_reduce_d<NT>(wcx::wave_max_f64(v), red, [](double a, double b) { return a > b ? a : b; },
+                            -HUGE_VAL);
+}
+template <int NT>
+__device__ __forceinline__ double block_min_d(double v, double *red) {
+  return block_reduce_d<NT>(wcx::wave_min_f64(v), red, [](double a, double b) { return a < b ? a : b; },
+                            HUGE_VAL);
+}
+
 // ---- (1) prepare: weighted centring + prefix sums -------------------------------------------
-// S[lo + i] = sum_{t < i} w (x - mean), Wp likewise (both arrays have one slot per element + the
-// segment's end slot lives at index hi of arrays sized N + 1: segments are disjoint and ordered,
-// the end slot of one is the start slot of the next, rewritten by whoever runs later -- so every
-// segment keeps its OWN end value in SegOut.W / a separate tail array).
+// S[lo + i] = sum_{t < i} w (x - mean), Wp likewise (one slot per element; a segment's end values
+// are 0 / W by construction and are not stored: segments are disjoint and ordered, the end slot of
+// one is the start slot of the next).  yd = sqrt(w) (x - mean) (fp64) and its fp32 image y, rw =
+// sqrt(w) (fp32) feed the permutation kernels.
 __global__ __launch_bounds__(NTP) void k_cbs_prepare(const double *__restrict__ x,
                                                      const double *__restrict__ w,
                                                      const SegIn *__restrict__ segs,
                                                      double *__restrict__ S, double *__restrict__ Wp,
-                                                     float *__restrict__ y, float *__restrict__ rw,
-                                                     float *__restrict__ Wpf,
+                                                     double *__restrict__ yd, float *__restrict__ y,
+                                                     float *__restrict__ rw,
                                                      SegOut *__restrict__ out) {
   const SegIn sg = segs[blockIdx.x];
   const int n = sg.n, tid = threadIdx.x;
   const double *xs = x + sg.lo, *ws = w + sg.lo;
-  __shared__ double red[2][NTP / 64];
+  __shared__ double red[NTP / 64];
   __shared__ double tot[2][NTP];
-  auto block_sum2 = [&](double a, double b, double &ra, double &rb) {
-    a = wcx::wave_sum(a);
-    b = wcx::wave_sum(b);
-    __syncthreads();
-    if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = b; }
-    __syncthreads();
-    ra = 0.0; rb = 0.0;
-    for (int q = 0; q < NTP / 64; ++q) { ra += red[0][q]; rb += red[1][q]; }
-  };
-  double sw = 0.0, sx = 0.0;
-  for (int i = tid; i < n; i += NTP) { sw += ws[i]; sx += ws[i] * xs[i]; }
-  double W, SX;
-  block_sum2(sw, sx, W, SX);
+  double sw = 0.0, sx = 0.0, xmin = HUGE_VAL, xmax = -HUGE_VAL, wmin = HUGE_VAL, wmax = 0.0;
+  for (int i = tid; i < n; i += NTP) {
+    sw += ws[i]; sx += ws[i] * xs[i];
+    xmin = xs[i] < xmin ? xs[i] : xmin;
+    xmax = xs[i] > xmax ? xs[i] : xmax;
+    wmin = ws[i] < wmin ? ws[i] : wmin;
+    wmax = ws[i] > wmax ? ws[i] : wmax;
+  }
+  const double W = block_sum_d<NTP>(sw, red), SX = block_sum_d<NTP>(sx, red);
+  xmin = block_min_d<NTP>(xmin, red);
+  xmax = block_max_d<NTP>(xmax, red);
+  wmin = block_min_d<NTP>(wmin, red);
+  wmax = block_max_d<NTP>(wmax, red);
   const double mean = SX / W;
   // chunked scan: thread t owns elements [t*chunk, (t+1)*chunk)
   const int chunk = (n + NTP - 1) / NTP;
   const int i0 = tid * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-  double ls = 0.0, lw = 0.0, lt = 0.0;
+  double ls = 0.0, lw = 0.0, lt = 0.0, ymax = 0.0;
   for (int i = i0; i < i1; ++i) {
     const double c = xs[i] - mean;
     ls += ws[i] * c;
@@ -135,18 +245,22 @@ __global__ __launch_bounds__(NTP) void k_cbs_prepare(const double *__restrict__ 
   for (int i = i0; i < i1; ++i) {
     S[sg.lo + i] = rs;
     Wp[sg.lo + i] = rwt;
-    Wpf[sg.lo + i] = (float)rwt;
     const double c = xs[i] - mean, r = sqrt(ws[i]);
-    y[sg.lo + i] = (float)(c * r);
+    const double yy = c * r;
+    yd[sg.lo + i] = yy;
+    y[sg.lo + i] = (float)yy;
     rw[sg.lo + i] = (float)r;
+    ymax = fabs(yy) > ymax ? fabs(yy) : ymax;
     rs += ws[i] * c;
     rwt += ws[i];
   }
-  double tss, dummy;
-  block_sum2(lt, 0.0, tss, dummy);
+  const double tss = block_sum_d<NTP>(lt, red);
+  ymax = block_max_d<NTP>(ymax, red);
   if (tid == 0) {
     SegOut o;
-    o.tss = tss; o.W = W; o.ostat = 0.0; o.pval1 = 0.0; o.bi = 0; o.bj = 0; o.valid = 0; o.pad = 0;
+    o.tss = tss; o.W = W; o.mean = mean; o.ostat = 0.0; o.pval1 = 0.0; o.delta = 0.0;
+    o.range = xmax - xmin; o.wmin = wmin; o.wmax = wmax; o.ymax = ymax;
+    o.bi = 0; o.bj = 0; o.valid = 0; o.pad = 0;
     out[blockIdx.x] = o;
   }
 }
@@ -228,15 +342,19 @@ __global__ __launch_bounds__(256) void k_cbs_arcmax(const double *__restrict__ S
   if (threadIdx.x == 0) { best[blockIdx.x].b = sb[0]; best[blockIdx.x].i = si_[0]; best[blockIdx.x].j = sj_[0]; }
 }
 
-// per segment: reduce its stripes (items [first[s], first[s+1])), t^2 of the best arc, and the
-// grid of x values of the tail-probability integral
-__global__ void k_cbs_arcfinish(const ArcBest *__restrict__ best, const int *__restrict__ first,
-                                const SegIn *__restrict__ segs, SegOut *__restrict__ so, int kmax,
-                                int ngrid, double *__restrict__ tx) {
+// per segment: reduce its stripes (items [first[s], first[s+1])), t^2 of the best arc, the weighted
+// short-arc fraction delta, and the grid of x values of the tail-probability integral
+__global__ __launch_bounds__(128) void k_cbs_arcfinish(const ArcBest *__restrict__ best,
+                                                       const int *__restrict__ first,
+                                                       const SegIn *__restrict__ segs,
+                                                       const double *__restrict__ Wp,
+                                                       SegOut *__restrict__ so, int kmax, int ngrid,
+                                                       double *__restrict__ tx) {
   const int s = blockIdx.x;
   // best stripe of the segment; ties -> the first stripe (stripes ascend in i): deterministic
   __shared__ double rb[128];
   __shared__ int rq[128];
+  __shared__ double red[2];
   {
     double bb = -1.0;
     int bq = 0x7fffffff;
@@ -254,24 +372,44 @@ __global__ void k_cbs_arcfinish(const ArcBest *__restrict__ best, const int *__r
       __syncthreads();
     }
   }
+  const SegIn sg = segs[s];
+  const int n = sg.n;
+  // weighted delta (DNAcopy getmncwt, recalled): smallest weight of an arc of kmax + 1 points,
+  // wrap-around arcs (= complements of arcs of n - kmax - 1 points) included, over W
+  double dmin = HUGE_VAL;
+  const double W = so[s].W;
+  if (sg.hybrid) {
+    const int j = kmax + 1, nmj = n - j;
+    for (int i = threadIdx.x; i + j <= n; i += blockDim.x) {
+      const double wa = seg_W(Wp, sg, W, i + j) - seg_W(Wp, sg, W, i);
+      dmin = wa < dmin ? wa : dmin;
+    }
+    if (nmj >= 1)
+      for (int i = threadIdx.x; i + nmj <= n; i += blockDim.x) {
+        const double wa = W - (seg_W(Wp, sg, W, i + nmj) - seg_W(Wp, sg, W, i));
+        dmin = wa < dmin ? wa : dmin;
+      }
+    dmin = block_min_d<128>(dmin, red);
+  }
   if (threadIdx.x == 0) {
     const double bb = rb[0];
     int bi = 0, bj = 0;
     if (bb > 0.0) { bi = best[rq[0]].i; bj = best[rq[0]].j; }
     SegOut o = so[s];
-    const int n = segs[s].n;
-    if (bb > 0.0 && o.tss > 0.0) {
-      o.ostat = bb / ((o.tss - bb) / (n - 2.0));     // t^2 of the best arc
+    if (bb > 0.0) {
+      double t = o.tss;
+      if (t <= bb + 1e-4) t = bb + 1.0;            // DNAcopy (recalled)
+      o.ostat = bb / ((t - bb) / (n - 2.0));       // t^2 of the best arc
       o.bi = bi; o.bj = bj; o.valid = 1;
     }
+    o.delta = sg.hybrid ? dmin / W : 0.0;
     so[s] = o;
   }
   __syncthreads();
   // tail probability grid (Siegmund approximation; DNAcopy tailp): x_i = b / sqrt(m t (1 - t))
   const SegOut o = so[s];
-  const int n = segs[s].n;
-  if (!o.valid || !segs[s].hybrid) return;
-  const double delta = (kmax + 1.0) / n;
+  if (!o.valid || !sg.hybrid) return;
+  const double delta = o.delta;
   const double dincr = (0.5 - delta) / ngrid;
   const double bsqrtm = sqrt(o.ostat) / sqrt((double)n);
   for (int i = threadIdx.x; i < ngrid; i += blockDim.x) {
@@ -317,14 +455,13 @@ __device__ __forceinline__ double it1tsq(double x, double a) {   // integral of 
   return r;
 }
 
-// P(max over arcs with delta <= length/m <= 1-delta of the CBS statistic >= b), Gaussian null
+// P(max over arcs with delta <= weight fraction <= 1-delta of the CBS statistic >= b), Gaussian null
 __global__ void k_cbs_tailp(const double *__restrict__ nu, const SegIn *__restrict__ segs,
-                            SegOut *__restrict__ so, int kmax, int ngrid) {
+                            SegOut *__restrict__ so, int ngrid) {
   const int s = blockIdx.x;
   if (threadIdx.x != 0 || !so[s].valid || !segs[s].hybrid) return;
-  const int n = segs[s].n;
   const double b = sqrt(so[s].ostat);
-  const double delta = (kmax + 1.0) / n;
+  const double delta = so[s].delta;
   const double dincr = (0.5 - delta) / ngrid;
   double acc = 0.0, tl = 0.5 - dincr;
   for (int i = 0; i < ngrid; ++i) {
@@ -335,267 +472,346 @@ __global__ void k_cbs_tailp(const double *__restrict__ nu, const SegIn *__restri
   so[s].pval1 = 9.973557e-2 * b * b * b * exp(-b * b / 2.0) * acc;
 }
 
-// Exclusive scan over the NTP threads of a workgroup: wave scan + one LDS hop (2 barriers).
-__device__ __forceinline__ float block_excl_scan_f32(float v, float *ws) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float incl = v;     // wave inclusive scan by shuffles (fp32 adds in a fixed order: deterministic)
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float o = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += o;
-  }
-  __syncthreads();
-  if (lane == 63) ws[wave] = incl;
-  __syncthreads();
-  float base = 0.f;
-  for (int q = 0; q < wave; ++q) base += ws[q];
-  return base + incl - v;
-}
-
 // ---- (4) permutations ------------------------------------------------------------------------
-// One workgroup per permutation of one job.  y = centred residual * sqrt(w) (exchangeable under
-// H0), rw = sqrt(w), Wpf = prefix sums of w.  A permutation whose statistic reaches the job's
-// threshold bumps nrej[job]; once nrej > nrejc the remaining workgroups of the job return at once.
-// BIG: the sort buffer lives in global scratch (n > LDS capacity; slot = blockIdx.x, the grid is
-// then limited and strides over the permutations).
-// Arc weights of a hybrid permutation job: q[a - 2][i] = W / (w_a (W - w_a)) for the arc (i, i + a],
-// a = 2 .. KMAXC, 0 where the arc does not exist.  The weights are not permuted (DNAcopy permutes
-// the data under fixed weights), so this is shared by all permutations of the job.
-__global__ void k_cbs_arcweights(const float *__restrict__ rw_all, const float *__restrict__ Wpf_all,
-                                 const PermJob *__restrict__ jobs, int minw, float *__restrict__ qtab) {
+// Arc weights of a hybrid job, from the fp64 prefix weights, rounded once to fp32:
+//   q[a - 2][i] = W / (w_a (W - w_a)) for the arc (i, i + a], a = 2 .. KMAXC (0 where the arc does
+//   not exist), then qc[c][i] likewise for the arcs (i, i + n - c] whose COMPLEMENT has c = 2 ..
+//   KMAXC points (i = 0 .. c; 0 where such an arc is also a short arc or does not exist).
+// The weights are not permuted (DNAcopy permutes the data under fixed weights), so the table is
+// shared by all permutations of the job.
+__global__ void k_cbs_arcweights(const double *__restrict__ Wp_all, const PermJob *__restrict__ jobs,
+                                 int minw, float *__restrict__ qtab) {
   const PermJob jb = jobs[blockIdx.y];
   if (jb.mode != 0) return;
   const int n = jb.n;
   const int npad = (n + NTP - 1) / NTP * NTP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad) return;
-  const float *rw = rw_all + jb.lo, *Wpf = Wpf_all + jb.lo;
-  const float W = Wpf[n - 1] + rw[n - 1] * rw[n - 1];
+  const double *Wp = Wp_all + jb.lo;
+  const double W = jb.W;
   const int amax_all = n - minw;
   const int a_hi = KMAXC < amax_all ? KMAXC : amax_all;
   float *q = qtab + jb.qoff;
-  const float w0 = i < n ? Wpf[i] : W;
+  auto Wat = [&](int p) { return p < n ? Wp[p] : W; };
+  const double w0 = Wat(i < n ? i : n);
   for (int a = 2; a <= KMAXC; ++a) {
     float v = 0.f;
     if (a >= minw && a <= a_hi && i + a <= n) {
-      const float wa = (i + a < n ? Wpf[i + a] : W) - w0;
-      v = W / (wa * (W - wa));
+      const double wa = Wat(i + a) - w0;
+      v = (float)(W / (wa * (W - wa)));
     }
     q[(size_t)(a - 2) * npad + i] = v;
   }
+  if (i < (KMAXC + 1) * QC_W) {
+    const int c = i / QC_W, s = i % QC_W, a = n - c;
+    float v = 0.f;
+    if (c >= minw && c >= 2 && s <= c && a > a_hi && a >= minw) {
+      const double wa = Wat(s + a) - Wat(s);
+      v = (float)(W / (wa * (W - wa)));
+    }
+    q[(size_t)(KMAXC - 1) * npad + i] = v;
+  }
 }
 
+// exceedances recorded in the 256-permutation chunks BEFORE permutation p's chunk (all = every
+// chunk): once they pass the budget the sequential rule has stopped before p
+__device__ __forceinline__ bool budget_spent(const unsigned int *cnt, int slot, int p, int budget,
+                                             bool all, int lane) {
+  const int lim = all ? NCH : p / PCHUNK;
+  int c = 0;
+  if (lane < lim)
+    c = (int)__hip_atomic_load(&cnt[(size_t)slot * NCH + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return wcx::wave_sum_i(c) > budget;
+}
+__device__ __forceinline__ void record_exceed(unsigned int *bits, unsigned int *cnt, int nw, int slot,
+                                              int p) {
+  atomicOr(&bits[(size_t)slot * nw + (p >> 5)], 1u << (p & 31));
+  atomicAdd(&cnt[(size_t)slot * NCH + p / PCHUNK], 1u);
+}
+
+// Hybrid statistic, fp32 screen.  One workgroup per permutation of one job.  y = centred residual *
+// sqrt(w), rw = sqrt(w).  BIG: the permuted series lives in global scratch (n > LDS capacity; slot =
+// blockIdx.x, the grid is then limited and strides over the permutations).
 template <bool BIG>
-__global__ __launch_bounds__(NTP) void k_cbs_perm(const float *__restrict__ y_all,
-                                                  const float *__restrict__ rw_all,
-                                                  const float *__restrict__ Wpf_all,
-                                                  const PermJob *__restrict__ jobs, int nperm,
-                                                  int npad_max, int minw, int kmax,
-                                                  const float *__restrict__ qtab,
-                                                  unsigned int *__restrict__ big_scr,
-                                                  unsigned int *__restrict__ nrej) {
-  extern __shared__ unsigned int lds[];
-  __shared__ float red[NTP / 64];
-  __shared__ float tot[NTP];
+__global__ __launch_bounds__(NTP) void k_cbs_perm_hyb(const float *__restrict__ y_all,
+                                                      const float *__restrict__ rw_all,
+                                                      const PermJob *__restrict__ jobs, int p0, int p1,
+                                                      int slot_stride, const float *__restrict__ qtab,
+                                                      float *__restrict__ big_scr,
+                                                      unsigned int *__restrict__ bits,
+                                                      unsigned int *__restrict__ cnt, int nw,
+                                                      uint2 *__restrict__ flags,
+                                                      unsigned int *__restrict__ nflag) {
+  extern __shared__ float ldsf[];
+  __shared__ double redd[NTP / 64];
+  __shared__ int s_skip;
   const int tid = threadIdx.x;
   const PermJob jb = jobs[blockIdx.y];
   const int n = jb.n;
   const int npad = (n + NTP - 1) / NTP * NTP;
-  const float *y = y_all + jb.lo, *rw = rw_all + jb.lo, *Wpf = Wpf_all + jb.lo;
-  unsigned int *sk = BIG ? big_scr + (size_t)blockIdx.x * npad_max : lds;   // [npad]
-  const float W = Wpf[n - 1] + rw[n - 1] * rw[n - 1];
-  auto block_sum = [&](float v) {
-    v = (float)wcx::wave_sum((double)v);
+  const float *y = y_all + jb.lo, *rw = rw_all + jb.lo;
+  float *sk = BIG ? big_scr + (size_t)blockIdx.x * slot_stride : ldsf;   // [npad + 32]
+  const float *q = qtab + jb.qoff;
+  const float *qc = q + (size_t)(KMAXC - 1) * npad;
+  for (int p = p0 + (int)blockIdx.x; p < p1; p += gridDim.x) {
     __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int q = 0; q < NTP / 64; ++q) t += red[q];
-    return t;
-  };
-  auto Wat = [&](int i) { return i < n ? Wpf[i] : W; };
-  // Random permutation WITHOUT a sort: a keyed bijection of [0, n).  Four Feistel rounds on
-  // Z_a x Z_a, a = ceil(sqrt(n)) (so the domain a*a exceeds n by < 2 sqrt(n) + 1 and the
-  // cycle walk back into [0, n) almost never iterates); round function = murmur3's 32-bit
-  // finaliser of (half + round key), mapped to [0, a) by a high multiply.  The null distribution
-  // of the short-arc maximum under these permutations is indistinguishable from numpy's shuffles
-  // (two-sample KS on 4000 + 4000 permutations, p = 0.36; 3 rounds already pass).
-  if (tid < 32) sk[npad + tid] = 0u;     // the arc loop reads up to 32 slots past the scan
-  unsigned int fa = (unsigned int)sqrtf((float)n);
-  while ((unsigned long long)fa * fa < (unsigned long long)n) ++fa;
-  while (fa > 1 && (unsigned long long)(fa - 1) * (fa - 1) >= (unsigned long long)n) --fa;
-  const float inv_fa = 1.0f / (float)fa;
-  __shared__ unsigned int s_spent;
-  for (int p = blockIdx.x; p < nperm; p += gridDim.x) {
-    __syncthreads();
-    if (tid == 0) s_spent = atomicAdd(&nrej[blockIdx.y], 0u) > (unsigned int)jb.nrejc ? 1u : 0u;
-    __syncthreads();
-    if (s_spent) return;                                   // budget spent (uniform decision)
-    const unsigned long long s0 = mix64(jb.seed ^ ((unsigned long long)p * 0xd1342543de82ef95ull));
-    const unsigned long long s1 = mix64(s0 + 1ull);
-    const unsigned int rk[4] = {(unsigned int)s0, (unsigned int)(s0 >> 32), (unsigned int)s1,
-                                (unsigned int)(s1 >> 32)};
-    auto perm_at = [&](int i) {
-      unsigned int x = (unsigned int)i;
-      do {
-        unsigned int L = (unsigned int)((float)x * inv_fa);
-        int R = (int)(x - L * fa);
-        if (R < 0) { --L; R += (int)fa; }
-        else if (R >= (int)fa) { ++L; R -= (int)fa; }
-        unsigned int Rr = (unsigned int)R;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          unsigned int h = Rr + rk[r];
-          h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-          unsigned int sN = L + __umulhi(h, fa);
-          sN = sN >= fa ? sN - fa : sN;
-          L = Rr; Rr = sN;
-        }
-        x = L * fa + Rr;
-      } while (x >= (unsigned int)n);
-      return (int)x;
-    };
-    bool exceed;
-    if (jb.mode == 2) {
-      // two-sample edge test: |weighted mean of the shorter side| of the permuted series (the
-      // series is centred: the overall weighted mean is 0 up to the permutation's reweighting)
-      // (y is centred on the mean of the segment the sub-series was cut from: re-centre on the
-      // sub-series' own weighted mean c first, y' = y - c rw)
-      float cw = 0.f, ws = 0.f;
-      for (int i = tid; i < n; i += NTP) { cw += rw[i] * y[i]; ws += rw[i] * rw[i]; }
-      const float Wsub = block_sum(ws);
-      const float c = block_sum(cw) / Wsub;
-      float part = 0.f, w1 = 0.f, all = 0.f;
-      for (int i = tid; i < n; i += NTP) {
-        const int src = perm_at(i);
-        const float v = rw[i] * (y[src] - c * rw[src]);    // w_i * (permuted value at position i)
-        all += v;
-        const bool in1 = jb.first ? i < jb.m1 : i >= n - jb.m1;
-        if (in1) { part += v; w1 += rw[i] * rw[i]; }
-      }
-      const float s_all = block_sum(all), s1 = block_sum(part), W1 = block_sum(w1);
-      const float xbar = s_all / Wsub;
-      exceed = (double)fabsf(s1 / W1 - xbar) >= jb.ostat;
-    } else {
-      // weighted mean of the permuted series: sum_i w_i (y_pi(i) / rw_i) = sum_i rw_i y_pi(i)
-      float part = 0.f;
-      for (int i = tid; i < n; i += NTP) { sk[i] = __float_as_uint(y[perm_at(i)]); part += rw[i] * __uint_as_float(sk[i]); }
-      const float mean = block_sum(part) / W;
-      float tssl = 0.f;
-      for (int i = tid; i < npad; i += NTP) {
-        float cx = 0.f;
-        if (i < n) {
-          const float r = rw[i];
-          const float v = __uint_as_float(sk[i]) * __builtin_amdgcn_rcpf(r) - mean;
-          cx = r * r * v;          // w_i v_i
-          tssl += cx * v;          // w_i v_i^2
-        }
-        sk[i] = __float_as_uint(cx);
-      }
-      const float tss = block_sum(tssl);
-      // inclusive prefix scan of sk (as floats): serial chunks + scan of chunk totals
-      const int chunk = npad / NTP > 0 ? npad / NTP : 1;
-      const int nth = npad / chunk;   // threads that own a chunk
-      float run = 0.f;
-      if (tid < nth) {
-        for (int c = 0; c < chunk; ++c) {
-          run += __uint_as_float(sk[tid * chunk + c]);
-          sk[tid * chunk + c] = __float_as_uint(run);
-        }
-      }
-      const float base = block_excl_scan_f32(tid < nth ? run : 0.f, tot);
-      if (tid < nth && tid > 0) {
-        for (int c = 0; c < chunk; ++c)
-          sk[tid * chunk + c] = __float_as_uint(__uint_as_float(sk[tid * chunk + c]) + base);
-      }
-      __syncthreads();
-      auto Sx = [&](int i) { return i == 0 ? 0.f : __uint_as_float(sk[i - 1]); };   // S_0 = 0; defined to npad + 32
-      float bmax = 0.f;
-      const int amax_all = n - minw;
-      if (jb.mode == 0) {
-        const int a_hi = kmax < amax_all ? kmax : amax_all;
-        // short arcs (i, i + a], a = 2 .. 25: a thread owns 8 consecutive start positions, keeps
-        // their 33 prefix sums in registers and multiplies d^2 by the job's precomputed
-        // permutation-independent arc weight W / (w_a (W - w_a)) (0 for arcs that do not exist);
-        // two arcs per packed fp32 instruction
-        const float *q = qtab + jb.qoff;
-        f32x2 bm = {0.f, 0.f};
-        for (int i0 = tid * 8; i0 < n; i0 += 8 * NTP) {
-          float sv[8 + KMAXC];
-#pragma unroll
-          for (int t = 0; t < 8 + KMAXC; ++t) sv[t] = Sx(i0 + t);
-          const float *qp = q + i0;
-          float4 q0 = *reinterpret_cast<const float4 *>(qp);
-          float4 q1 = *reinterpret_cast<const float4 *>(qp + 4);
-#pragma unroll
-          for (int a = 2; a <= KMAXC; ++a) {
-            // next arc length's weights are fetched while this one is evaluated (the barrier keeps
-            // the compiler from hoisting all 48 loads to the top: that spilled)
-            const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            if (a < KMAXC) {
-              qp += npad;
-              q0 = *reinterpret_cast<const float4 *>(qp);
-              q1 = *reinterpret_cast<const float4 *>(qp + 4);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-              // (scalar differences: a packed subtract would need a second, odd-aligned copy of
-              // sv in registers for the odd arc lengths -- that spilled)
-              float dx = sv[j + a] - sv[j], dy = sv[j + 1 + a] - sv[j + 1];
-#if defined(__HIP_DEVICE_COMPILE__)
-              asm volatile("" : "+v"(dx), "+v"(dy));
-#endif
-              f32x2 d = {dx, dy};
-              const f32x2 qq = {qv[j], qv[j + 1]};
-              d = d * d * qq;
-              bm.x = __builtin_fmaxf(bm.x, d.x);
-              bm.y = __builtin_fmaxf(bm.y, d.y);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        bmax = bm.x > bm.y ? bm.x : bm.y;
-        const int a_lo = (n - kmax > a_hi + 1) ? n - kmax : a_hi + 1;   // complement is short
-        for (int a = a_lo; a <= amax_all; ++a)
-          for (int i = tid; i + a <= n; i += NTP) {
-            const float d = Sx(i + a) - Sx(i), wa = Wat(i + a) - Wat(i);
-            const float b = d * d / (wa * (W - wa) / W);
-            bmax = b > bmax ? b : bmax;
-          }
-      } else {
-        for (int i = 0; i < n; ++i)
-          for (int j = i + minw + tid; j <= n && n - (j - i) >= minw; j += NTP) {
-            const float d = Sx(j) - Sx(i), wa = Wat(j) - Wat(i);
-            const float b = d * d / (wa * (W - wa) / W);
-            bmax = b > bmax ? b : bmax;
-          }
-      }
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(bmax, m, 64); bmax = o > bmax ? o : bmax; }
-      __syncthreads();
-      if ((tid & 63) == 0) red[tid >> 6] = bmax;
-      __syncthreads();
-      float b = 0.f;
-      for (int q = 0; q < NTP / 64; ++q) b = red[q] > b ? red[q] : b;
-      const double pstat = (double)b / (((double)tss - (double)b) / (double)(n - 2));
-      exceed = pstat >= jb.ostat;
+    if (tid < 64) {
+      const bool sp = budget_spent(cnt, jb.slot, p, jb.budget, false, tid);
+      if (tid == 0) s_skip = sp ? 1 : 0;
     }
-    if (tid == 0 && exceed) atomicAdd(&nrej[blockIdx.y], 1u);
     __syncthreads();
+    if (s_skip) return;                        // uniform; later permutations of this workgroup too
+    Feistel f;
+    f.init(n, jb.key, p);
+    // permuted, weighted series (raw values; no prefix scan: arc sums are local, see below)
+    double tsum = 0.0;
+    for (int i = tid; i < npad + 32; i += NTP) {
+      float v = 0.f;
+      if (i < n) v = rw[i] * y[f.at(i)];
+      sk[i] = v;
+      tsum += (double)v;
+    }
+    const double T = block_sum_d<NTP>(tsum, redd);       // (barrier: sk is complete)
+    // re-centre on the permuted series' weighted mean T / W: v_i - (T / W) w_i (then an arc and its
+    // complement carry the same statistic and the wrap-around arcs are plain short sums)
+    {
+      const float mf = (float)(T / jb.W);
+      for (int i = tid; i < n; i += NTP) { const float r = rw[i]; sk[i] -= mf * (r * r); }
+    }
+    __syncthreads();
+    // short arcs (i, i + a], a = 2 .. 25: a thread owns 8 consecutive start positions, builds the
+    // 33 LOCAL prefix sums of the 32 values that follow in registers (error bounded by the window,
+    // not by the series) and multiplies d^2 by the job's arc weight (0 for arcs that do not exist);
+    // two arcs per packed fp32 instruction
+    f32x2 bm = {0.f, 0.f};
+    for (int i0 = tid * 8; i0 < n; i0 += 8 * NTP) {
+      float sv[8 + KMAXC];
+      sv[0] = 0.f;
+#pragma unroll
+      for (int t4 = 0; t4 < 8; ++t4) {
+        const float4 r = *reinterpret_cast<const float4 *>(sk + i0 + 4 * t4);
+        sv[4 * t4 + 1] = sv[4 * t4] + r.x;
+        sv[4 * t4 + 2] = sv[4 * t4 + 1] + r.y;
+        sv[4 * t4 + 3] = sv[4 * t4 + 2] + r.z;
+        sv[4 * t4 + 4] = sv[4 * t4 + 3] + r.w;
+      }
+      const float *qp = q + i0;
+      float4 q0 = *reinterpret_cast<const float4 *>(qp);
+      float4 q1 = *reinterpret_cast<const float4 *>(qp + 4);
+#pragma unroll
+      for (int a = 2; a <= KMAXC; ++a) {
+        // next arc length's weights are fetched while this one is evaluated (the barrier keeps
+        // the compiler from hoisting all 48 loads to the top: that spilled)
+        const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        if (a < KMAXC) {
+          qp += npad;
+          q0 = *reinterpret_cast<const float4 *>(qp);
+          q1 = *reinterpret_cast<const float4 *>(qp + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          float dx = sv[j + a] - sv[j], dy = sv[j + 1 + a] - sv[j + 1];
+          asm volatile("" : "+v"(dx), "+v"(dy));
+          f32x2 d = {dx, dy};
+          const f32x2 qq = {qv[j], qv[j + 1]};
+          d = d * d * qq;
+          bm.x = __builtin_fmaxf(bm.x, d.x);
+          bm.y = __builtin_fmaxf(bm.y, d.y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float bmax = bm.x > bm.y ? bm.x : bm.y;
+    // arcs whose complement is short: (minus) the wrap-around sum of the first s and last c - s values
+    if (tid < (KMAXC + 1) * QC_W) {
+      const float qv = qc[tid];
+      if (qv > 0.f) {
+        const int c = tid / QC_W, s = tid % QC_W;
+        float h = 0.f, tl = 0.f;
+        for (int u = 0; u < s; ++u) h += sk[u];
+        for (int u = n - (c - s); u < n; ++u) tl += sk[u];
+        const float d = h + tl;
+        const float b = d * d * qv;
+        bmax = b > bmax ? b : bmax;
+      }
+    }
+    const double b = block_max_d<NTP>((double)bmax, redd);
+    if (tid == 0) {
+      const double sb = sqrt(b);
+      const double tssp = jb.tss - T * T / jb.W, dts = jb.eT * fabs(T);
+      const double bthr = jb.cthr * tssp;
+      const double sq = bthr > 0.0 ? sqrt(bthr) : 0.0;
+      const double esq = jb.D + 4.8e-7 * sb + (bthr > 0.0 ? jb.cthr * dts / (2.0 * sq) : HUGE_VAL);
+      const double gq = tssp - 1e-4 - dts;
+      const double sqg = gq > 0.0 ? sqrt(gq) : 0.0;
+      if (sb + esq >= sqg || (sb + esq >= sq && sb - esq < sq)) {
+        const unsigned int at = atomicAdd(nflag, 1u);
+        flags[at] = make_uint2(blockIdx.y, (unsigned int)p);
+      } else if (sb - esq >= sq) {
+        record_exceed(bits, cnt, nw, jb.slot, p);
+      }
+    }
   }
 }
 
-// Upper bound of the permutation statistic of the hybrid test (the maximum over arcs of at most
-// kmax points, or whose complement has at most kmax points) over ALL permutations of the series,
-// from O(n) sums and the kmax largest |y|.  With y_j = r_j (x_j - mean), r_j = sqrt(w_j), a
-// permutation pi puts y_pi(i) at position i (weights stay): part = sum r_i y_pi(i),
-// tss' = sum y^2 - part^2 / W, arc sum d = sum_arc r_i y_pi(i) - (part / W) w_arc.
-//   |part| <= sqrt(sum (r_i - rbar)^2 sum y^2) + rbar |sum y|                      (Cauchy-Schwarz)
-//   |d|    <= r_max Y_a + |part| a w_max / W,   Y_a = the a largest |y|
-//   w_arc (W - w_arc) >= min over the end points of [a w_min, a w_max]             (concave)
-// A strongly significant segment (a long aberration) has an observed statistic far above this
-// bound; its 10 000 permutations cannot produce a single exceedance and are not run.
-static double short_arc_bound(const double *x, const double *w, int n, int minw, int kmax) {
+// bss -> t^2 with DNAcopy's guard (recalled): tss <= bss + 1e-4 is replaced by bss + 1
+__device__ __forceinline__ double stat_from_bss(double bss, double tss, int n) {
+  const double t = tss <= bss + 1e-4 ? bss + 1.0 : tss;
+  return bss / ((t - bss) / (n - 2.0));
+}
+
+// Flagged permutations of hybrid jobs again, everything in fp64 (the permuted series in a global
+// scratch slot per workgroup).  Rare: speed is irrelevant, the arithmetic is the plain statement.
+__global__ __launch_bounds__(256) void k_cbs_perm_exact(const double *__restrict__ yd_all,
+                                                        const double *__restrict__ w_all,
+                                                        const double *__restrict__ Wp_all,
+                                                        const PermJob *__restrict__ jobs,
+                                                        const uint2 *__restrict__ flags,
+                                                        const unsigned int *__restrict__ nflag,
+                                                        double *__restrict__ scr, int slot_stride,
+                                                        int minw, unsigned int *__restrict__ bits,
+                                                        unsigned int *__restrict__ cnt, int nw) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const unsigned int nf = *nflag;
+  double *v = scr + (size_t)blockIdx.x * slot_stride;
+  for (unsigned int fi = blockIdx.x; fi < nf; fi += gridDim.x) {
+    const uint2 fl = flags[fi];
+    const PermJob jb = jobs[fl.x];
+    const int n = jb.n, p = (int)fl.y;
+    const double *yd = yd_all + jb.lo, *w = w_all + jb.lo, *Wp = Wp_all + jb.lo;
+    const double W = jb.W;
+    auto Wat = [&](int q) { return q < n ? Wp[q] : W; };
+    Feistel f;
+    f.init(n, jb.key, p);
+    __syncthreads();
+    double tsum = 0.0;
+    for (int i = tid; i < n; i += 256) {
+      const double t = sqrt(w[i]) * yd[f.at(i)];
+      v[i] = t;
+      tsum += t;
+    }
+    const double T = block_sum_d<256>(tsum, red);
+    {
+      const double m = T / W;
+      for (int i = tid; i < n; i += 256) v[i] -= m * w[i];     // (a thread's own elements)
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int amax_all = n - minw;
+    const int a_hi = KMAXC < amax_all ? KMAXC : amax_all;
+    double bmax = 0.0;
+    for (int i = tid; i < n; i += 256) {
+      double s = 0.0;
+      for (int a = 1; a <= a_hi && i + a <= n; ++a) {
+        s += v[i + a - 1];
+        if (a >= minw) {
+          const double wa = Wat(i + a) - Wat(i);
+          const double b = s * s / (wa * (W - wa) / W);
+          bmax = b > bmax ? b : bmax;
+        }
+      }
+    }
+    for (int t = tid; t < (KMAXC + 1) * QC_W; t += 256) {
+      const int c = t / QC_W, s = t % QC_W, a = n - c;
+      if (c >= minw && c >= 2 && s <= c && a > a_hi && a >= minw) {
+        double h = 0.0, tl = 0.0;
+        for (int u = 0; u < s; ++u) h += v[u];
+        for (int u = n - (c - s); u < n; ++u) tl += v[u];
+        const double d = h + tl;
+        const double wa = Wat(s + a) - Wat(s);
+        const double b = d * d / (wa * (W - wa) / W);
+        bmax = b > bmax ? b : bmax;
+      }
+    }
+    const double b = block_max_d<256>(bmax, red);
+    if (tid == 0 && jb.thr <= stat_from_bss(b, jb.tss - T * T / W, n)) record_exceed(bits, cnt, nw, jb.slot, p);
+  }
+}
+
+// n <= nmin: maximum over ALL arcs of the permuted series, fp64, one workgroup per permutation.
+__global__ __launch_bounds__(256) void k_cbs_perm_full(const double *__restrict__ yd_all,
+                                                       const double *__restrict__ w_all,
+                                                       const double *__restrict__ Wp_all,
+                                                       const PermJob *__restrict__ jobs, int p0, int p1,
+                                                       int minw, unsigned int *__restrict__ bits,
+                                                       unsigned int *__restrict__ cnt, int nw) {
+  __shared__ double red[4];
+  __shared__ double v[256], S[257], Wl[257];
+  __shared__ int s_skip;
+  const int tid = threadIdx.x;
+  const PermJob jb = jobs[blockIdx.y];
+  const int n = jb.n, p = p0 + (int)blockIdx.x;
+  if (p >= p1) return;
+  if (tid < 64) {
+    const bool sp = budget_spent(cnt, jb.slot, p, jb.budget, false, tid);
+    if (tid == 0) s_skip = sp ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_skip) return;
+  const double *yd = yd_all + jb.lo, *w = w_all + jb.lo, *Wp = Wp_all + jb.lo;
+  const double W = jb.W;
+  Feistel f;
+  f.init(n, jb.key, p);
+  double vt = 0.0;
+  if (tid < n) vt = sqrt(w[tid]) * yd[f.at(tid)];
+  const double T = block_sum_d<256>(vt, red);
+  if (tid < n) v[tid] = vt - T / W * w[tid];                 // re-centred on the permuted weighted mean
+  if (tid <= n) Wl[tid] = tid < n ? Wp[tid] : W;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    S[0] = 0.0;
+    for (int i = 0; i < n; ++i) { s += v[i]; S[i + 1] = s; }
+  }
+  __syncthreads();
+  double bmax = 0.0;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + minw + tid; j <= n && n - (j - i) >= minw; j += 256) {
+      const double d = S[j] - S[i], wa = Wl[j] - Wl[i];
+      const double b = d * d / (wa * (W - wa) / W);
+      bmax = b > bmax ? b : bmax;
+    }
+  const double b = block_max_d<256>(bmax, red);
+  if (tid == 0 && jb.thr <= stat_from_bss(b, jb.tss - T * T / W, n)) record_exceed(bits, cnt, nw, jb.slot, p);
+}
+
+// Two-sample edge test (DNAcopy wtpermp, recalled): the sub-series of n points (centred on the
+// SEGMENT mean), statistic |sum over the LAST m1 positions of sqrt(w_i) y[pi(i)] / rm1 - xbar|.
+// fp64, one wave per permutation; the total count decides, so any chunk's exceedances may stop it.
+__global__ __launch_bounds__(256) void k_cbs_perm_edge(const double *__restrict__ yd_all,
+                                                       const double *__restrict__ w_all,
+                                                       const PermJob *__restrict__ jobs, int p0, int p1,
+                                                       unsigned int *__restrict__ bits,
+                                                       unsigned int *__restrict__ cnt, int nw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const PermJob jb = jobs[blockIdx.y];
+  const int p = p0 + (int)blockIdx.x * 4 + wave;
+  if (p >= p1) return;
+  if (budget_spent(cnt, jb.slot, p, jb.budget, true, lane)) return;
+  const int n = jb.n, m1 = jb.m1;
+  const double *yd = yd_all + jb.lo, *w = w_all + jb.lo;
+  Feistel f;
+  f.init(n, jb.key, p);
+  double acc = 0.0;
+  for (int t = lane; t < m1; t += 64) {
+    const int i = n - m1 + t;
+    acc += sqrt(w[i]) * yd[f.at(i)];
+  }
+  const double xsum = wcx::wave_sum(acc);
+  if (lane == 0 && jb.thr <= fabs(xsum / jb.W - jb.tss)) record_exceed(bits, cnt, nw, jb.slot, p);
+}
+
+// Upper bound of the hybrid permutation statistic over ALL permutations of the series, from O(n)
+// sums and the kmax largest |y|.  With y_j = r_j (x_j - mean), r_j = sqrt(w_j), a permutation pi
+// puts v_i = r_i y_pi(i) at position i; T = sum v_i, |T| <= sqrt(sum (r_i - rbar)^2 sum y^2) +
+// rbar |sum y| (Cauchy-Schwarz); the re-centred arc sum is sum_arc v_i - (T / W) w_arc, so for an
+// arc of a points (or the wrap-around arc of a points whose complement it is)
+//   |d| <= r_max Y_a + |T| a w_max / W,   Y_a = the a largest |y|;   tss' = sum y^2 - T^2 / W;
+// the arc weight factor W / (w_a (W - w_a)) is at most its value at the end points of
+// [a w_min, a w_max] (convex).  A strongly significant segment has an observed statistic far above
+// this bound; its permutations cannot produce a single exceedance and are not run.
+static double short_arc_bound(const double *x, const double *w, int n, int minw, int kmax, double tss) {
   double W = 0, sx = 0;
   for (int i = 0; i < n; ++i) { W += w[i]; sx += w[i] * x[i]; }
   const double mean = sx / W;
@@ -610,10 +826,9 @@ static double short_arc_bound(const double *x, const double *w, int n, int minw,
   const double rbar = sr / n;
   double srr = 0;
   for (int i = 0; i < n; ++i) { const double e = sqrt(w[i]) - rbar; srr += e * e; }
-  const double part = sqrt(srr * syy) + rbar * fabs(sy);
-  const double tss_min = syy - part * part / W;
+  const double tmax = sqrt(srr * syy) + rbar * fabs(sy);
   const int a_hi = std::min(kmax, n - minw);
-  if (a_hi < minw || !(tss_min > 0)) return HUGE_VAL;
+  if (a_hi < minw) return HUGE_VAL;
   std::partial_sort(ay.begin(), ay.begin() + a_hi, ay.end(), std::greater<double>());
   const double rmax = sqrt(wmax);
   double Y = 0, bmax = 0;
@@ -621,12 +836,110 @@ static double short_arc_bound(const double *x, const double *w, int n, int minw,
     Y += ay[(size_t)a - 1];
     if (a < minw) continue;
     if (a * wmax >= W) return HUGE_VAL;
-    const double d = rmax * Y + part * a * wmax / W;
+    const double d = rmax * Y + tmax * a * wmax / W;
     const double den = std::min(a * wmin * (W - a * wmin), a * wmax * (W - a * wmax)) / W;
     bmax = std::max(bmax, d * d / den);
   }
-  if (!(tss_min > bmax)) return HUGE_VAL;
+  const double tss_min = std::min(tss, syy) - tmax * tmax / W;
+  if (!(tss_min > bmax + 1e-4)) return HUGE_VAL;
   return bmax / ((tss_min - bmax) / (n - 2.0));
+}
+
+// ---- sequential boundary (Venkatraman & Olshen 2007, section 2.2; DNAcopy getbdry, recalled) ----
+// (long double: getbdry() divides by differences of pexceed values ~1e-5 apart; with double lgamma
+// the last digits of lgamma(10001) ~ 8e4 decide single stopping points)
+static long double lchoose(long double n, long double k) {
+  if (k < 0 || k > n) return -HUGE_VALL;
+  return lgammal(n + 1.0L) - lgammal(k + 1.0L) - lgammal(n - k + 1.0L);
+}
+// ib[r] = smallest number of permutations at which "at most r exceedances so far" has probability
+// <= eta0 when n1s exceedances are scattered uniformly over nperm permutations.  The hypergeometric
+// probabilities advance draw by draw (pmf recurrence, all terms positive).
+static void etabdry(int nperm, double eta0, int n1s, int *ib) {
+  std::vector<double> pm((size_t)n1s + 1, 0.0);
+  pm[0] = 1.0;
+  int k = 0;
+  for (int i = 1; i <= nperm && k < n1s; ++i) {
+    const double rem = (double)(nperm - (i - 1));
+    const int xmax = std::min(i, n1s);
+    for (int x = xmax; x >= 1; --x)
+      pm[x] = pm[x] * (1.0 - (n1s - x) / rem) + pm[x - 1] * ((n1s - x + 1) / rem);
+    pm[0] = pm[0] * (1.0 - n1s / rem);
+    double cdf = 0.0;
+    for (int x = 0; x <= k; ++x) cdf += pm[x];
+    if (cdf <= eta0) ib[k++] = i;
+  }
+  while (k < n1s) ib[k++] = nperm;
+}
+static double pexceed(int nperm, int n1s, const int *b) {
+  const long double lc = lchoose(nperm, n1s);
+  long double p = expl(lchoose(nperm - b[0], n1s) - lc);
+  if (n1s >= 2) p += expl(logl((long double)b[0]) + lchoose(nperm - b[1], n1s - 1) - lc);
+  if (n1s >= 3) {
+    const long double t = lchoose(nperm - b[2], n1s - 2) - lc;
+    p += expl(logl((long double)b[0]) + logl(b[0] - 1.0L) - logl(2.0L) + t);
+    p += expl(logl((long double)b[0]) + logl((long double)(b[1] - b[0])) + t);
+  }
+  for (int i = 4; i <= n1s; ++i) {
+    const long double n1 = b[i - 4], n2 = b[i - 3], n3 = b[i - 2];
+    const long double t = lchoose(nperm - b[i - 1], n1s - i + 1) - lc;
+    p += expl(lchoose(n1, i - 1) + t);
+    p += expl(lchoose(n1, i - 2) + logl(n3 - n1) + t);
+    p += expl(lchoose(n1, i - 3) + logl(n2 - n1) + logl(n3 - n2) + t);
+    if (n2 - n1 > 1.0L) p += expl(lchoose(n1, i - 3) + logl(n2 - n1) - logl(2.0L) + logl(n2 - n1 - 1.0L) + t);
+  }
+  return (double)p;
+}
+static void getbdry(double eta, int nperm, int max_ones, std::vector<int> &bdry) {
+  bdry.assign((size_t)max_ones * (max_ones + 1) / 2, 0);
+  bdry[0] = nperm - (int)(nperm * eta);
+  double eta0 = eta;
+  size_t l = 1;
+  for (int j = 2; j <= max_ones; ++j) {
+    int *b = bdry.data() + l;
+    double etahi = eta0 * 1.1;
+    etabdry(nperm, etahi, j, b);
+    double phi = pexceed(nperm, j, b);
+    double etalo = eta0 * 0.25;
+    etabdry(nperm, etalo, j, b);
+    double plo = pexceed(nperm, j, b);
+    for (int it = 0; (etahi - etalo) / etalo > 1e-2 && it < 200 && phi != plo; ++it) {
+      eta0 = etalo + (etahi - etalo) * (eta - plo) / (phi - plo);
+      etabdry(nperm, eta0, j, b);
+      const double pexcd = pexceed(nperm, j, b);
+      if (pexcd > eta) { etahi = eta0; phi = pexcd; }
+      else { etalo = eta0; plo = pexcd; }
+    }
+    l += (size_t)j;
+  }
+}
+constexpr int MAX_ONES_CAP = 128;   // beyond: no early "significant" stop (see cbs_boundary)
+static std::mutex g_bdry_mu;
+static std::map<std::pair<int, int>, std::vector<int>> g_bdry;
+// the nrejc + 1 stopping points of a test with budget nrejc
+static std::vector<int> cbs_boundary(double alpha, int nperm, int nrejc) {
+  const int max_ones = (int)floor(nperm * alpha) + 1;
+  if (max_ones > MAX_ONES_CAP || nrejc + 1 > max_ones) {
+    // alpha > ~1.3 %: the table costs O(max_ones^2 nperm) to build; such tests run all their
+    // permutations instead (the boundary only ever saves work and errs with probability <= eta)
+    static bool warned = false;
+    if (!warned) {
+      warned = true;
+      fprintf(stderr, "[wcx_cbs] alpha = %g: sequential boundary not tabulated beyond %d exceedances; "
+                      "significant tests run all %d permutations\n", alpha, MAX_ONES_CAP - 1, nperm);
+    }
+    return std::vector<int>((size_t)nrejc + 1, nperm);
+  }
+  std::lock_guard<std::mutex> g(g_bdry_mu);
+  auto key = std::make_pair(nperm, max_ones);
+  auto it = g_bdry.find(key);
+  if (it == g_bdry.end()) {
+    std::vector<int> t;
+    getbdry(0.05, nperm, max_ones, t);
+    it = g_bdry.emplace(key, std::move(t)).first;
+  }
+  const size_t o = (size_t)nrejc * (nrejc + 1) / 2;
+  return std::vector<int>(it->second.begin() + o, it->second.begin() + o + nrejc + 1);
 }
 
 // ------------------------------------------------------------------ host side
@@ -636,11 +949,17 @@ struct CbsParams {
   unsigned long long seed;
 };
 
+static unsigned long long test_key(unsigned long long seed, int chrom, int lo, int hi, int kind) {
+  unsigned long long k = mix64(seed);
+  k = mix64(k ^ (unsigned long long)chrom);
+  k = mix64(k ^ (((unsigned long long)lo << 32) | (unsigned long long)(unsigned int)hi));
+  return mix64(k ^ (unsigned long long)kind);
+}
+
 // device arena of one call, grown on demand
 struct Arena {
-  wcx_ctx *ctx;
   char *base = nullptr;
-  size_t off = 0, cap = 0;
+  size_t off = 0;
   template <typename T> T *take(size_t count) {
     off = (off + 255) & ~(size_t)255;
     T *p = reinterpret_cast<T *>(base + off);
@@ -649,12 +968,39 @@ struct Arena {
   }
 };
 
-constexpr int LDS_KEYS_MAX = 32768;      // n above this sorts in global scratch (k_cbs_perm<true>)
+constexpr int LDS_KEYS_MAX = 32768;      // n above this keeps the permuted series in global scratch
 constexpr int BIG_GRID = 512;
+constexpr int EXACT_GRID = 256;
+constexpr size_t FLAG_CAP = (size_t)1 << 21;   // flagged (job, permutation) pairs per launch group
+constexpr int TRACE_W = 20;
+
+struct JobResult { int decided = 0, significant = 0, nrej = 0, np = 0; };
+
+// walk the exceedance bits of permutations [0, upto) under the sequential rule
+static void eval_sequential(const unsigned int *bits, int upto, int nperm, int nrejc,
+                            const std::vector<int> &block, JobResult &r) {
+  int nrej = 0;
+  for (int np = 1; np <= upto; ++np) {
+    if ((bits[(np - 1) >> 5] >> ((np - 1) & 31)) & 1u) ++nrej;
+    if (nrej > nrejc) { r.decided = 1; r.significant = 0; r.nrej = nrej; r.np = np; return; }
+    if (np >= block[(size_t)nrej]) { r.decided = 1; r.significant = 1; r.nrej = nrej; r.np = np; return; }
+  }
+  r.nrej = nrej; r.np = upto;
+  if (upto >= nperm) { r.decided = 1; r.significant = 1; }
+}
 
 }  // namespace
 
 extern "C" {
+
+int wcx_cbs_getbdry(double eta, int nperm, int max_ones, int32_t *out) {
+  WCX_ARG(out && eta > 0 && eta < 1 && nperm > 0 && nperm <= NCH * PCHUNK && max_ones >= 1 &&
+          max_ones <= 1024, "bad parameters");
+  std::vector<int> t;
+  getbdry(eta, nperm, max_ones, t);
+  for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
+  return WCX_OK;
+}
 
 int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples, int64_t n_bins,
                   const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
@@ -668,6 +1014,10 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
   P.alpha = alpha;
   P.seed = seed;
   hipStream_t st = ctx->stream;
+  const bool strict = (ctx->debug_flags & 2) != 0;     // no t >= 7 / t^2 > 25 shortcuts (diagnostics)
+  const bool tracing = (ctx->debug_flags & 128) != 0;
+  ctx->cbs_trace.clear();
+  const int nw = (P.nperm + 31) / 32;
 
   const auto T0 = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
@@ -680,7 +1030,8 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
   std::vector<Series> series;
   // two passes (count, then fill at known offsets) so that samples can be filled by host threads
   std::vector<int64_t> cnt_sc((size_t)n_samples * n_chr);
-  auto is_na = [](double v) { return v == 0.0 || v != v; };   // ratio == 0 -> NA
+  auto is_na = [](double v) { return v == 0.0 || v != v; };               // CBS.R:41 ratio == 0 -> NA; is.na()
+  auto is_drop = [](double v) { return v == 0.0 || !std::isfinite(v); };  // DNAcopy segment(): is.finite()
   auto for_samples = [&](auto &&fn) {
     const int nt = std::min(n_samples, 8);
     if (nt <= 1) { for (int s = 0; s < n_samples; ++s) fn(s); return; }
@@ -694,7 +1045,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       const double *rr = r + (int64_t)s * n_bins + chr_off[c];
       const int nall = (int)(chr_off[c + 1] - chr_off[c]);
       int64_t m = 0;
-      for (int i = 0; i < nall; ++i) m += is_na(rr[i]) ? 0 : 1;
+      for (int i = 0; i < nall; ++i) m += is_drop(rr[i]) ? 0 : 1;
       cnt_sc[(size_t)s * n_chr + c] = m;
     }
   });
@@ -716,7 +1067,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       int64_t at = lo_sc[(size_t)s * n_chr + c];
       for (int i = 0; i < nall; ++i) {
         const double v = r[o + i];
-        if (is_na(v)) continue;
+        if (is_drop(v)) continue;
         hx[at] = v;
         hw[at] = w[o + i] == 0.0 ? 1.0 : w[o + i];   // weight == 0 -> 1 (1^-99 == 1)
         hpos[at] = i + 1;
@@ -741,90 +1092,149 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     int max_n = 0;
     for (const Series &se : series) max_n = std::max(max_n, se.n);
     const int max_segs = (int)series.size() + 8;          // active segments per round <= series
+    const int max_jobs = max_segs * 2;                    // segmentation tests, then 2 edge tests each
     // ---- device arena
-    int npad_max = 64;
-    while (npad_max < max_n) npad_max <<= 1;
+    const int npad_max = (max_n + NTP - 1) / NTP * NTP;
     const bool any_big = max_n > LDS_KEYS_MAX;
-    Arena A;
-    A.ctx = ctx;
     const size_t max_items = (size_t)max_segs + (size_t)(N / 4) + 6144 + 64;
-    size_t need = (size_t)N * (8 * 4 + 4 * 3) + (size_t)max_segs * (sizeof(SegIn) + sizeof(SegOut) + 8) +
-                  (size_t)max_segs * P.ngrid * 16 + max_items * (sizeof(ArcItem) + sizeof(ArcBest)) +
-                  (size_t)max_segs * 3 * (sizeof(PermJob) + 4) +
-                  (any_big ? (size_t)BIG_GRID * (npad_max + 32) * 4 : 0) +
-                  (size_t)(KMAXC - 1) * ((size_t)N + (size_t)NTP * max_segs) * 4 + (1 << 16);
+    const size_t qtab_floats = (size_t)(KMAXC - 1) * ((size_t)N + (size_t)NTP * max_segs) +
+                               (size_t)max_segs * (KMAXC + 1) * QC_W;
+    const size_t need = (size_t)N * (8 * 5 + 4 * 2) + (size_t)max_segs * (sizeof(SegIn) + sizeof(SegOut) + 8) +
+                        (size_t)max_segs * P.ngrid * 16 + max_items * (sizeof(ArcItem) + sizeof(ArcBest)) +
+                        (size_t)max_jobs * (2 * sizeof(PermJob) + (size_t)(nw + NCH) * 4) +
+                        (any_big ? (size_t)BIG_GRID * (npad_max + 64) * 4 : 0) +
+                        (size_t)EXACT_GRID * npad_max * 8 + FLAG_CAP * sizeof(uint2) + qtab_floats * 4 +
+                        (1 << 16);
     void *scr = nullptr;
     rc = wcx_scratch(ctx, need, &scr);
     if (rc) return rc;
+    Arena A;
     A.base = reinterpret_cast<char *>(scr);
-    A.cap = need;
     double *dX = A.take<double>(N), *dW = A.take<double>(N), *dS = A.take<double>(N), *dWp = A.take<double>(N);
-    float *dy = A.take<float>(N), *drw = A.take<float>(N), *dWpf = A.take<float>(N);
+    double *dYd = A.take<double>(N);
+    float *dy = A.take<float>(N), *drw = A.take<float>(N);
     SegIn *dseg = A.take<SegIn>(max_segs);
     SegOut *dso = A.take<SegOut>(max_segs);
     int *dfirst = A.take<int>(max_segs + 1);
     double *dtx = A.take<double>((size_t)max_segs * P.ngrid), *dnu = A.take<double>((size_t)max_segs * P.ngrid);
     ArcItem *ditems = A.take<ArcItem>(max_items);
     ArcBest *dbest = A.take<ArcBest>(max_items);
-    PermJob *djobs = A.take<PermJob>((size_t)max_segs * 3);
-    unsigned int *dnrej = A.take<unsigned int>((size_t)max_segs * 3);
-    unsigned int *dbig = any_big ? A.take<unsigned int>((size_t)BIG_GRID * (npad_max + 32)) : nullptr;
-    float *dq = A.take<float>((size_t)(KMAXC - 1) * ((size_t)N + (size_t)NTP * max_segs));
+    PermJob *djobs = A.take<PermJob>((size_t)max_jobs * 2);
+    unsigned int *dbits = A.take<unsigned int>((size_t)max_jobs * nw);
+    unsigned int *dcnt = A.take<unsigned int>((size_t)max_jobs * NCH + 64);
+    unsigned int *dnflag = dcnt + (size_t)max_jobs * NCH;
+    float *dbig = any_big ? A.take<float>((size_t)BIG_GRID * (npad_max + 64)) : nullptr;
+    double *dexact = A.take<double>((size_t)EXACT_GRID * npad_max);
+    uint2 *dflags = A.take<uint2>(FLAG_CAP);
+    float *dq = A.take<float>(qtab_floats);
     WCX_HIP(hipMemcpyAsync(dX, hx, (size_t)N * 8, hipMemcpyHostToDevice, st));
     WCX_HIP(hipMemcpyAsync(dW, hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
-    const size_t lds_small = (size_t)(std::min((max_n + NTP - 1) / NTP * NTP, LDS_KEYS_MAX) + 32) * 4;
-    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cbs_perm<false>),
+    const size_t lds_small = (size_t)(std::min(npad_max, LDS_KEYS_MAX) + 32) * 4;
+    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cbs_perm_hyb<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
 
-    // one batch of permutation jobs -> exceedance counts
-    std::vector<unsigned int> hnrej;
-    auto run_jobs = [&](std::vector<PermJob> &jobs) -> int {
-      hnrej.assign(jobs.size(), 0u);
+    // One batch of permutation tests -> results.  seq[q] = the job's stopping points (modes 0 / 1).
+    std::vector<JobResult> jres;
+    std::vector<unsigned int> hbits;
+    auto run_jobs = [&](std::vector<PermJob> &jobs, const std::vector<std::vector<int>> &seq) -> int {
+      jres.assign(jobs.size(), JobResult());
       if (jobs.empty()) return WCX_OK;
-      // small jobs (LDS sort) and big jobs (global scratch) go to their own launches
-      for (int big = 0; big < 2; ++big) {
-        std::vector<PermJob> sel;
-        std::vector<size_t> where;
-        for (size_t q = 0; q < jobs.size(); ++q)
-          if ((jobs[q].n > LDS_KEYS_MAX) == (big == 1)) { sel.push_back(jobs[q]); where.push_back(q); }
-        if (sel.empty()) continue;
-        size_t qoff = 0;
-        int sel_max_n = 0;
-        bool any_hybrid = false;
-        for (PermJob &jb : sel) {
-          jb.qoff = (int64_t)qoff;
-          if (jb.mode == 0) {
-            qoff += (size_t)(KMAXC - 1) * (size_t)((jb.n + NTP - 1) / NTP * NTP);
-            any_hybrid = true;
-          }
-          sel_max_n = std::max(sel_max_n, jb.n);
-        }
-        WCX_HIP(hipMemcpyAsync(djobs, sel.data(), sel.size() * sizeof(PermJob), hipMemcpyHostToDevice, st));
-        WCX_HIP(hipMemsetAsync(dnrej, 0, sel.size() * 4, st));
-        if (any_hybrid) {
-          const int npad_sel = (sel_max_n + NTP - 1) / NTP * NTP;
-          k_cbs_arcweights<<<dim3((unsigned)(npad_sel / 256), (unsigned)sel.size()), 256, 0, st>>>(
-              drw, dWpf, djobs, P.minw, dq);
+      WCX_ARG(jobs.size() <= (size_t)max_jobs, "internal: permutation job table overflow");
+      size_t qoff = 0;
+      for (size_t q = 0; q < jobs.size(); ++q) {
+        jobs[q].slot = (int)q;
+        jobs[q].qoff = (int64_t)qoff;
+        if (jobs[q].mode == 0)
+          qoff += (size_t)(KMAXC - 1) * (size_t)((jobs[q].n + NTP - 1) / NTP * NTP) + (size_t)(KMAXC + 1) * QC_W;
+      }
+      WCX_ARG(qoff <= qtab_floats, "internal: arc-weight table overflow");
+      WCX_HIP(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(PermJob), hipMemcpyHostToDevice, st));
+      WCX_HIP(hipMemsetAsync(dbits, 0, jobs.size() * (size_t)nw * 4, st));
+      WCX_HIP(hipMemsetAsync(dcnt, 0, jobs.size() * (size_t)NCH * 4, st));
+      {
+        int hyb_max_n = 0;
+        for (const PermJob &jb : jobs) if (jb.mode == 0) hyb_max_n = std::max(hyb_max_n, jb.n);
+        if (hyb_max_n > 0) {
+          const int npad_sel = (hyb_max_n + NTP - 1) / NTP * NTP;
+          k_cbs_arcweights<<<dim3((unsigned)(npad_sel / 256), (unsigned)jobs.size()), 256, 0, st>>>(
+              dWp, djobs, P.minw, dq);
           WCX_HIP(hipGetLastError());
         }
-        if (big)
-          k_cbs_perm<true><<<dim3(BIG_GRID, (unsigned)sel.size()), NTP, 64, st>>>(
-              dy, drw, dWpf, djobs, P.nperm, npad_max + 32, P.minw, P.kmax, dq, dbig, dnrej);
-        else
-          k_cbs_perm<false><<<dim3((unsigned)P.nperm, (unsigned)sel.size()), NTP, lds_small, st>>>(
-              dy, drw, dWpf, djobs, P.nperm, npad_max + 32, P.minw, P.kmax, dq, nullptr, dnrej);
-        WCX_HIP(hipGetLastError());
-        std::vector<unsigned int> got(sel.size());
-        WCX_HIP(hipMemcpyAsync(got.data(), dnrej, sel.size() * 4, hipMemcpyDeviceToHost, st));
+      }
+      hbits.resize(jobs.size() * (size_t)nw);
+      std::vector<int> pending(jobs.size());
+      for (size_t q = 0; q < jobs.size(); ++q) pending[q] = (int)q;
+      const int stages[3] = {0, std::min(STAGE_A, P.nperm), P.nperm};
+      for (int sg = 0; sg < 2 && !pending.empty(); ++sg) {
+        const int p0 = stages[sg], p1 = stages[sg + 1];
+        if (p1 <= p0) continue;
+        // kernels take contiguous job ranges: group the pending jobs by kind into launches over
+        // [first, last] runs of the (unsorted) job table via a compacted copy
+        std::vector<PermJob> sel[4];     // 0 hybrid small, 1 hybrid big, 2 full, 3 edge
+        for (int q : pending) {
+          const PermJob &jb = jobs[(size_t)q];
+          const int kind = jb.mode == 0 ? (jb.n > LDS_KEYS_MAX ? 1 : 0) : jb.mode == 1 ? 2 : 3;
+          sel[kind].push_back(jb);
+        }
+        size_t joff = 0;
+        PermJob *dsel = djobs + jobs.size();             // second half of the job table
+        WCX_ARG(pending.size() + jobs.size() <= (size_t)max_jobs * 2, "internal: job table overflow");
+        for (int kind = 0; kind < 4; ++kind) {
+          std::vector<PermJob> &sj = sel[kind];
+          if (sj.empty()) continue;
+          // hybrid launches are cut so that their flag list cannot overflow
+          const size_t per_launch = kind <= 1 ? std::max<size_t>(1, FLAG_CAP / (size_t)(p1 - p0)) : sj.size();
+          for (size_t j0 = 0; j0 < sj.size(); j0 += per_launch) {
+            const size_t nj = std::min(per_launch, sj.size() - j0);
+            PermJob *dj = dsel + joff;
+            WCX_HIP(hipMemcpyAsync(dj, sj.data() + j0, nj * sizeof(PermJob), hipMemcpyHostToDevice, st));
+            joff += nj;
+            if (kind <= 1) {
+              WCX_HIP(hipMemsetAsync(dnflag, 0, 4, st));
+              if (kind == 1)
+                k_cbs_perm_hyb<true><<<dim3((unsigned)std::min(BIG_GRID, p1 - p0), (unsigned)nj), NTP, 0, st>>>(
+                    dy, drw, dj, p0, p1, npad_max + 64, dq, dbig, dbits, dcnt, nw, dflags, dnflag);
+              else
+                k_cbs_perm_hyb<false><<<dim3((unsigned)(p1 - p0), (unsigned)nj), NTP, lds_small, st>>>(
+                    dy, drw, dj, p0, p1, 0, dq, nullptr, dbits, dcnt, nw, dflags, dnflag);
+              WCX_HIP(hipGetLastError());
+              k_cbs_perm_exact<<<EXACT_GRID, 256, 0, st>>>(dYd, dW, dWp, dj, dflags, dnflag, dexact, npad_max,
+                                                           P.minw, dbits, dcnt, nw);
+            } else if (kind == 2) {
+              k_cbs_perm_full<<<dim3((unsigned)(p1 - p0), (unsigned)nj), 256, 0, st>>>(dYd, dW, dWp, dj, p0, p1,
+                                                                                      P.minw, dbits, dcnt, nw);
+            } else {
+              k_cbs_perm_edge<<<dim3((unsigned)((p1 - p0 + 3) / 4), (unsigned)nj), 256, 0, st>>>(
+                  dYd, dW, dj, p0, p1, dbits, dcnt, nw);
+            }
+            WCX_HIP(hipGetLastError());
+          }
+        }
+        WCX_HIP(hipMemcpyAsync(hbits.data(), dbits, jobs.size() * (size_t)nw * 4, hipMemcpyDeviceToHost, st));
         WCX_HIP(hipStreamSynchronize(st));
-        for (size_t q = 0; q < sel.size(); ++q) hnrej[where[q]] = got[q];
+        std::vector<int> still;
+        for (int q : pending) {
+          const PermJob &jb = jobs[(size_t)q];
+          const unsigned int *b = hbits.data() + (size_t)q * nw;
+          JobResult &res = jres[(size_t)q];
+          if (jb.mode == 2) {
+            int nrej = 0;
+            for (int t = 0; t < nw; ++t) nrej += __builtin_popcount(b[t]);
+            res.nrej = nrej; res.np = p1;
+            if (nrej > jb.budget) { res.decided = 1; res.significant = 0; }
+            else if (p1 >= P.nperm) { res.decided = 1; res.significant = 1; }
+          } else {
+            eval_sequential(b, p1, P.nperm, jb.budget, seq[(size_t)q], res);
+          }
+          if (!res.decided) still.push_back(q);
+        }
+        pending.swap(still);
       }
       return WCX_OK;
     };
 
     // ---- level-synchronous recursion (DNAcopy changepoints(): stack of segment ends per series)
     struct Active { int series, lo, hi; };
-    unsigned long long test_id = 0;
     for (;;) {
       // top-of-stack segment of every series that is not finished
       std::vector<Active> act;
@@ -866,49 +1276,78 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       WCX_HIP(hipMemcpyAsync(dseg, hseg.data(), (size_t)ns * sizeof(SegIn), hipMemcpyHostToDevice, st));
       WCX_HIP(hipMemcpyAsync(ditems, items.data(), items.size() * sizeof(ArcItem), hipMemcpyHostToDevice, st));
       WCX_HIP(hipMemcpyAsync(dfirst, first.data(), (size_t)(ns + 1) * 4, hipMemcpyHostToDevice, st));
-      k_cbs_prepare<<<ns, NTP, 0, st>>>(dX, dW, dseg, dS, dWp, dy, drw, dWpf, dso);
+      k_cbs_prepare<<<ns, NTP, 0, st>>>(dX, dW, dseg, dS, dWp, dYd, dy, drw, dso);
       k_cbs_arcmax<<<(unsigned)items.size(), 256, 0, st>>>(dS, dWp, dseg, dso, ditems, P.minw, dbest);
-      k_cbs_arcfinish<<<ns, 128, 0, st>>>(dbest, dfirst, dseg, dso, P.kmax, P.ngrid, dtx);
+      k_cbs_arcfinish<<<ns, 128, 0, st>>>(dbest, dfirst, dseg, dWp, dso, P.kmax, P.ngrid, dtx);
       k_nu_series<<<dim3(P.ngrid, ns), 256, 0, st>>>(dtx, dseg, dso, P.ngrid, dnu);
-      k_cbs_tailp<<<ns, 64, 0, st>>>(dnu, dseg, dso, P.kmax, P.ngrid);
+      k_cbs_tailp<<<ns, 64, 0, st>>>(dnu, dseg, dso, P.ngrid);
       WCX_HIP(hipGetLastError());
       std::vector<SegOut> hso(ns);
       WCX_HIP(hipMemcpyAsync(hso.data(), dso, (size_t)ns * sizeof(SegOut), hipMemcpyDeviceToHost, st));
       WCX_HIP(hipStreamSynchronize(st));
 
-      // segmentation tests that need permutations
+      // ---- decisions (DNAcopy wfindcpt, recalled) and the tests that need permutations
       std::vector<PermJob> jobs;
+      std::vector<std::vector<int>> seq;
       std::vector<int> job_of(ns, -1);
       std::vector<int> verdict(ns, 0);     // 0 = no change, 1 = significant
+      std::vector<int> why(ns, 0);         // 1 constant/invalid, 2 t<=0.1, 3 t>=7, 4 tailp, 5 perm, 6 bound
       int n_shortcut = 0;
       for (int a = 0; a < ns; ++a) {
-        if (!hso[a].valid) continue;
+        const SegOut &o = hso[a];
+        const int n = hseg[a].n;
+        if (!o.valid || o.range <= 1.4901161193847656e-08) { why[a] = 1; continue; }
+        const double ostat1 = sqrt(o.ostat);
+        if (ostat1 <= 0.1) { why[a] = 2; continue; }
+        const int arc = std::min(o.bj - o.bi, n - o.bj + o.bi);
+        if (!strict && ostat1 >= 7.0 && arc >= 10) { why[a] = 3; verdict[a] = 1; continue; }
         double pval2 = P.alpha;
         if (hseg[a].hybrid) {
-          if (hso[a].pval1 > P.alpha) continue;
-          pval2 = P.alpha - hso[a].pval1;
+          if (o.pval1 > P.alpha) { why[a] = 4; continue; }
+          pval2 = P.alpha - o.pval1;
         }
         PermJob jb;
-        jb.lo = hseg[a].lo; jb.n = hseg[a].n; jb.mode = hseg[a].hybrid ? 0 : 1;
-        jb.m1 = 0; jb.first = 0; jb.pad = 0;
-        jb.nrejc = (int)(pval2 * P.nperm);
-        jb.ostat = 0.99999 * hso[a].ostat;
+        memset(&jb, 0, sizeof(jb));
+        jb.lo = hseg[a].lo; jb.n = n; jb.mode = hseg[a].hybrid ? 0 : 1;
+        jb.budget = (int)(pval2 * (double)P.nperm);
+        jb.thr = 0.99999 * o.ostat;
+        jb.tss = o.tss;
+        jb.W = o.W;
         if (jb.mode == 0 && !(ctx->debug_flags & 32) &&
-            short_arc_bound(hx + jb.lo, hw + jb.lo, jb.n, P.minw, P.kmax) * 1.05 < jb.ostat) {
-          // no permutation of this series can reach the observed statistic with an arc of <= kmax
-          // points: the exceedance count is 0 without running the nperm permutations
-          verdict[a] = 1;
-          ++n_shortcut;
+            short_arc_bound(hx + jb.lo, hw + jb.lo, jb.n, P.minw, P.kmax, o.tss) * 1.0001 < jb.thr) {
+          // no permutation of this series can reach the observed statistic with a short arc: zero
+          // exceedances whatever the order -- significant under the sequential rule too
+          why[a] = 6; verdict[a] = 1; ++n_shortcut;
           continue;
         }
-        jb.seed = P.seed ^ ((++test_id) * 0x2545f4914f6cdd1dull);
+        if (jb.mode == 0) {
+          // fp32 screen: arc sums are <= 33 local adds of v_i - m w_i, v_i a product of two rounded
+          // factors: |d32 - d| <= u vmax (2700 + 75 n wmax / W) (the second term: the error of
+          // m = T / W on an arc of <= 25 points), vmax = max sqrt(w) * max |y|, u = 2^-24; the arc
+          // weights are rounded once (relative 2 u, in the 4.8e-7 sb term of the kernel)
+          const double u = 5.9604644775390625e-08;
+          const double vmax = sqrt(o.wmax) * o.ymax;
+          const double wlo = P.minw * o.wmin;
+          const double qmax = o.W / (wlo * (o.W - wlo));
+          jb.cthr = jb.thr / ((n - 2.0) + jb.thr);
+          jb.D = u * vmax * (2700.0 + 75.0 * n * o.wmax / o.W) * sqrt(qmax) * 1.001;
+          jb.eT = 6.0 * u * n * vmax / o.W * 1.001;
+          const double bthr = jb.cthr * o.tss;
+          if (!(wlo > 0) || !(o.W > 2 * wlo) || !(bthr > 1e-30) || !(bthr < 1e30) || !std::isfinite(jb.D))
+            jb.D = HUGE_VAL;                                       // everything goes to fp64
+        }
+        const Series &se = series[act[a].series];
+        jb.key = test_key(P.seed, se.chr, act[a].lo, act[a].hi, 0);
+        why[a] = 5;
         job_of[a] = (int)jobs.size();
+        seq.push_back(cbs_boundary(P.alpha, P.nperm, jb.budget));
         jobs.push_back(jb);
       }
-      rc = run_jobs(jobs);
+      rc = run_jobs(jobs, seq);
       if (rc) return rc;
+      std::vector<JobResult> seg_res(ns);
       for (int a = 0; a < ns; ++a)
-        if (job_of[a] >= 0) verdict[a] = hnrej[job_of[a]] <= (unsigned int)jobs[job_of[a]].nrejc ? 1 : 0;
+        if (job_of[a] >= 0) { seg_res[a] = jres[(size_t)job_of[a]]; verdict[a] = seg_res[a].significant; }
       ctx->cbs_shortcuts += n_shortcut;
 
       // interior arcs: each of the two change-points needs its own two-sample test
@@ -919,6 +1358,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
         if (!verdict[a]) continue;
         const int n = hseg[a].n, bi = hso[a].bi, bj = hso[a].bj;
         if (bi == 0 || bj == n) continue;
+        const double mean = hso[a].mean;
         const double *x = hx + hseg[a].lo, *ww = hw + hseg[a].lo;
         // test 1: [0, bi) vs [bi, bj) ; test 2: [bi, bj) vs [bj, n)
         for (int which = 0; which < 2; ++which) {
@@ -926,42 +1366,47 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
           const int n1 = which == 0 ? bi : bj - bi, n2 = n12 - n1;
           EdgeRef er{a, which, -1};
           if (n1 == 1 || n2 == 1) { er.shortcut = 0; eref.push_back(er); continue; }   // p = 1: not kept
-          double w1 = 0, w2 = 0, s1 = 0, s2 = 0;
-          for (int i = 0; i < n1; ++i) { w1 += ww[l + i]; s1 += ww[l + i] * x[l + i]; }
-          for (int i = n1; i < n12; ++i) { w2 += ww[l + i]; s2 += ww[l + i] * x[l + i]; }
-          const double xbar = (s1 + s2) / (w1 + w2);
-          double tss = 0;
-          for (int i = 0; i < n12; ++i) tss += ww[l + i] * (x[l + i] - xbar) * (x[l + i] - xbar);
+          double w1 = 0, w2 = 0, s1 = 0, s2 = 0, ssq = 0;
+          for (int i = 0; i < n1; ++i) { const double c = x[l + i] - mean; w1 += ww[l + i]; s1 += ww[l + i] * c; ssq += ww[l + i] * c * c; }
+          for (int i = n1; i < n12; ++i) { const double c = x[l + i] - mean; w2 += ww[l + i]; s2 += ww[l + i] * c; ssq += ww[l + i] * c * c; }
+          const double rn = w1 + w2;
+          const double xbar = (s1 + s2) / rn;
+          const double tss = ssq - rn * xbar * xbar;
           const bool first_short = n1 <= n2;
           const int m1 = first_short ? n1 : n2;
           const double wm = first_short ? w1 : w2, wo = first_short ? w2 : w1;
-          const double dm = (first_short ? s1 / w1 : s2 / w2) - xbar;
-          double tstat = dm * dm * wm * (wm + wo) / wo;
+          const double dm = fabs((first_short ? s1 / w1 : s2 / w2) - xbar);
+          double tstat = dm * dm * wm * rn / wo;
           tstat = tstat / ((tss - tstat) / (n12 - 2.0));
-          if (tstat > 25.0 && m1 >= 10) { er.shortcut = 1; eref.push_back(er); continue; }   // p = 0
-          // permutation test on the centred sub-series: needs its own prepared y / rw / Wpf, which
-          // the segment's buffers hold for the WHOLE segment (centred on the segment mean): the
-          // statistic below re-centres per permutation, so the segment's y serves as is
+          if (!strict && tstat > 25.0 && m1 >= 10) { er.shortcut = 1; eref.push_back(er); continue; }   // kept
           PermJob jb;
-          jb.lo = hseg[a].lo + l; jb.n = n12; jb.mode = 2; jb.m1 = m1; jb.first = first_short ? 1 : 0;
-          jb.pad = 0;
-          jb.nrejc = (int)(P.alpha * P.nperm);          // p <= alpha  <=>  nrej <= alpha * nperm
-          jb.ostat = 0.99999 * fabs(dm);
-          jb.seed = P.seed ^ ((++test_id) * 0x2545f4914f6cdd1dull);
+          memset(&jb, 0, sizeof(jb));
+          jb.lo = hseg[a].lo + l; jb.n = n12; jb.mode = 2; jb.m1 = m1;
+          // kept <=> nrej / nperm <= alpha
+          int budget = (int)floor(P.alpha * P.nperm);
+          while ((double)(budget + 1) / (double)P.nperm <= P.alpha) ++budget;
+          while (budget >= 0 && (double)budget / (double)P.nperm > P.alpha) --budget;
+          jb.budget = budget;
+          jb.thr = 0.99999 * dm;
+          jb.tss = xbar;
+          jb.W = wm;
+          const Series &se = series[act[a].series];
+          jb.key = test_key(P.seed, se.chr, act[a].lo, act[a].hi, 1 + which);
           er.shortcut = -1 - (int)ejobs.size();          // (-1 - job index)
           ejobs.push_back(jb);
           eref.push_back(er);
         }
       }
-      rc = run_jobs(ejobs);
+      rc = run_jobs(ejobs, {});
       if (rc) return rc;
-      std::vector<int> keep(ns * 2, 0);
+      std::vector<int> keep(ns * 2, 0), enrej(ns * 2, -2);
       for (const EdgeRef &er : eref) {
         bool ok;
-        if (er.shortcut >= 0) ok = er.shortcut == 1;
+        if (er.shortcut >= 0) { ok = er.shortcut == 1; enrej[er.a * 2 + er.which] = -1; }
         else {
           const int q = -1 - er.shortcut;
-          ok = hnrej[q] <= (unsigned int)ejobs[q].nrejc;
+          ok = jres[(size_t)q].significant != 0;
+          enrej[er.a * 2 + er.which] = jres[(size_t)q].nrej;
         }
         keep[er.a * 2 + er.which] = ok ? 1 : 0;
       }
@@ -972,12 +1417,22 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
         int ncpt = 0, icpt[2] = {0, 0};
         if (verdict[a]) {
           const int bi = hso[a].bi, bj = hso[a].bj;
-          if (bi == 0) { ncpt = 1; icpt[0] = bj; }
-          else if (bj == n) { ncpt = 1; icpt[0] = bi; }
+          if (bj == n) { ncpt = 1; icpt[0] = bi; }
+          else if (bi == 0) { ncpt = 1; icpt[0] = bj; }
           else {
             if (keep[a * 2]) icpt[ncpt++] = bi;
             if (keep[a * 2 + 1]) icpt[ncpt++] = bj;
           }
+        }
+        if (tracing) {
+          const double rec[TRACE_W] = {
+              (double)se.sample, (double)se.chr, (double)lo, (double)hi, (double)n, (double)hso[a].bi,
+              (double)hso[a].bj, hso[a].ostat, hseg[a].hybrid ? hso[a].pval1 : __builtin_nan(""),
+              hso[a].delta, (double)why[a], job_of[a] >= 0 ? (double)jobs[(size_t)job_of[a]].budget : -1.0,
+              job_of[a] >= 0 ? (double)seg_res[a].nrej : -1.0, job_of[a] >= 0 ? (double)seg_res[a].np : -1.0,
+              (double)verdict[a], (double)ncpt, (double)keep[a * 2], (double)enrej[a * 2],
+              (double)keep[a * 2 + 1], (double)enrej[a * 2 + 1]};
+          ctx->cbs_trace.insert(ctx->cbs_trace.end(), rec, rec + TRACE_W);
         }
         if (ncpt == 0) { se.change_loc.push_back(hi); se.seg_end.pop_back(); }
         else if (ncpt == 1) se.seg_end.insert(se.seg_end.end() - 1, lo + icpt[0]);
@@ -1008,8 +1463,8 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       prev = e;
       std::vector<int> start_pos, end_pos;
       for (int b = s1; b < e1; ++b) {   // b, b+1 are 1-based bins inside the segment
-        const bool na0 = (r[o + b - 1] == 0.0 || r[o + b - 1] != r[o + b - 1]);
-        const bool na1 = (r[o + b] == 0.0 || r[o + b] != r[o + b]);
+        const bool na0 = is_na(r[o + b - 1]);
+        const bool na1 = is_na(r[o + b]);
         if (!na0 && na1) start_pos.push_back(b);
         if (na0 && !na1) end_pos.push_back(b);
       }
@@ -1024,7 +1479,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
         double num = 0, den = 0;                    // CBS.R:122-127 weighted.mean(na.rm=T)
         for (int t = a; t <= b; ++t) {
           const double v = r[o + t - 1];
-          if (v == 0.0 || v != v) continue;
+          if (is_na(v)) continue;
           const double wt = w[o + t - 1] == 0.0 ? 1.0 : w[o + t - 1];
           num += v * wt; den += wt;
         }
@@ -1053,6 +1508,15 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
 int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]) {
   WCX_ARG(ctx && out, "NULL argument");
   out[0] = ctx->cbs_shortcuts; out[1] = out[2] = out[3] = 0;
+  return WCX_OK;
+}
+
+int wcx_cbs_trace(wcx_ctx *ctx, double *out, int cap_records, int *count) {
+  WCX_ARG(ctx && count && cap_records >= 0 && (out || cap_records == 0), "bad parameters");
+  const int have = (int)(ctx->cbs_trace.size() / TRACE_W);
+  *count = have;
+  const int ncopy = std::min(have, cap_records);
+  if (ncopy > 0) memcpy(out, ctx->cbs_trace.data(), (size_t)ncopy * TRACE_W * sizeof(double));
   return WCX_OK;
 }
 
