@@ -109,6 +109,27 @@ def cpu_baseline(Xs, chr_cum, k, budget_s=10.0):
             "extrapolated_full_search_s": float(np.sum(mb * (B - mb))) / (pairs_py / dt_py)}
 
 
+def verify_rows(w, n_blocks=128, rows_per_block=16):
+    """Out of the timed region: the reference-bin tables of the LAST timed step against the C oracle
+    (oracle/wcx_oracle_tiled.c on the host's cores) on n_blocks x rows_per_block scattered target
+    rows, each against all its candidates -- indices and distances bit for bit."""
+    from oracle import c_oracle as CO
+    if w.last is None:
+        return None
+    rng = np.random.default_rng(11)
+    starts = np.sort(rng.choice(w.B - rows_per_block, n_blocks, replace=False))
+    t0 = time.perf_counter()
+    rows, oi, od = CO.topk_row_blocks_threaded(w.Xs_host, w.cum, starts, rows_per_block, w.k)
+    sel = w.torch.from_numpy(rows).to(w.last[0].device)
+    gi = w.last[0][sel].cpu().numpy()
+    gd = w.last[1][sel].cpu().numpy()
+    bad = int(np.count_nonzero((gi != oi).any(axis=1) | (gd != od).any(axis=1)))
+    return {"rows": int(len(rows)), "mismatches": bad, "seconds": time.perf_counter() - t0,
+            "what": "indices and distances of {} target rows ({} scattered blocks) of the last timed "
+                    "step, bit for bit against oracle/wcx_oracle_tiled.c on {} host threads (each row "
+                    "against all its candidates)".format(len(rows), n_blocks, max(1, (os.cpu_count() or 2) - 2))}
+
+
 class Workload:
     """Device-resident inputs and the step of one problem size."""
 
@@ -155,6 +176,7 @@ class Workload:
                                      "predict_full", "gather_ref")}
         self.fb_rows = []
         self.n_segments = 0
+        self.last = None                             # (idx, dist) of the last step, for verify_rows
 
     def step(self, record):
         wd, ctx, torch = self.wd, self.ctx, self.torch
@@ -173,6 +195,7 @@ class Workload:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         idx, dist_, nr = wd.gather_reference3(idx_l, dist_l, nr_l, self.B, self.world, self.backend)
+        self.last = (idx, dist_)
         if record and self.world > 1:
             torch.cuda.synchronize()
             self.ms["gather_ref"].append(1e3 * (time.perf_counter() - t0))
@@ -259,6 +282,7 @@ def main():
     ap.add_argument("--refsize", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the S=100 block")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run oracle check")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling ablations (invalid results)")
     args = ap.parse_args()
 
@@ -351,6 +375,8 @@ def main():
                             "roofline": {k_: r2[k_] for k_ in r2
                                          if k_ not in ("kernel", "attainable_note",
                                                        "fallback_rows_per_step")}}
+    if rank == 0 and not args.debug_flags and not args.no_verify:
+        out["verified"] = verify_rows(w)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w.Xs_host, w.cum, w.k)
     if rank == 0:

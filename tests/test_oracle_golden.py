@@ -133,6 +133,44 @@ def test_c_oracle_edge_cases(g_search, tag, cs, ce, k):
     assert np.array_equal(dist, g_search[tag + "_dist"])
 
 
+@pytest.mark.parametrize("tag", ["A", "A1", "F", "M", "M2"])
+def test_tiled_c_oracle_get_reference(g_search, tag):
+    """oracle/wcx_oracle_tiled.c (the cache-tiled, threaded verifier of the full-size GPU tests) vs the
+    reference's own get_reference output: bit-exact indices and distances."""
+    from oracle import c_oracle as CO
+    from oracle.wcx_oracle import get_part
+    g = g_search
+    mb = g[tag + "_mb"].tolist()
+    cum = np.cumsum(mb).tolist()
+    part, parts = g[tag + "_part"].tolist()
+    Xs = np.ascontiguousarray(g["Xs"][:, :cum[-1]])
+    s, e = get_part(part - 1, parts, cum[-1])
+    idx, dist = CO.get_reference_rows_threaded(Xs, cum, s, e, 40, threads=3, rows_per_task=17)
+    assert np.array_equal(idx, g[tag + "_idx"])
+    assert np.array_equal(dist, g[tag + "_dist"])
+
+
+@pytest.mark.parametrize("tag,cs,ce,k", [("tie", 20, 50, 25), ("few", 10, 18, 40), ("nan", 20, 30, 45)])
+def test_tiled_c_oracle_edge_cases_and_random(g_search, tag, cs, ce, k):
+    """The tiled variant on the tie / short / NaN fixtures, and == the per-row C oracle on a seeded
+    problem whose tiles, row blocks and chromosome gap do not line up with anything."""
+    from oracle import c_oracle as CO
+    Xs = np.ascontiguousarray(g_search[tag + "_Xs"])
+    S, B = Xs.shape
+    idx = np.empty((ce - cs, k), dtype=np.int32)
+    dist = np.empty((ce - cs, k))
+    assert CO.lib_tiled().wcxo_topk_rows_tiled(Xs.ctypes.data, B, S, cs, ce, cs, ce, k, idx.ctypes.data,
+                                               dist.ctypes.data) == 0
+    assert np.array_equal(idx, g_search[tag + "_idx"]) and np.array_equal(dist, g_search[tag + "_dist"])
+    rng = np.random.default_rng(k)
+    Xr = 1.0 + 0.05 * rng.standard_normal((37, 1500))
+    Xr[:, rng.integers(0, 1500, 40)] = Xr[:, rng.integers(0, 1500, 40)]      # duplicate rows: ties
+    cum = [401, 777, 1500]
+    i0, d0 = CO.get_reference_rows(Xr, cum, 0, 1500, 60)
+    i1, d1 = CO.get_reference_rows_threaded(Xr, cum, 0, 1500, 60, threads=4, rows_per_task=45)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+
+
 # ---- BASELINE config 1: predict one sample at 1 Mb bins vs a 50-sample reference ------------
 def _sha(a):
     import hashlib
