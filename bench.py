@@ -98,6 +98,13 @@ def cpu_baseline(Xs, chr_cum, k, budget_s=10.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt_c = time.perf_counter() - t0
+    # the cache-tiled C port on every host thread the cgroup allows (what a tuned CPU build would do)
+    nth = CO.host_threads()
+    starts = np.sort(rng.choice(B - 32, 4 * nth, replace=False))
+    t0 = time.perf_counter()
+    rows_mt, _, _ = CO.topk_row_blocks_threaded(Xs, chr_cum, starts, 32, k, threads=nth)
+    dt_mt = time.perf_counter() - t0
+    pairs_mt = sum(B - (own(int(t))[1] - own(int(t))[0]) for t in rows_mt)
     mb = np.diff(np.concatenate(([0], chr_cum)))
     return {"value": pairs_py / dt_py, "unit": "bin-pairs/s", "cores": 1, "kind": "port",
             "host_cores_available": os.cpu_count(),
@@ -106,6 +113,10 @@ def cpu_baseline(Xs, chr_cum, k, budget_s=10.0):
                       "single-threaded like the reference".format(n_py, B, Xs.shape[0], k, dt_py),
             "c_port": {"value": pairs_c / dt_c, "rows": n_c, "seconds": dt_c,
                        "what": "oracle/wcx_oracle.c, the same loop in C, 1 core"},
+            "c_port_tiled_mt": {"value": pairs_mt / dt_mt, "rows": int(len(rows_mt)), "seconds": dt_mt,
+                                "threads": nth,
+                                "what": "oracle/wcx_oracle_tiled.c (same arithmetic, cache-tiled) on the "
+                                        "host threads the cgroup CPU quota allows"},
             "extrapolated_full_search_s": float(np.sum(mb * (B - mb))) / (pairs_py / dt_py)}
 
 
@@ -127,7 +138,7 @@ def verify_rows(w, n_blocks=128, rows_per_block=16):
     return {"rows": int(len(rows)), "mismatches": bad, "seconds": time.perf_counter() - t0,
             "what": "indices and distances of {} target rows ({} scattered blocks) of the last timed "
                     "step, bit for bit against oracle/wcx_oracle_tiled.c on {} host threads (each row "
-                    "against all its candidates)".format(len(rows), n_blocks, max(1, (os.cpu_count() or 2) - 2))}
+                    "against all its candidates)".format(len(rows), n_blocks, CO.host_threads())}
 
 
 class Workload:

@@ -17,6 +17,23 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def host_threads():
+    """Worker threads worth starting: the CPUs this process may use, capped by the cgroup CPU quota
+    (the GPU boxes expose 256 CPUs under a 16-CPU quota; 254 busy threads are throttled to a third
+    of the throughput of 32)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, 2 * int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -83,7 +100,7 @@ def get_reference_rows_threaded(Xs, chr_cum, row_begin, row_end, k, threads=None
     Xs = np.ascontiguousarray(Xs, dtype=np.float64)
     S, B = Xs.shape
     n_chr = len(chr_cum)
-    threads = threads or max(1, (os.cpu_count() or 2) - 2)
+    threads = threads or host_threads()
     out_i = np.zeros((row_end - row_begin, k), dtype=np.int32)
     out_d = np.ones((row_end - row_begin, k), dtype=np.float64)
     fn = lib_tiled().wcxo_topk_rows_tiled
@@ -135,6 +152,6 @@ def topk_row_blocks_threaded(Xs, chr_cum, starts, rows_per_block, k, threads=Non
         i, d = idx[o:o + b - a], dist[o:o + b - a]
         if fn(Xs.ctypes.data, B, S, cs, ce, a, b, k, i.ctypes.data, d.ctypes.data):
             raise MemoryError("wcxo_topk_rows_tiled failed")
-    with ThreadPoolExecutor(max_workers=threads or max(1, (os.cpu_count() or 2) - 2)) as ex:
+    with ThreadPoolExecutor(max_workers=threads or host_threads()) as ex:
         list(ex.map(work, tasks))
     return rows, idx, dist

@@ -107,7 +107,8 @@ def bdry():
 
 @pytest.fixture(scope="module")
 def pool():
-    n = max(2, min(96, (os.cpu_count() or 4) - 2))
+    from oracle import c_oracle
+    n = max(2, min(96, c_oracle.host_threads()))
     with ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("spawn")) as ex:
         yield ex
 
