@@ -101,6 +101,23 @@ def test_predict_cli_tables(built, g_pipe):
     assert "Copy number profile abnormality (CPA) score" in stats
 
 
+@pytest.mark.parametrize("S", [1700, 2100])
+def test_pca_stage_large_cohort(S):
+    """cohorts beyond S = 1638 need more than the default 64 KB of dynamic LDS for the
+    eigenvectors (k_pca_comps) and fewer Gram slices; same agreement with the host PCA."""
+    from wisecondorx_amd import _lib, prep
+    rng = np.random.default_rng(S)
+    B = 900
+    load = rng.normal(size=(S, 5)) * np.array([5.0, 4.0, 3.0, 2.0, 1.4])   # five separated factors
+    fac = rng.normal(size=(5, B))
+    data = 1.0 + 0.01 * (load @ fac) + 0.002 * rng.normal(size=(S, B))
+    ctx = _lib.default_context(0)
+    Xh, ph = prep.train_pca(np.ascontiguousarray(data.T))
+    Xg, pg = prep.train_pca_gpu(data, ctx, sample_major=True)
+    np.testing.assert_allclose(pg.mean_, ph.mean_, rtol=1e-12)
+    np.testing.assert_allclose(Xg, Xh, rtol=1e-9)
+
+
 def test_pca_stage_on_gpu_matches_host(g_pipe):
     """f2: wcx_pca_begin/finish (Gram, components, reconstruction, ratio, distance profile on the
     device) vs prep.train_pca (host NumPy, itself pinned against scikit-learn's full-SVD PCA in

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from oracle import wcx_oracle as O
 
@@ -419,3 +420,31 @@ def test_post_process_fused_equals_the_step_by_step_path():
         np.testing.assert_array_equal(flat, np.concatenate(ref[key]))
         np.testing.assert_array_equal(pt._flatten(got, key, 2), np.concatenate(ref[key][:2]))
         np.testing.assert_array_equal(pt._flatten(ref, key), np.concatenate(ref[key]))
+
+
+def test_reference_npz_reader_detects_corruption(tmp_path):
+    """the direct reader of the big stored members verifies their CRC-32 (chunk CRCs from
+    the reader threads, combined) and their sizes, like zipfile would; the writer replaces the target
+    only after every write succeeded."""
+    import zlib
+    from wisecondorx_amd import npz_io
+    a, b = os.urandom(1000), os.urandom(777)
+    assert npz_io.crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    assert npz_io.crc32_combine(zlib.crc32(a), zlib.crc32(b""), 0) == zlib.crc32(a)
+    rng = np.random.default_rng(0)
+    arrs = {"indexes": rng.integers(0, 1000, (30000, 100)).astype(np.int32),
+            "distances": rng.random((30000, 100)), "binsize": np.array(15000)}
+    path = npz_io.save_npz(str(tmp_path / "ref.npz"), arrs)
+    assert sorted(os.listdir(tmp_path)) == ["ref.npz"]                 # no .tmp left behind
+    got = npz_io.load_reference(path)
+    assert np.array_equal(got["indexes"], arrs["indexes"]) and np.array_equal(got["distances"], arrs["distances"])
+    with np.load(path) as z:                                           # still an ordinary .npz
+        assert np.array_equal(z["distances"], arrs["distances"])
+    size = os.path.getsize(path)
+    with open(path, "r+b") as fh:                                      # flip one bit of a big member
+        fh.seek(size // 2)
+        c = fh.read(1)
+        fh.seek(size // 2)
+        fh.write(bytes([c[0] ^ 4]))
+    with pytest.raises(IOError, match="CRC-32 mismatch"):
+        npz_io.load_reference(path)

@@ -258,6 +258,10 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_ARG(B < (int64_t)0x7fffffff, "B must fit in int32 (indices are int32)");
   WCX_ARG(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
   WCX_HIP(hipSetDevice(ctx->device));
+  // A null-sample ranking that was started inside an EARLIER search and never consumed (that search
+  // or its caller failed before wcx_null_ratios_dev) must not be matched by device address later:
+  // a prepared ranking lives through one search at most.
+  if (ctx->rank_X && !ctx->rank_pending) ctx->rank_X = nullptr;
   const int64_t n_rows = row_end - row_begin;
   if (n_rows == 0) return WCX_OK;
 

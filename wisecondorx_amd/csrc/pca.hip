@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_pca_gram(const double *__restrict__ t,
   int ti = 0, rem = blockIdx.x;
   while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
   const int tj = ti + rem;
-  const int64_t per = (B + GSLICES - 1) / GSLICES;
+  const int64_t per = (B + gridDim.y - 1) / gridDim.y;
   const int64_t b_lo = (int64_t)blockIdx.y * per, b_hi = b_lo + per < B ? b_lo + per : B;
   __shared__ double sa[GK][GT + 1], sb[GK][GT + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_pca_gram(const double *__restrict__ t,
 
 // gram[i][j] = sum over slices (in order) of the upper-triangle partials; mirrored
 __global__ __launch_bounds__(256) void k_pca_gram_reduce(const double *__restrict__ partial, int S,
-                                                         double *__restrict__ gram) {
+                                                         int slices, double *__restrict__ gram) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)S * S) return;
   const int i = (int)(e / S), j = (int)(e % S);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_pca_gram_reduce(const double *__restric
   // tiles with ti <= tj only were written: (a, b) with a <= b lies in such a tile unless both fall
   // into the same tile with a > b -- impossible here
   double s = 0.0;
-  for (int q = 0; q < GSLICES; ++q) s += partial[(int64_t)q * S * S + (int64_t)a * S + b];
+  for (int q = 0; q < slices; ++q) s += partial[(int64_t)q * S * S + (int64_t)a * S + b];
   gram[e] = s;
 }
 
@@ -210,19 +210,23 @@ int wcx_pca_begin(wcx_ctx *ctx, const double *t_data, int64_t B, int S, double *
   double *dt = reinterpret_cast<double *>(ctx->d_pca);
   double *dmean = dt + (size_t)S * B * 2;
   const int ntile = (S + GT - 1) / GT;
-  const size_t part_b = (size_t)GSLICES * S * S * 8;
+  // slices of the bin range reduced in a fixed order (bit-reproducible for a given S): 64 for the
+  // cohorts the reference is built from; fewer for very large cohorts, whose S x S partials would
+  // otherwise take GSLICES * S^2 * 8 bytes (8.6 GB at S = 4096)
+  const int slices = S <= 1024 ? GSLICES : S <= 2048 ? 16 : 4;
+  const size_t part_b = (size_t)slices * S * S * 8;
   void *scr = nullptr;
   int rc = wcx_scratch(ctx, part_b + (size_t)S * S * 8 + 256, &scr);
   if (rc) return rc;
   double *dpart = reinterpret_cast<double *>(scr);
-  double *dgram = dpart + (size_t)GSLICES * S * S;
+  double *dgram = dpart + (size_t)slices * S * S;
   WCX_HIP(hipMemcpyAsync(dt, t_data, tb, hipMemcpyHostToDevice, st));
   rc = wcx_timer_begin(ctx, "pca_gram");
   if (rc) return rc;
   k_pca_mean<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(dt, B, S, dmean);
-  k_pca_gram<<<dim3((unsigned)(ntile * (ntile + 1) / 2), GSLICES), 256, 0, st>>>(dt, dmean, B, S, ntile,
-                                                                                 dpart);
-  k_pca_gram_reduce<<<(unsigned)(((int64_t)S * S + 255) / 256), 256, 0, st>>>(dpart, S, dgram);
+  k_pca_gram<<<dim3((unsigned)(ntile * (ntile + 1) / 2), (unsigned)slices), 256, 0, st>>>(dt, dmean, B, S, ntile,
+                                                                                          dpart);
+  k_pca_gram_reduce<<<(unsigned)(((int64_t)S * S + 255) / 256), 256, 0, st>>>(dpart, S, slices, dgram);
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "pca_gram");
   if (rc) return rc;
@@ -258,6 +262,10 @@ int wcx_pca_finish(wcx_ctx *ctx, const double *u, const double *sv, int ncomp, d
   rc = wcx_timer_begin(ctx, "pca_apply");
   if (rc) return rc;
   const unsigned gb = (unsigned)((B + 255) / 256);
+  // the eigenvectors sit in LDS: S * 5 * 8 bytes, beyond the default 64 KB from S = 1639 (160 KB
+  // = the CU's LDS at the S = 4096 limit of wcx_pca_begin)
+  WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pca_comps<5>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)S * 5 * 8)));
   k_pca_comps<5><<<gb, 256, (size_t)S * 5 * 8, st>>>(dt, dmean, du, dsv, B, S, dcomps);
   k_pca_transform<5><<<S, 1024, 0, st>>>(dt, dmean, dcomps, B, dtr);
   k_pca_correct<5><<<dim3(gb, (unsigned)S), 256, 0, st>>>(dt, dmean, dcomps, dtr, B, dX);
@@ -275,6 +283,15 @@ int wcx_pca_finish(wcx_ctx *ctx, const double *u, const double *sv, int ncomp, d
   if (dist_to_med_out)
     WCX_HIP(hipMemcpyAsync(dist_to_med_out, dd2m, (size_t)B * 8, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipStreamSynchronize(st));
+  if (dist_to_med_out) {
+    // np.median (newref_control.py:40), not nanmedian: one NaN in a sample's column makes that
+    // sample's median NaN and with it EVERY bin's distance (the filter then drops nothing).  A NaN
+    // in X shows up as a NaN distance of its own bin.
+    bool any_nan = false;
+    for (int64_t b = 0; b < B && !any_nan; ++b) any_nan = dist_to_med_out[b] != dist_to_med_out[b];
+    if (any_nan)
+      for (int64_t b = 0; b < B; ++b) dist_to_med_out[b] = __builtin_nan("");
+  }
   return WCX_OK;
 }
 

@@ -535,19 +535,25 @@ __global__ __launch_bounds__(1024) void k_nanmean1(const double *__restrict__ w,
                                                    double *__restrict__ out) {
   __shared__ double ss[16];
   __shared__ double sc[16];
-  double s = 0.0, c = 0.0;
+  __shared__ double sb[16];
+  double s = 0.0, c = 0.0, bad = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) {
     const double v = w[i];
     if (v == v) { s += v; c += 1.0; }
+    if (!(v - v == 0.0)) bad += 1.0;                         // NaN or +-inf
   }
   s = wcx::wave_sum(s);
   c = wcx::wave_sum(c);
-  if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; }
+  bad = wcx::wave_sum(bad);
+  if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; sb[threadIdx.x >> 6] = bad; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0;
-    for (int q = 0; q < 16; ++q) { a += ss[q]; b += sc[q]; }
-    out[0] = a / b;
+    double a = 0.0, b = 0.0, nb = 0.0;
+    for (int q = 0; q < 16; ++q) { a += ss[q]; b += sc[q]; nb += sb[q]; }
+    const double m = a / b;
+    out[0] = m;
+    // main.py:252-256: any NaN / inf in w / nanmean(w) -> all weights 1 ("reference too small")
+    out[1] = (nb > 0.0 || !(m - m == 0.0) || m == 0.0) ? 1.0 : 0.0;
   }
 }
 
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(256) void k_post_process(
   const int64_t p = pos[i];
   full[p] = lr;
   full[n_bins + p] = good ? z[i] - m_z[0] : 0.0;
-  full[2 * n_bins + p] = good ? w[i] / wmean[0] : 0.0;
+  full[2 * n_bins + p] = good ? (wmean[1] != 0.0 ? 1.0 : w[i] / wmean[0]) : 0.0;
 }
 
 }  // namespace

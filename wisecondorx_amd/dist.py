@@ -237,8 +237,9 @@ def predict_one_dev(backend, idx, dist, nr, d_x, B, k, chr_cum, rem_input, pt):
     mask = np.asarray(rem_input["mask"], dtype=bool)
     n_bins = len(mask)
     cache = getattr(backend, "_predict_bufs", None)
-    if cache is None or cache["key"] != (B, n_bins, id(rem_input["mask"])):
-        cache = {"key": (B, n_bins, id(rem_input["mask"])),
+    key = (B, n_bins, hash(mask.tobytes()))      # the mask's CONTENT: ids are reused after collection
+    if cache is None or cache["key"] != key:
+        cache = {"key": key,
                  "pos": torch.from_numpy(np.flatnonzero(mask).astype(np.int32)).to(dev),
                  "host": torch.empty((3, n_bins), dtype=torch.float64).pin_memory(),
                  "out": torch.empty((4, B), dtype=torch.float64, device=dev),

@@ -265,12 +265,22 @@ def tool_test(args):
     m_lr = res_a[4]
     n_aut_masked = int(np.sum(ref_file["mask"]))
     n_aut = int(np.sum(ref_file["bins_per_chr"]))
-    if int(np.sum(ref_file["mask" + ap][:n_aut])) != n_aut_masked:
+    mask_aut, mask_gon_aut = np.asarray(ref_file["mask"])[:n_aut], np.asarray(ref_file["mask" + ap])[:n_aut]
+    if int(np.sum(mask_gon_aut)) != n_aut_masked:
+        # upstream walks the merged vector through mask{ap} bin by bin (predict_tools.py:163-170):
+        # with fewer autosomal bins there it shifts every later bin silently, with more it raises
+        # IndexError -- neither is a result worth reproducing
         logging.critical("Reference mask{} holds {} autosomal bins but the autosomal reference {}: "
                          "the reference was built with a PCA-distance filter skew "
-                         "(newref_control.py:51-54) and cannot be aligned".format(
-                             ap, int(np.sum(ref_file["mask" + ap][:n_aut])), n_aut_masked))
-        sys.exit()
+                         "(newref_control.py:51-54) and cannot be aligned; rebuild it with this "
+                         "newref (or upstream's after removing the skewed samples)".format(
+                             ap, int(np.sum(mask_gon_aut)), n_aut_masked))
+        sys.exit(1)
+    if not np.array_equal(mask_gon_aut, mask_aut):
+        logging.warning("Reference mask{} keeps the same NUMBER of autosomal bins as the autosomal "
+                        "reference but at {} different positions: autosomal results are reported "
+                        "at the positions of mask{} (as upstream does)".format(
+                            ap, int(np.sum(mask_gon_aut != mask_aut)), ap))
     r, z, w, ref_sizes, weights_ok = pt.merge_autosomes_gonosomes(res_a, res_g)
     if not weights_ok:       # main.py:252-256
         logging.warning("Non-numeric values found in weights -- reference too small. "

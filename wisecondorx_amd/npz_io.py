@@ -11,7 +11,9 @@ CLI's wall-clock once the search runs on the GPU, so both go around `zipfile` fo
                   them with positional writes from those threads; small members are deflated.
                   The result is an ordinary ZIP (ZIP64 records when needed).
   load_reference  reads stored `.npy` members straight into their arrays (readinto from worker
-                  threads, no CRC pass); anything else goes through np.load.
+                  threads); their CRC-32 is checked like zipfile would -- per chunk on the reader
+                  threads, combined with crc32_combine (WCX_NPZ_NO_CRC=1 skips it) -- and their
+                  sizes against the file; anything else goes through np.load.
 """
 import io
 import os
@@ -89,7 +91,11 @@ def save_npz(path, arrays, compress_small=True):
         m["data_off"] = off + m["lhdr_len"]
         off = m["data_off"] + m["csize"]
     cd_off = off
+    # written next to the target and renamed once EVERY write has succeeded: a failed write (disk
+    # full) must not leave a plausible-looking archive behind
+    final_path, path = path, str(path) + ".tmp"
     fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    ok = False
     try:
         with ThreadPoolExecutor(max_workers=_THREADS) as ex:
             # payload writes (positional, in pieces) and the CRC-32 of each stored member run side
@@ -108,20 +114,21 @@ def save_npz(path, arrays, compress_small=True):
             for m in members:
                 # ZIP64 extra field of the local header: uncompressed, compressed size
                 extra = struct.pack("<HHQQ", 1, 16, m["usize"], m["csize"]) if m["z64"] else b""
-                lhdr = struct.pack("<IHHHHHIIIHH", 0x04034b50, 45 if m["z64"] else 20, 0, m["method"],
+                flag = 0 if m["name"].isascii() else 0x800     # bit 11: the name is UTF-8
+                lhdr = struct.pack("<IHHHHHIIIHH", 0x04034b50, 45 if m["z64"] else 20, flag, m["method"],
                                    _DOS_TIME, _DOS_DATE, m["crc"],
                                    0xFFFFFFFF if m["z64"] else m["csize"],
                                    0xFFFFFFFF if m["z64"] else m["usize"], len(m["name"]),
                                    len(extra)) + m["name"] + extra
                 assert len(lhdr) == m["lhdr_len"]
-                os.pwrite(fd, lhdr + m["head"], m["offset"])
+                _pwrite_all(fd, memoryview(lhdr + m["head"]), m["offset"])
                 fields = []
                 if m["z64"]:
                     fields += [m["usize"], m["csize"]]
                 if m["offset"] >= _Z64:
                     fields.append(m["offset"])
                 extra = struct.pack("<HH" + "Q" * len(fields), 1, 8 * len(fields), *fields) if fields else b""
-                cd += struct.pack("<IHHHHHHIIIHHHHHII", 0x02014b50, 45, 45 if fields else 20, 0,
+                cd += struct.pack("<IHHHHHHIIIHHHHHII", 0x02014b50, 45, 45 if fields else 20, flag,
                                   m["method"], _DOS_TIME, _DOS_DATE, m["crc"],
                                   0xFFFFFFFF if m["z64"] else m["csize"],
                                   0xFFFFFFFF if m["z64"] else m["usize"], len(m["name"]), len(extra),
@@ -137,12 +144,20 @@ def save_npz(path, arrays, compress_small=True):
                                 min(len(members), 0xFFFF),
                                 0xFFFFFFFF if len(cd) >= _Z64 else len(cd),
                                 0xFFFFFFFF if cd_off >= _Z64 else cd_off, 0)
-            os.pwrite(fd, cd + tail, cd_off)
+            _pwrite_all(fd, memoryview(cd + tail), cd_off)
             for f in futs:
                 f.result()
+        ok = True
     finally:
         os.close(fd)
-    return path
+        if ok:
+            os.replace(path, final_path)
+        else:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+    return final_path
 
 
 def _pwrite_all(fd, view, offset):
@@ -169,7 +184,8 @@ def save_sample(path, sample, binsize, quality=None):
     np.savez_compressed(path, binsize=binsize, sample=sample, quality=quality or {})
 
 
-def _read_into(path, offset, view):
+def _read_into(path, offset, view, want_crc=False):
+    crc = 0
     with open(path, "rb", buffering=0) as fh:
         fh.seek(offset)
         done = 0
@@ -177,14 +193,53 @@ def _read_into(path, offset, view):
             n = fh.readinto(view[done:done + (64 << 20)])
             if not n:
                 raise IOError("short read in {}".format(path))
+            if want_crc:
+                crc = zlib.crc32(view[done:done + n], crc)
             done += n
+    return crc
+
+
+def _gf2_times(mat, vec):
+    s, i = 0, 0
+    while vec:
+        if vec & 1:
+            s ^= mat[i]
+        vec >>= 1
+        i += 1
+    return s
+
+
+def crc32_combine(crc1, crc2, len2):
+    """CRC-32 of A + B from crc32(A), crc32(B) and len(B) (zlib's crc32_combine: the operator that
+    appends len2 zero bytes, by repeated squaring in GF(2))."""
+    if len2 <= 0:
+        return crc1
+    odd = [0xEDB88320] + [1 << n for n in range(31)]          # one zero BIT
+    even = [_gf2_times(odd, odd[n]) for n in range(32)]       # two
+    odd = [_gf2_times(even, even[n]) for n in range(32)]      # four
+    while True:
+        even = [_gf2_times(odd, odd[n]) for n in range(32)]   # first pass: one zero BYTE
+        if len2 & 1:
+            crc1 = _gf2_times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = [_gf2_times(even, even[n]) for n in range(32)]
+        if len2 & 1:
+            crc1 = _gf2_times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
 
 
 def load_reference(path):
     """All members of a reference .npz as a dict.  Stored (uncompressed) numeric members are read
-    straight into their arrays by worker threads; the rest (small deflated or pickled members)
-    goes through np.load."""
+    straight into their arrays by worker threads (sizes checked against the file, CRC-32 against
+    the directory); the rest (small deflated or pickled members) goes through np.load."""
     out, direct = {}, []
+    check_crc = os.environ.get("WCX_NPZ_NO_CRC", "") in ("", "0")
+    fsize = os.path.getsize(path)
     with zipfile.ZipFile(path) as zf, open(path, "rb") as fh:
         for info in zf.infolist():
             if not info.filename.endswith(".npy"):
@@ -207,18 +262,30 @@ def load_reference(path):
             if dtype.hasobject:
                 continue
             arr = np.empty(shape, dtype=dtype, order="F" if fortran else "C")
-            direct.append((key, arr, fh.tell()))
+            head_len = fh.tell() - data_off
+            if head_len + arr.nbytes != info.file_size or data_off + info.file_size > fsize:
+                raise IOError("{}: member {} is truncated or its sizes disagree ({} + {} bytes announced, "
+                              "{} stored, file of {} bytes)".format(path, info.filename, head_len, arr.nbytes,
+                                                                    info.file_size, fsize))
+            fh.seek(data_off)
+            direct.append((key, arr, data_off + head_len, zlib.crc32(fh.read(head_len)), info.CRC))
     with ThreadPoolExecutor(max_workers=_THREADS) as ex:
-        futs = []
-        for key, arr, off in direct:
+        pending = []
+        for key, arr, off, head_crc, want in direct:
             view = _raw_view(arr)
-            for a, b in _crc_chunks(view, _THREADS):
-                futs.append(ex.submit(_read_into, path, off + a, view[a:b]))
+            futs = [(b - a, ex.submit(_read_into, path, off + a, view[a:b], check_crc))
+                    for a, b in _crc_chunks(view, _THREADS)]
+            pending.append((key, futs, head_crc, want))
             out[key] = arr
-        npz = np.load(path, encoding="latin1", allow_pickle=True)
-        for k in npz.files:
-            if k not in out:
-                out[k] = npz[k]
-        for f in futs:
-            f.result()
+        with np.load(path, encoding="latin1", allow_pickle=True) as npz:
+            for k in npz.files:
+                if k not in out:
+                    out[k] = npz[k]
+        for key, futs, crc, want in pending:
+            for n, f in futs:
+                c = f.result()
+                if check_crc:
+                    crc = crc32_combine(crc, c, n)
+            if check_crc and crc != want:
+                raise IOError("{}: CRC-32 mismatch in member {}.npy (corrupted file)".format(path, key))
     return out
