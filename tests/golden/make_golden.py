@@ -490,6 +490,29 @@ def golden_config1():
     save("config1.npz", **out)
 
 
+def golden_gender():
+    """f4: the reference's own gender model (newref_tools.train_gender_model, :21-68) on a cohort whose
+    Y-read fractions have a real bimodal valley, WITHOUT --yfrac: the Gaussian-mixture fit and the
+    argrelextrema cut-off search (:57-62) run.  np.random is seeded for the mixture's k-means
+    initialisation."""
+    import argparse
+    from wisecondorx import newref_tools as ref_nt
+    rng = np.random.default_rng(21)
+    n = 46
+    is_m = rng.random(n) < 0.5
+    total = rng.integers(8_000_000, 25_000_000, n)
+    yfrac = np.where(is_m, rng.normal(0.0042, 0.0006, n), rng.normal(0.00035, 0.00012, n)).clip(1e-5)
+    y = np.round(total * yfrac).astype(np.int64)
+    other = (total - y).astype(np.int64)
+    samples = [{"1": np.array([o // 2, o - o // 2]), "24": np.array([yy])} for o, yy in zip(other, y)]
+    args = argparse.Namespace(plotyfrac=None, yfrac=None)
+    np.random.seed(7)
+    genders, cut = ref_nt.train_gender_model(args, samples)
+    assert set(genders) == {"M", "F"} and 0.0005 < cut < 0.004
+    save("gender.npz", other=other, y=y, genders=np.array(genders), cut_off=np.array(cut), np_seed=7,
+         is_m=is_m)
+
+
 def golden_cbs_bdry():
     """NOT a reference output (DNAcopy is not in the reference repository): the sequential-boundary
     table of the CBS ORACLE (oracle/cbs_oracle.getbdry, scipy hypergeometric CDF, ~50 s) for
@@ -503,6 +526,8 @@ def golden_cbs_bdry():
 if __name__ == "__main__":
     if "bdry" in sys.argv[1:]:
         golden_cbs_bdry()
+    if "gender" in sys.argv[1:]:
+        golden_gender()
     which = sys.argv[1:] or ["search", "pipeline", "prep_filter", "config1", "tables"]
     if "tables" in which:
         golden_tables()

@@ -448,3 +448,23 @@ def test_reference_npz_reader_detects_corruption(tmp_path):
         fh.write(bytes([c[0] ^ 4]))
     with pytest.raises(IOError, match="CRC-32 mismatch"):
         npz_io.load_reference(path)
+
+
+def test_gender_model_cutoff_matches_reference():
+    """f4: main.train_gender_model WITHOUT --yfrac against the reference's own run
+    (tests/golden/gender.npz, made by importing newref_tools.train_gender_model): the mixture fit and
+    the first local minimum of its density (newref_tools.py:36-62) give the same cut-off and the
+    same genders."""
+    import argparse
+    from conftest import GOLDEN
+    from wisecondorx_amd import main
+    g = np.load(os.path.join(GOLDEN, "gender.npz"))
+    samples = [{"1": np.array([o // 2, o - o // 2]), "24": np.array([yy])} for o, yy in zip(g["other"], g["y"])]
+    np.random.seed(int(g["np_seed"]))
+    genders, cut = main.train_gender_model(argparse.Namespace(plotyfrac=None, yfrac=None), samples)
+    assert cut == float(g["cut_off"])
+    assert genders == [str(x) for x in g["genders"]]
+    assert [x == "M" for x in genders] == g["is_m"].tolist()
+    # --yfrac given: no mixture, the value is used as is (newref_tools.py:55-56)
+    g2, c2 = main.train_gender_model(argparse.Namespace(plotyfrac=None, yfrac=0.002), samples)
+    assert c2 == 0.002 and g2 == genders
