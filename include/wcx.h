@@ -141,6 +141,12 @@ int wcx_null_ratios(wcx_ctx *ctx, const double *Xs, int64_t B, int S, const int3
  * sample_ids uses it.  Results are identical with or without this call. */
 int wcx_null_rank_prepare_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                               const int32_t *sample_ids /*host*/, int n_ids);
+/* The same for rows whose reference-bin row is the dummy of a gonosomal pass (all indices 0,
+ * newref_tools.py:186-191): the median of k copies of x[0] is x[0], so out[r][m] =
+ * log2(X[row][sid[m]] / X[0][sid[m]]) exactly as newref_tools.py:219-221 computes it, without gathers. */
+int wcx_null_ratios_dummy_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S, int64_t row_begin,
+                              int64_t row_end, const int32_t *sample_ids /*host*/, int n_ids,
+                              double *d_out);
 int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                         const int32_t *d_idx, int64_t row_begin, int64_t row_end, int k,
                         const int32_t *sample_ids /*host*/, int n_ids, double *d_out);
@@ -183,6 +189,27 @@ int wcx_post_process_dev(wcx_ctx *ctx, const double *d_z, const double *d_r, con
                          double minrefbins, const int32_t *d_pos, int64_t n_bins, double *out_r,
                          double *out_z, double *out_w);
 
+/* The general, batched form: main.py:242-257 (autosomal + gonosomal results appended, z - m_z of the
+ * autosomal pass, w = append(wA * nanmean(wG), wG * nanmean(wA)) / nanmean(...), all weights 1 if any
+ * is NaN / inf), predict_control.get_post_processed_result for r, z, w (predict_control.py:49-63)
+ * and predict_tools.log_trans (predict_tools.py:180-193) for n_samples samples whose normalisation
+ * outputs are device-resident:
+ *   autosomal  d_zA, d_rA, d_nA double[n_samples][BA] (wcx_predict_normalize_dev, ct = 0), d_wA double[BA]
+ *   gonosomal  d_zG, d_rG, d_nG double[n_samples][BG] (rows from ct of the .F / .M reference), d_wG
+ *              double[BG] (wcx_weights_dev of that reference, rows from ct); BG = 0: autosomes only
+ *   d_m_lr, d_m_z double[n_samples]: the autosomal pass's medians; d_pos int32[BA + BG]: position of
+ *   merged masked bin i in the unmasked vector (mask{ap}).
+ * Outputs stay on the DEVICE: d_out_r (log2 ratios), d_out_z, d_out_w double[n_samples][n_bins]
+ * (masked-out bins 0) -- the inputs of wcx_cbs_batch_dev / wcx_segment_z_dev.  *weights_fallback
+ * (may be NULL; non-NULL synchronises) = 1 when the all-ones rule fired (main.py:252-256 logs a warning). */
+int wcx_post_process_merge_dev(wcx_ctx *ctx, const double *d_zA, const double *d_rA,
+                               const double *d_nA, const double *d_wA, int64_t BA,
+                               const double *d_zG, const double *d_rG, const double *d_nG,
+                               const double *d_wG, int64_t BG, int n_samples, const double *d_m_lr,
+                               const double *d_m_z, double minrefbins, const int32_t *d_pos,
+                               int64_t n_bins, double *d_out_r, double *d_out_z, double *d_out_w,
+                               int *weights_fallback);
+
 /* ---- row-sharded predict (multi-GPU) --------------------------------------
  * A handle made by wcx_ref_wrap_rows_dev holds only rows [row0,row0+nrows) of indexes/distances
  * (the block this rank built).  The host drives normalize_repeat (predict_tools.py:94-108)
@@ -222,6 +249,12 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
 int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples, int64_t n_bins,
                   const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
                   double *out_seg, int cap, int *out_count);
+/* wcx_cbs_batch on DEVICE-resident r, w (wcx_post_process_merge_dev's outputs): they are copied once
+ * into pinned host memory (the NA-free series are assembled and the segments post-processed on the
+ * host, CBS.R:41-63,84-129); everything else as wcx_cbs_batch. */
+int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_samples,
+                      int64_t n_bins, const int64_t *chr_off, int n_chr, double alpha, int64_t binsize,
+                      uint64_t seed, double *out_seg, int cap, int *out_count);
 /* Diagnostics of the CBS calls on this context since its creation: out[0] = hybrid tests decided
  * by the short-arc bound (their permutations were not run), out[1..3] reserved. */
 int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]);
@@ -256,6 +289,10 @@ int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
 int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
                   const int64_t *chr_off, int n_chr, const double *seg, int n_seg,
                   double *out_z, double *out_nnull);
+/* The same with DEVICE-resident r, w (one sample's rows of wcx_post_process_merge_dev's outputs)
+ * and the attached null matrix. */
+int wcx_segment_z_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, const int64_t *chr_off,
+                      int n_chr, const double *seg, int n_seg, double *out_z, double *out_nnull);
 
 #ifdef __cplusplus
 }

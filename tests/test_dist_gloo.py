@@ -1,5 +1,6 @@
-"""CPU, world_size=2, gloo: the row-sharded reference build (partition + the one all-gather +
-result gather) gives exactly the single-process result.  The compute backend injected here is
+"""CPU, world_size 2 and 8, gloo: the row-sharded reference build (partition + the one all-gather +
+result gather) gives exactly the single-process result -- 8 uneven _get_part shards with padding
+included.  The compute backend injected here is
 the oracle (tests may use it); on the GPU the same orchestration drives libwcx_hip.so."""
 import os
 import socket
@@ -84,7 +85,7 @@ def _worker(rank, world, port, X, cum, k, ids, q):
     local[:e - b] = torch.from_numpy(np.ascontiguousarray(X[b:e]))
     idx, dd, nr, Xs = wd.newref_sharded(local, B, cum, k, ids, OracleBackend(), rank, world)
     assert Xs.shape == (X.shape[1], B)
-    fi, fd = wd.gather_reference(idx, dd, B, world)
+    fi, fd, fnr = wd.gather_reference3(idx, dd, nr, B, world)
     # row-sharded predict of one sample against the rows this rank just built
     mb = np.diff(np.concatenate(([0], cum))).tolist()
     pb = OraclePredictBackend(mb, list(cum))
@@ -93,13 +94,14 @@ def _worker(rank, world, port, X, cum, k, ids, q):
     xt = torch.from_numpy(np.ascontiguousarray(X[:, 0]) * (1 + 0.2 * np.sin(np.arange(B))))
     z, r, n, mlr, mz = wd.normalize_sharded(pb, ref, xt, B, 0, cutoff, rank, world)
     q.put((rank, idx.numpy().copy(), dd.numpy().copy(), nr.numpy().copy(),
-           fi.numpy().copy(), fd.numpy().copy(),
+           fi.numpy().copy(), fd.numpy().copy(), fnr.numpy().copy(),
            (cutoff, z.numpy().copy(), r.numpy().copy(), n.numpy().copy(), mlr, mz)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_row_sharded_newref_two_ranks():
+@pytest.mark.parametrize("world", [2, 8])
+def test_row_sharded_newref(world):
     import torch.multiprocessing as mp
     from oracle import wcx_oracle as O
     from wisecondorx_amd.synth import corrected_matrix
@@ -111,13 +113,16 @@ def test_row_sharded_newref_two_ranks():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, X, cum, k, ids, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, X, cum, k, ids, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
+    from wisecondorx_amd import dist as wd
+    sizes = [wd.row_shard(r, world, X.shape[0])[1] - wd.row_shard(r, world, X.shape[0])[0] for r in range(world)]
+    assert [len(r[1]) for r in res] == sizes and (world == 2 or len(set(sizes)) > 1)   # uneven at 8
     ei, ed, enr = O.get_reference(X, mbpc, cum, k, 1, 1, ids)
     assert np.array_equal(np.concatenate([r[1] for r in res]), ei)
     assert np.array_equal(np.concatenate([r[2] for r in res]), ed)
@@ -126,8 +131,8 @@ def test_row_sharded_newref_two_ranks():
     ecut = O.get_optimal_cutoff(ed, 5)
     ez, er, en, emlr, emz = O.normalize_repeat(x, mbpc, cum, ei, ed, ecut, 0, 0)
     for r in res:      # every replica holds the whole reference after the gather
-        assert np.array_equal(r[4], ei) and np.array_equal(r[5], ed)
-        cutoff, z, rr, n, mlr, mz = r[6]
+        assert np.array_equal(r[4], ei) and np.array_equal(r[5], ed) and np.array_equal(r[6], enr)
+        cutoff, z, rr, n, mlr, mz = r[7]
         np.testing.assert_allclose(cutoff, ecut, rtol=1e-12)
         np.testing.assert_allclose(z, ez, rtol=1e-9, atol=1e-12, equal_nan=True)
         np.testing.assert_allclose(rr, er, rtol=1e-12, equal_nan=True)

@@ -1,4 +1,4 @@
-"""GPU, world_size 2 over gloo with BOTH ranks on cuda:0: the multi-GPU orchestration of dist.py
+"""GPU, world_size 2 and 8 over gloo with ALL ranks on cuda:0: the multi-GPU orchestration of dist.py
 (row shards, the all-gather of X, sharded cut-off and normalisation) driving the real HIP library
 (GpuBackend), compared with the oracle.  RCCL itself needs one device per rank and is exercised
 by bench.py on the multi-GPU node; everything around the collectives is covered here."""
@@ -32,24 +32,29 @@ def _worker(rank, world, port, X, cum, k, ids, q):
     local = torch.zeros((pad, X.shape[1]), dtype=torch.float64, device=dev)
     local[:e - b] = torch.from_numpy(np.ascontiguousarray(X[b:e])).to(dev)
     idx, dd, nr, Xs = wd.newref_sharded(local, B, cum, k, ids, be, rank, world)
+    fi, fd, fnr = wd.gather_reference3(idx, dd, nr, B, world, be)     # padded all-gather + compact_rows
     h = be.wrap_rows(idx, dd, B, k, cum, b, e - b)
     cutoff = wd.cutoff_sharded(be, h, 5, world)
     xt = torch.from_numpy(np.ascontiguousarray(X[:, 0]) * (1 + 0.2 * np.sin(np.arange(B)))).to(dev)
     z, r, n, mlr, mz = wd.normalize_sharded(be, h, xt, B, 0, cutoff, rank, world)
     ctx.sync()
     be.free_ref(h)
+    import hashlib
+    full_sha = hashlib.sha256(fi.cpu().numpy().tobytes() + fd.cpu().numpy().tobytes() +
+                              fnr.cpu().numpy().tobytes()).hexdigest()
     q.put((rank, idx.cpu().numpy().copy(), dd.cpu().numpy().copy(), nr.cpu().numpy().copy(),
-           (cutoff, z.cpu().numpy().copy(), r.cpu().numpy().copy(), n.cpu().numpy().copy(), mlr, mz)))
+           (cutoff, z.cpu().numpy().copy(), r.cpu().numpy().copy(), n.cpu().numpy().copy(), mlr, mz), full_sha))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_device_real_kernels():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_on_one_device_real_kernels(world):
     import torch.multiprocessing as mp
     from oracle import c_oracle as CO
     from oracle import wcx_oracle as O
     from wisecondorx_amd.synth import corrected_matrix
-    X, mbpc, cum = corrected_matrix([900, 800, 700, 600, 500], 40, seed=23)
+    X, mbpc, cum = corrected_matrix([900, 800, 700, 600, 503], 40, seed=23)      # 3503 rows: uneven in 8
     X = np.asfortranarray(X)
     B, k, ids = cum[-1], 64, [3, 1, 7, 0, 22, 39]
     with socket.socket() as s:
@@ -57,12 +62,12 @@ def test_two_ranks_one_device_real_kernels():
         port = s.getsockname()[1]
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, 2, port, X, cum, k, ids, q)) for r in range(2)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, X, cum, k, ids, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     ei, ed = CO.get_reference_rows(np.ascontiguousarray(X.T), cum, 0, B, k)
     assert np.array_equal(np.concatenate([r[1] for r in res]), ei)
@@ -70,6 +75,12 @@ def test_two_ranks_one_device_real_kernels():
     with np.errstate(all="ignore"):
         enr = O.null_ratios(X, ei, 0, B, ids)
     np.testing.assert_allclose(np.concatenate([r[3] for r in res]), enr, rtol=1e-12, atol=1e-13)
+    # every rank's gathered copy of the finished reference (idx | dist | null ratios) is the same
+    # dense table = the concatenation of the shards
+    import hashlib
+    want = hashlib.sha256(np.concatenate([r[1] for r in res]).tobytes() + np.concatenate([r[2] for r in res]).tobytes()
+                          + np.concatenate([r[3] for r in res]).tobytes()).hexdigest()
+    assert all(r[5] == want for r in res)
     x = np.ascontiguousarray(X[:, 0]) * (1 + 0.2 * np.sin(np.arange(B)))
     ecut = O.get_optimal_cutoff(ed, 5)
     ez, er, en, emlr, emz = O.normalize_repeat(x, mbpc, cum, ei, ed, ecut, 0, 0)

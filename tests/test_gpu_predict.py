@@ -156,7 +156,8 @@ def test_row_sharded_primitives_equal_batched_path(pt):
 def test_post_process_dev_matches_host_post_processing():
     """wcx_post_process_dev + wcx_weights_dev against get_post_processed_result x3 + log_trans on
     the host (predict_control.py:49-63, predict_tools.py:180-193): zero / negative / inf / nan
-    ratios, ratio == 1, bins below minrefbins, NaN z and NaN weights."""
+    ratios, ratio == 1, bins below minrefbins, NaN z, and a NaN weight -- which makes ALL weights 1
+    (main.py:252-256); a second round without it checks the plain w / nanmean(w)."""
     import argparse
     import torch
     from wisecondorx_amd import _lib, predict_tools as pt
@@ -175,7 +176,11 @@ def test_post_process_dev_matches_host_post_processing():
     args = argparse.Namespace(minrefbins=150)
     bpc = [1200, 800, 3000]
     rem = {"mask": mask, "bins_per_chr": bpc}
-    want = {"results_r": r, "results_z": z - m_z, "results_w": w / np.nanmean(w)}
+    w_scaled = w / np.nanmean(w)
+    if np.isnan(w_scaled).any() or np.isinf(w_scaled).any():          # main.py:252-256
+        w_scaled = np.ones(len(w_scaled))
+    assert np.all(w_scaled == 1.0)                                    # (the NaN weight triggers it)
+    want = {"results_r": r, "results_z": z - m_z, "results_w": w_scaled}
     for key in want:
         want[key] = pt.get_post_processed_result(args, want[key], n, rem)
     pt.log_trans(want, m_lr)
@@ -193,3 +198,65 @@ def test_post_process_dev_matches_host_post_processing():
     for row, key in enumerate(("results_r", "results_z", "results_w")):
         np.testing.assert_allclose(got[row], np.concatenate(want[key]), rtol=1e-12, atol=1e-15,
                                    equal_nan=True, err_msg=key)
+    w[4] = 1.3                                                        # all weights finite now
+    want_w = pt.get_post_processed_result(args, w / np.nanmean(w), n, rem)
+    wd = {"results_r": pt.get_post_processed_result(args, r, n, rem), "results_z": pt.get_post_processed_result(args, z - m_z, n, rem),
+          "results_w": want_w}
+    pt.log_trans(wd, m_lr)
+    d[3] = torch.from_numpy(w).to(dev)
+    _lib.check(ctx.lib.wcx_post_process_dev(ctx.h, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                                            d[3].data_ptr(), B, med[0:].data_ptr(), med[1:].data_ptr(),
+                                            150.0, pos.data_ptr(), n_bins, host[0].data_ptr(),
+                                            host[1].data_ptr(), host[2].data_ptr()))
+    np.testing.assert_allclose(host.numpy()[2], np.concatenate(wd["results_w"]), rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", ["t0", "t1", "t2"])
+def test_device_resident_full_predict_golden(pt, g_pipe, name):
+    """dist.predict_full_dev: both normalisation passes, the A + gonosome merge, minrefbins /
+    inflation / log2 transform (wcx_post_process_merge_dev) with everything device-resident, against
+    the vectors the REFERENCE produced after get_post_processed_result + log_trans (_post_r/z/w of
+    tests/golden/pipeline.npz; t1 additionally applies a blacklist there, so only its non-blacklisted
+    bins are compared), then segment z of the golden segments on the device-resident vectors."""
+    import torch
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd import dist as wd
+    g = g_pipe
+    ref = ref_dict_from_golden(g)
+    gender = str(g[name + "_gender"])
+    ap = "." + gender
+    sample = sample_from_counts(g[name + "_counts"], g["cohort_bpc"])
+    if gender == "M":
+        sample["23"] = sample["23"] * 2
+        sample["24"] = sample["24"] * 2
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    A = {"idx": t(ref["indexes"]), "dist": t(ref["distances"]), "nr": t(ref["null_ratios"]),
+         "cum": ref["masked_bins_per_chr_cum"]}
+    G = {"idx": t(ref["indexes" + ap]), "dist": t(ref["distances" + ap]), "nr": t(ref["null_ratios" + ap]),
+         "cum": ref["masked_bins_per_chr_cum" + ap]}
+    xA = pt.project_pc(pt.coverage_normalize_and_mask(sample, ref, ""), ref, "")
+    xG = pt.project_pc(pt.coverage_normalize_and_mask(sample, ref, ap), ref, ap)
+    args = argparse.Namespace(minrefbins=20, maskrepeats=5, alpha=1e-4, seed=3)
+    rem = {"args": args, "mask": ref["mask" + ap], "bins_per_chr": ref["bins_per_chr" + ap],
+           "binsize": int(ref["binsize"]), "ref_gender": gender}
+    rows, host = wd.predict_full_dev(be, A, G, t(xA), t(xG), rem, pt, want_host=True)
+    keep = np.ones(host.shape[1], dtype=bool)
+    if name == "t1":                                     # the fixture's blacklist zeroes these afterwards
+        keep = g[name + "_post_r"] != 0
+    for row, key in enumerate(("_post_r", "_post_z", "_post_w")):
+        np.testing.assert_allclose(host[row][keep], g[name + key][keep], rtol=1e-9, atol=1e-12,
+                                   equal_nan=True, err_msg=key)
+    assert len(rows) >= len(rem["bins_per_chr"]) - 1 and all(len(r) == 5 for r in rows)
+    if name != "t1":
+        out = be._predict_full_bufs["out"]
+        seg = np.ascontiguousarray(g[name + "_segs"], dtype=np.float64)
+        off, off_p = _lib.i64_array(np.concatenate(([0], np.cumsum(rem["bins_per_chr"]))))
+        z, nn = np.empty(len(seg)), np.empty(len(seg))
+        _lib.check(ctx.lib.wcx_segment_z_dev(ctx.h, out[0].data_ptr(), out[2].data_ptr(), off_p, len(off) - 1,
+                                             _lib.ptr(seg), len(seg), _lib.ptr(z), _lib.ptr(nn)))
+        assert np.array_equal(nn == 0, g[name + "_segz_isstr"])
+        got = np.where(nn == 0, np.nan, z)
+        np.testing.assert_allclose(got, g[name + "_segz"], rtol=1e-9, atol=1e-9, equal_nan=True)

@@ -65,6 +65,12 @@ SIGNATURES = {
     "wcx_cbs": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64, vp,
                           C.c_int, C.POINTER(C.c_int)]),
     "wcx_cbs_stats": (C.c_int, [vp, c_i64p]),
+    "wcx_cbs_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, c_i64, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64,
+                                    vp, C.c_int, vp]),
+    "wcx_segment_z_dev": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, vp, C.c_int, vp, vp]),
+    "wcx_post_process_merge_dev": (C.c_int, [vp, vp, vp, vp, vp, c_i64, vp, vp, vp, vp, c_i64, C.c_int, vp, vp,
+                                             C.c_double, vp, c_i64, vp, vp, vp, vp]),
+    "wcx_null_ratios_dummy_dev": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64, c_i64, c_i32p, C.c_int, vp]),
     "wcx_cbs_trace": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "wcx_cbs_getbdry": (C.c_int, [C.c_double, C.c_int, C.c_int, vp]),
     "wcx_weights_dev": (C.c_int, [vp, vp, vp]),

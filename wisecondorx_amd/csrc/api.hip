@@ -153,6 +153,7 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
   }
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
+  if (ctx->host_scratch2) hipHostFree(ctx->host_scratch2);
   if (ctx->scratch2) hipFree(ctx->scratch2);
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_small) hipFree(ctx->d_small);

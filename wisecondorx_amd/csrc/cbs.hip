@@ -151,9 +151,9 @@ int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
   return WCX_OK;
 }
 
-int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
-                  const int64_t *chr_off, int n_chr, const double *seg, int n_seg, double *out_z,
-                  double *out_nnull) {
+static int segment_z_impl(wcx_ctx *ctx, const double *r, const double *w, bool rw_on_device,
+                          const double *nr, int m, const int64_t *chr_off, int n_chr,
+                          const double *seg, int n_seg, double *out_z, double *out_nnull) {
   WCX_ARG(ctx && r && w && chr_off && seg && out_z, "NULL argument");
   WCX_ARG(n_chr > 0 && n_seg >= 0, "bad sizes");
   if (n_seg == 0) return WCX_OK;
@@ -206,8 +206,13 @@ int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *
   double *dpden = (double *)p; p += pb;
   int *dpany = (int *)p;
   hipStream_t st = ctx->stream;
-  WCX_HIP(hipMemcpyAsync(dr, r, vb, hipMemcpyHostToDevice, st));
-  WCX_HIP(hipMemcpyAsync(dw, w, vb, hipMemcpyHostToDevice, st));
+  if (rw_on_device) {
+    dr = const_cast<double *>(r);
+    dw = const_cast<double *>(w);
+  } else {
+    WCX_HIP(hipMemcpyAsync(dr, r, vb, hipMemcpyHostToDevice, st));
+    WCX_HIP(hipMemcpyAsync(dw, w, vb, hipMemcpyHostToDevice, st));
+  }
   if (!attached) WCX_HIP(hipMemcpyAsync(dnr, nr, nrb, hipMemcpyHostToDevice, st));
   WCX_HIP(hipMemcpyAsync(dsr, sr.data(), sb, hipMemcpyHostToDevice, st));
   WCX_HIP(hipMemcpyAsync(dchunk0, chunk0.data(), (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, st));
@@ -228,6 +233,17 @@ int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *
   if (out_nnull) WCX_HIP(hipMemcpyAsync(out_nnull, dn, sb, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipStreamSynchronize(st));
   return WCX_OK;
+}
+
+int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
+                  const int64_t *chr_off, int n_chr, const double *seg, int n_seg, double *out_z,
+                  double *out_nnull) {
+  return segment_z_impl(ctx, r, w, false, nr, m, chr_off, n_chr, seg, n_seg, out_z, out_nnull);
+}
+
+int wcx_segment_z_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, const int64_t *chr_off,
+                      int n_chr, const double *seg, int n_seg, double *out_z, double *out_nnull) {
+  return segment_z_impl(ctx, d_r, d_w, true, nullptr, 0, chr_off, n_chr, seg, n_seg, out_z, out_nnull);
 }
 
 }  // extern "C"

@@ -1505,6 +1505,32 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
   return WCX_OK;
 }
 
+int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_samples,
+                      int64_t n_bins, const int64_t *chr_off, int n_chr, double alpha, int64_t binsize,
+                      uint64_t seed, double *out_seg, int cap, int *out_count) {
+  WCX_ARG(ctx && d_r && d_w && n_samples > 0 && n_bins > 0, "bad parameters");
+  WCX_HIP(hipSetDevice(ctx->device));
+  // the series are assembled (NA-free compaction, CBS.R:41-63) and the segments post-processed
+  // (CBS.R:84-129) on the host: r and w come down once into pinned memory
+  const size_t bytes = (size_t)n_samples * n_bins * 8;
+  if (ctx->host_scratch2_bytes < 2 * bytes) {
+    if (ctx->host_scratch2) { WCX_HIP(hipStreamSynchronize(ctx->stream)); WCX_HIP(hipHostFree(ctx->host_scratch2)); }
+    ctx->host_scratch2 = nullptr; ctx->host_scratch2_bytes = 0;
+    hipError_t e = hipHostMalloc(&ctx->host_scratch2, 2 * bytes + bytes / 2, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      wcx_set_error("hipHostMalloc(%zu bytes) failed: %s", 2 * bytes + bytes / 2, hipGetErrorString(e));
+      return WCX_ERR_NOMEM;
+    }
+    ctx->host_scratch2_bytes = 2 * bytes + bytes / 2;
+  }
+  double *hr = reinterpret_cast<double *>(ctx->host_scratch2), *hw = hr + (size_t)n_samples * n_bins;
+  WCX_HIP(hipMemcpyAsync(hr, d_r, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  WCX_HIP(hipMemcpyAsync(hw, d_w, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  WCX_HIP(hipStreamSynchronize(ctx->stream));
+  return wcx_cbs_batch(ctx, hr, hw, n_samples, n_bins, chr_off, n_chr, alpha, binsize, seed, out_seg, cap,
+                       out_count);
+}
+
 int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]) {
   WCX_ARG(ctx && out, "NULL argument");
   out[0] = ctx->cbs_shortcuts; out[1] = out[2] = out[3] = 0;

@@ -354,6 +354,19 @@ int wcx_null_rank_prepare_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
 
 }  // extern "C"
 
+// Rows whose reference-bin row is the gonosomal passes' dummy (all indices 0, newref_tools.py:186-191):
+// the median of k copies of x[0] is x[0], so out[r][m] = log2(x[row] / x[0]) -- no gather, no selection.
+__global__ __launch_bounds__(256) void k_null_dummy(const double *__restrict__ Xs, int64_t B,
+                                                    const int32_t *__restrict__ sids, int n_ids,
+                                                    int64_t row_begin, int64_t n_rows,
+                                                    double *__restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  if (r >= n_rows) return;
+  const double *x = Xs + (int64_t)sids[m] * B;
+  out[r * n_ids + m] = log2(x[row_begin + r] / x[0]);
+}
+
 // Starts the pending ranking on the auxiliary stream, behind the main stream's current position.
 // The search calls this between its sweep and its refine (see wcx_topk_screen_launch for the
 // measurements behind that choice); wcx_null_ratios_dev calls it as a catch-all.
@@ -442,6 +455,27 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
 #undef WCX_NR_LAUNCH
   WCX_HIP(hipGetLastError());
   return wcx_timer_end(ctx, "null_ratios");
+}
+
+int wcx_null_ratios_dummy_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S, int64_t row_begin,
+                              int64_t row_end, const int32_t *sample_ids, int n_ids, double *d_out) {
+  WCX_ARG(ctx && dXs && sample_ids && d_out, "NULL argument");
+  WCX_ARG(B > 0 && S > 0 && n_ids >= 0 && n_ids <= 128, "bad sizes");
+  WCX_ARG(0 <= row_begin && row_begin <= row_end && row_end <= B, "bad row range");
+  int rc = check_ids(sample_ids, n_ids, S);
+  if (rc) return rc;
+  WCX_HIP(hipSetDevice(ctx->device));
+  const int64_t n_rows = row_end - row_begin;
+  if (n_rows == 0 || n_ids == 0) return WCX_OK;
+  void *scr = nullptr;
+  rc = wcx_scratch2(ctx, 1024, &scr);
+  if (rc) return rc;
+  rc = wcx_upload_small(ctx, scr, sample_ids, (size_t)n_ids * 4);
+  if (rc) return rc;
+  k_null_dummy<<<dim3((unsigned)((n_rows + 255) / 256), (unsigned)n_ids), 256, 0, ctx->stream>>>(
+      dXs, B, reinterpret_cast<const int32_t *>(scr), n_ids, row_begin, n_rows, d_out);
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
 }
 
 int wcx_null_ratios(wcx_ctx *ctx, const double *Xs, int64_t B, int S, const int32_t *idx,

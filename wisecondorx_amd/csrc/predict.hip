@@ -579,6 +579,93 @@ __global__ __launch_bounds__(256) void k_post_process(
   full[2 * n_bins + p] = good ? (wmean[1] != 0.0 ? 1.0 : w[i] / wmean[0]) : 0.0;
 }
 
+// ---- A + gonosome merge + post-processing of a batch (wcx_post_process_merge_dev) ----------------
+// weight statistics of one weight vector: {nanmean, count of non-NaN, non-finite entries}
+__global__ __launch_bounds__(1024) void k_wstats(const double *__restrict__ w, int64_t n,
+                                                 double *__restrict__ out) {
+  __shared__ double ss[16], sc[16], sb[16];
+  double s = 0.0, c = 0.0, bad = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double v = w[i];
+    if (v == v) { s += v; c += 1.0; }
+    if (!(v - v == 0.0)) bad += 1.0;
+  }
+  s = wcx::wave_sum(s); c = wcx::wave_sum(c); bad = wcx::wave_sum(bad);
+  if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; sb[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0, nb = 0.0;
+    for (int q = 0; q < 16; ++q) { a += ss[q]; b += sc[q]; nb += sb[q]; }
+    out[0] = a / b; out[1] = b; out[2] = nb;
+  }
+}
+
+// main.py:247-256: w = append(wA * nanmean(wG), wG * nanmean(wA)); w /= nanmean(w); any NaN / inf
+// left -> all ones.  One workgroup: first the nanmean of the concatenation, then the vector.
+// stA / stG = k_wstats of the two parts (stG unused when BG == 0: w = wA / nanmean(wA)).
+__global__ __launch_bounds__(1024) void k_wmerge(const double *__restrict__ wA, int64_t BA,
+                                                 const double *__restrict__ wG, int64_t BG,
+                                                 const double *__restrict__ stA,
+                                                 const double *__restrict__ stG,
+                                                 double *__restrict__ wout, int *__restrict__ fallback) {
+  __shared__ double ss[16], sc[16];
+  __shared__ double s_mean;
+  __shared__ int s_bad;
+  const double mA = stA[0], mG = BG ? stG[0] : 1.0;
+  const double fa = BG ? mG : 1.0, fg = mA;          // scale of the autosomal / gonosomal part
+  double s = 0.0, c = 0.0;
+  for (int64_t i = threadIdx.x; i < BA + BG; i += 1024) {
+    const double v = i < BA ? wA[i] * fa : wG[i - BA] * fg;
+    if (v == v) { s += v; c += 1.0; }
+  }
+  s = wcx::wave_sum(s); c = wcx::wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < 16; ++q) { a += ss[q]; b += sc[q]; }
+    const double m = a / b;
+    s_mean = m;
+    // a non-finite weight, scale or mean anywhere makes some w / mean non-finite
+    const bool bad = stA[2] > 0.0 || (BG && stG[2] > 0.0) || !(m - m == 0.0) || m == 0.0 ||
+                     !(fa - fa == 0.0) || !(fg - fg == 0.0);
+    s_bad = bad ? 1 : 0;
+    *fallback = s_bad;
+  }
+  __syncthreads();
+  const double m = s_mean;
+  const bool bad = s_bad != 0;
+  for (int64_t i = threadIdx.x; i < BA + BG; i += 1024) {
+    const double v = i < BA ? wA[i] * fa : wG[i - BA] * fg;
+    wout[i] = bad ? 1.0 : v / m;
+  }
+}
+
+// per (sample, merged masked bin): minrefbins rule, z - m_z(A), log2 transform, inflation
+__global__ __launch_bounds__(256) void k_post_merge(
+    const double *__restrict__ zA, const double *__restrict__ rA, const double *__restrict__ nA,
+    int64_t BA, const double *__restrict__ zG, const double *__restrict__ rG,
+    const double *__restrict__ nG, int64_t BG, const double *__restrict__ wfin,
+    const double *__restrict__ m_lr, const double *__restrict__ m_z, double minrefbins,
+    const int32_t *__restrict__ pos, int64_t n_bins, double *__restrict__ out_r,
+    double *__restrict__ out_z, double *__restrict__ out_w) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (i >= BA + BG) return;
+  const bool aut = i < BA;
+  const int64_t j = aut ? (int64_t)s * BA + i : (int64_t)s * BG + (i - BA);
+  const double nref = aut ? nA[j] : nG[j], rr = aut ? rA[j] : rG[j], zz = aut ? zA[j] : zG[j];
+  const bool keep = nref >= minrefbins;
+  double lr = log2(keep ? rr : 0.0);
+  const bool good = (lr - lr == 0.0);                      // finite
+  lr = good ? lr : 0.0;
+  if (lr != 0.0) lr -= m_lr[s];
+  const int64_t p = (int64_t)s * n_bins + pos[i];
+  out_r[p] = lr;
+  out_z[p] = good && keep ? zz - m_z[s] : 0.0;
+  out_w[p] = good && keep ? wfin[i] : 0.0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -698,6 +785,42 @@ int wcx_post_process_dev(wcx_ctx *ctx, const double *d_z, const double *d_r, con
   WCX_HIP(hipMemcpyAsync(out_z, full + n_bins, (size_t)n_bins * 8, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipMemcpyAsync(out_w, full + 2 * n_bins, (size_t)n_bins * 8, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipStreamSynchronize(st));
+  return WCX_OK;
+}
+
+int wcx_post_process_merge_dev(wcx_ctx *ctx, const double *d_zA, const double *d_rA,
+                               const double *d_nA, const double *d_wA, int64_t BA,
+                               const double *d_zG, const double *d_rG, const double *d_nG,
+                               const double *d_wG, int64_t BG, int n_samples, const double *d_m_lr,
+                               const double *d_m_z, double minrefbins, const int32_t *d_pos,
+                               int64_t n_bins, double *d_out_r, double *d_out_z, double *d_out_w,
+                               int *weights_fallback) {
+  WCX_ARG(ctx && d_zA && d_rA && d_nA && d_wA && d_m_lr && d_m_z && d_pos && d_out_r && d_out_z && d_out_w,
+          "NULL argument");
+  WCX_ARG(BG == 0 || (d_zG && d_rG && d_nG && d_wG), "gonosomal part incomplete");
+  WCX_ARG(BA > 0 && BG >= 0 && n_samples > 0 && n_bins >= BA + BG, "bad sizes");
+  WCX_HIP(hipSetDevice(ctx->device));
+  void *scr = nullptr;
+  int rc = wcx_scratch2(ctx, (size_t)(BA + BG) * 8 + 512, &scr);
+  if (rc) return rc;
+  double *d_wfin = reinterpret_cast<double *>(scr);
+  double *d_st = d_wfin + (BA + BG);                         // stA[3] | stG[3] | fallback flag
+  int *d_fb = reinterpret_cast<int *>(d_st + 8);
+  hipStream_t st = ctx->stream;
+  WCX_HIP(hipMemsetAsync(d_out_r, 0, (size_t)n_samples * n_bins * 8, st));
+  WCX_HIP(hipMemsetAsync(d_out_z, 0, (size_t)n_samples * n_bins * 8, st));
+  WCX_HIP(hipMemsetAsync(d_out_w, 0, (size_t)n_samples * n_bins * 8, st));
+  k_wstats<<<1, 1024, 0, st>>>(d_wA, BA, d_st);
+  if (BG) k_wstats<<<1, 1024, 0, st>>>(d_wG, BG, d_st + 3);
+  k_wmerge<<<1, 1024, 0, st>>>(d_wA, BA, d_wG, BG, d_st, d_st + 3, d_wfin, d_fb);
+  k_post_merge<<<dim3((unsigned)((BA + BG + 255) / 256), (unsigned)n_samples), 256, 0, st>>>(
+      d_zA, d_rA, d_nA, BA, d_zG, d_rG, d_nG, BG, d_wfin, d_m_lr, d_m_z, minrefbins, d_pos, n_bins,
+      d_out_r, d_out_z, d_out_w);
+  WCX_HIP(hipGetLastError());
+  if (weights_fallback) {
+    WCX_HIP(hipMemcpyAsync(weights_fallback, d_fb, 4, hipMemcpyDeviceToHost, st));
+    WCX_HIP(hipStreamSynchronize(st));
+  }
   return WCX_OK;
 }
 

@@ -52,6 +52,8 @@ struct wcx_ctx {
   long long cbs_shortcuts = 0;       // hybrid CBS tests decided by the short-arc bound (no permutations)
   void *host_scratch = nullptr;      // pinned host staging (wcx_host_scratch)
   size_t host_scratch_bytes = 0;
+  void *host_scratch2 = nullptr;     // pinned copy of r | w for wcx_cbs_batch_dev
+  size_t host_scratch2_bytes = 0;
   void *scratch2 = nullptr;
   size_t scratch2_bytes = 0;
   // null-ratio matrix attached for wcx_segment_z (wcx_set_null_matrix)

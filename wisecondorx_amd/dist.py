@@ -154,13 +154,23 @@ class GpuBackend(_GpuPredictMixin):
         ids, ids_p = _lib.i32_array(sample_ids)
         # the ranking of the null samples needs X only: start it on the auxiliary stream now, it
         # runs beside the search
-        _lib.check(lib.wcx_null_rank_prepare_dev(self.ctx.h, d_Xs.data_ptr(), B, S, ids_p, len(ids)))
+        # gonosomal pass (n_chr > 22): the autosomal target rows are dummies (index 0 / distance 1,
+        # newref_tools.py:186-191); their null ratios are log2(x[row] / x[0]) without any gather
+        ct = int(cum[21]) if len(cum) > 22 else 0
+        real_lo = max(row_begin, ct)
+        if real_lo < row_end:
+            _lib.check(lib.wcx_null_rank_prepare_dev(self.ctx.h, d_Xs.data_ptr(), B, S, ids_p, len(ids)))
         _lib.check(lib.wcx_newref_topk_dev(self.ctx.h, d_Xs.data_ptr(), B, S, cum_p, len(cum),
                                            row_begin, row_end, k, mode, d_idx.data_ptr(),
                                            d_dist.data_ptr()))
-        _lib.check(lib.wcx_null_ratios_dev(self.ctx.h, d_Xs.data_ptr(), B, S, d_idx.data_ptr(),
-                                           row_begin, row_end, k, ids_p, len(ids),
-                                           d_nr.data_ptr()))
+        if row_begin < min(row_end, ct):
+            _lib.check(lib.wcx_null_ratios_dummy_dev(self.ctx.h, d_Xs.data_ptr(), B, S, row_begin,
+                                                     min(row_end, ct), ids_p, len(ids), d_nr.data_ptr()))
+        if real_lo < row_end:
+            skip = real_lo - row_begin
+            _lib.check(lib.wcx_null_ratios_dev(self.ctx.h, d_Xs.data_ptr(), B, S,
+                                               d_idx.data_ptr() + skip * k * 4, real_lo, row_end, k,
+                                               ids_p, len(ids), d_nr.data_ptr() + skip * len(ids) * 8))
 
 
 def newref_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, world, out=None):
@@ -276,6 +286,94 @@ def predict_one_dev(backend, idx, dist, nr, d_x, B, k, chr_cum, rem_input, pt):
     pt.attach_null_matrix_dev(nr, rem_input["mask"], ctx)
     results["results_nr"] = pt.ATTACHED
     return pt.exec_cbs(rem_input, results, ctx)
+
+
+def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
+    """predict of ONE sample, complete and device-resident (main.py:191-279): autosomal pass against
+    A = {"idx", "dist", "nr", "cum"} (device tensors of the autosomal reference + its cumulative bin
+    counts), gonosomal pass against G (the .F / .M reference: all its rows; None = autosomes only),
+    cut-off on the AUTOSOMAL distances (predict_tools.py:75), the A + gonosome merge, minrefbins /
+    inflation / log2 transform (wcx_post_process_merge_dev), CBS (wcx_cbs_batch_dev) and segment z
+    (wcx_segment_z_dev) -- no NumPy between the normalisation and the segments.
+    d_xA / d_xG: the projected coverage vectors of the sample for the two references.
+    rem_input["mask"] / ["bins_per_chr"] are those of the reference the gonosomes come from.
+    Returns the reference's result rows [chr, start, end, z, ratio] (+ the host copies of the
+    per-bin r, z, w if want_host)."""
+    import numpy as np
+    import torch
+    from . import _lib
+    ctx = backend.ctx
+    lib = ctx.lib
+    dev = d_xA.device
+    args = rem_input["args"]
+    mask = np.asarray(rem_input["mask"], dtype=bool)
+    n_bins = len(mask)
+    BA, k = A["idx"].shape
+    cumA, cumA_p = _lib.i64_array(A["cum"])
+    ct = BG_all = BG = 0
+    if G is not None:
+        BG_all = G["idx"].shape[0]
+        cumG, cumG_p = _lib.i64_array(G["cum"])
+        ct = int(cumG[21])
+        BG = BG_all - ct
+    cache = getattr(backend, "_predict_full_bufs", None)
+    key = (BA, BG, n_bins, hash(mask.tobytes()))
+    if cache is None or cache["key"] != key:
+        pos = np.flatnonzero(mask).astype(np.int32)
+        if len(pos) != BA + BG:
+            raise ValueError("mask selects {} bins, the references hold {} + {}".format(len(pos), BA, BG))
+        cache = {"key": key, "pos": torch.from_numpy(pos).to(dev),
+                 "a": torch.empty((4, BA), dtype=torch.float64, device=dev),
+                 "g": torch.empty((4, max(BG_all, 1)), dtype=torch.float64, device=dev),
+                 "med": torch.empty(4, dtype=torch.float64, device=dev),
+                 "out": torch.empty((3, n_bins), dtype=torch.float64, device=dev),
+                 "host": torch.empty((3, n_bins), dtype=torch.float64).pin_memory()}
+        backend._predict_full_bufs = cache
+    a, g, med, out = cache["a"], cache["g"], cache["med"], cache["out"]
+    hA, hG = _lib.vp(), _lib.vp()
+    _lib.check(lib.wcx_ref_wrap_dev(ctx.h, A["idx"].data_ptr(), A["dist"].data_ptr(), BA, k, cumA_p,
+                                    len(cumA), _lib.C.byref(hA)))
+    try:
+        cutoff = _lib.C.c_double()
+        _lib.check(lib.wcx_cutoff(ctx.h, hA, int(args.maskrepeats), _lib.C.byref(cutoff)))
+        _lib.check(lib.wcx_weights_dev(ctx.h, hA, a[3].data_ptr()))
+        _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hA, d_xA.data_ptr(), 1, cutoff.value, 0, 0,
+                                                 a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                                 med[0:].data_ptr(), med[1:].data_ptr()))
+        if G is not None:
+            _lib.check(lib.wcx_ref_wrap_dev(ctx.h, G["idx"].data_ptr(), G["dist"].data_ptr(), BG_all, k,
+                                            cumG_p, len(cumG), _lib.C.byref(hG)))
+            _lib.check(lib.wcx_weights_dev(ctx.h, hG, g[3].data_ptr()))
+            _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hG, d_xG.data_ptr(), 1, cutoff.value, ct, 22,
+                                                     g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                                                     med[2:].data_ptr(), med[3:].data_ptr()))
+        fb = _lib.C.c_int(0)
+        _lib.check(lib.wcx_post_process_merge_dev(
+            ctx.h, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), BA,
+            g[0].data_ptr() if BG else None, g[1].data_ptr() if BG else None,
+            g[2].data_ptr() if BG else None, g[3].data_ptr() + 8 * ct if BG else None, BG, 1,
+            med[0:].data_ptr(), med[1:].data_ptr(), float(args.minrefbins), cache["pos"].data_ptr(),
+            n_bins, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None))
+    finally:
+        lib.wcx_ref_free(ctx.h, hA)
+        if hG:
+            lib.wcx_ref_free(ctx.h, hG)
+    # null ratios: autosomal rows + the gonosomal rows of the gonosomal reference (main.py:216-219)
+    if G is None:
+        nr = A["nr"]
+    else:
+        parts = [A["nr"], G["nr"][ct:]]
+        m = max(p_.shape[1] for p_ in parts)          # ragged (fewer than 100 samples of one gender):
+        parts = [p_ if p_.shape[1] == m else          # padded with NaN like main.py's host merge
+                 torch.cat((p_, torch.full((p_.shape[0], m - p_.shape[1]), float("nan"), dtype=p_.dtype,
+                                           device=p_.device)), 1) for p_ in parts]
+        nr = torch.cat(parts, 0)
+    pt.attach_null_matrix_dev(nr, rem_input["mask"], ctx)
+    rows = pt.exec_cbs_dev(rem_input, out[0], out[2], ctx)
+    if want_host:
+        cache["host"].copy_(out, non_blocking=False)
+        return rows, cache["host"].numpy()
+    return rows
 
 
 def _allreduce2(a, b, world):

@@ -364,6 +364,36 @@ def exec_cbs(rem_input, results, ctx=None):
     return [results_c[i][:3] + [segment_z[i]] + [results_c[i][3]] for i in range(len(results_c))]
 
 
+def exec_cbs_dev(rem_input, d_r, d_w, ctx=None):
+    """exec_cbs on DEVICE-resident per-bin vectors (torch tensors [n_bins] of one sample, as
+    wcx_post_process_merge_dev leaves them; the null matrix attached): CBS + segment z without a
+    NumPy hop.  Returns the rows [chr0, start, end, z, ratio]."""
+    ctx = ctx or _lib.default_context()
+    bpc = [int(v) for v in rem_input["bins_per_chr"]]
+    n_chr = min(24 if rem_input["ref_gender"] == "M" else 23, len(bpc))      # CBS.R:30-34
+    off, off_p = _lib.i64_array(np.concatenate(([0], np.cumsum(bpc[:n_chr]))))
+    n_bins = int(d_r.numel())
+    cap = 4096
+    seg = np.empty((cap, 4))
+    cnt = np.zeros(1, dtype=np.int32)
+    seed = rem_input["args"].seed
+    _lib.check(ctx.lib.wcx_cbs_batch_dev(ctx.h, d_r.data_ptr(), d_w.data_ptr(), 1, n_bins, off_p, n_chr,
+                                         float(rem_input["args"].alpha), int(rem_input["binsize"]),
+                                         0 if seed is None else int(seed), _lib.ptr(seg), cap,
+                                         _lib.ptr(cnt)))
+    n_seg = int(cnt[0])
+    seg = np.ascontiguousarray(seg[:n_seg])
+    z = np.empty(n_seg)
+    nn = np.empty(n_seg)
+    # segment z sees every chromosome of the result vectors (24 for the reference's lists)
+    off_all, off_all_p = _lib.i64_array(np.concatenate(([0], np.cumsum(bpc))))
+    if n_seg:
+        _lib.check(ctx.lib.wcx_segment_z_dev(ctx.h, d_r.data_ptr(), d_w.data_ptr(), off_all_p, len(bpc),
+                                             _lib.ptr(seg), n_seg, _lib.ptr(z), _lib.ptr(nn)))
+    return [[int(s[0]), int(s[1]), int(s[2]), "nan" if nn[i] == 0 else float(z[i]), float(s[3])]
+            for i, s in enumerate(seg)]
+
+
 def run_cbs_batch(results_list, ref_gender, alpha, binsize, seed, ctx=None):
     """CBS of a batch of samples in ONE library call (wcx_cbs_batch): all chromosomes of all
     samples advance together on the device.  results_list: results dicts with the same chromosome
