@@ -2,15 +2,19 @@
 """bench.py -- the WisecondorX newref+predict hot path on MI355X.
 
 Contract (see the task prompt): `python bench.py --gpus N --steps K --warmup W` prints ONE
-JSON line on rank 0.  A "step" = one pass of the hot path over one synthetic batch:
-  newref   reference-bin search of every autosomal bin (all-pairs distance + top-k, k=300)
-           + the null-ratio table, target rows split over the N ranks with the reference's
-           own _get_part formula (newref_tools.py:244-247) after ONE RCCL all-gather of the
-           row-sharded bin-feature matrix X; the finished row blocks are all-gathered so that
-           every rank holds the whole reference (what `newref` writes to disk);
-  predict  one test sample against that reference, complete: cut-off, weights, three masked
-           normalisation passes, post-processing, CBS segmentation, segment z-scores
-           (replicated on every rank: predict has no collective on its path).
+JSON line on rank 0.  A "step" = one pass of the hot path over one synthetic batch = the whole
+`newref` + one `predict`:
+  newref   the three passes of main.py:82-130 -- A (all samples, every autosomal bin), F (the female
+           samples, chrX rows), M (the male samples, chrX + chrY rows): reference-bin search
+           (all-pairs distance + top-k, k=300) + null-ratio table per pass.  Target rows split over
+           the N ranks (A: the reference's own _get_part formula, newref_tools.py:244-247; F / M:
+           their gonosomal rows) after ONE RCCL all-gather per pass of the row-sharded bin-feature
+           matrix X; the finished row blocks are all-gathered so that every rank holds the whole
+           reference (what `newref` writes to disk);
+  predict  one (female) test sample against that reference, complete and device-resident: cut-off,
+           weights, three masked normalisation passes for the autosomes and for the gonosomes, the
+           A + gonosome merge, post-processing, CBS segmentation of 23 chromosomes, segment
+           z-scores (replicated on every rank: predict has no collective on its path).
 Default workload = north_star's headline problem, the size of BASELINE.json configs[3]:
 15 kb bins (hg38, ~5 % of bins masked) x 500 reference samples, refsize 300 -- it fits one
 GPU; with --gpus N the same problem is row-sharded (strong scaling).  Inputs are resident in
@@ -32,7 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 vector == matrix (not in the guide)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA
-SPINUP_STEPS = int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "10"))
+SPINUP_STEPS = int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "0"))   # extra untimed steps (0: only --warmup)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "screen_traffic.json")
 
 
@@ -46,7 +50,8 @@ def screen_source_sha():
 
 
 def make_workload(binsize, n_samples, seed=0, device=0):
-    """Synthetic cohort -> masked, depth-normalised, PCA-corrected X (host, untimed)."""
+    """Synthetic cohort -> masked, depth-normalised, PCA-corrected X of the autosomal pass (host,
+    untimed).  (The single-pass form: scripts/ and tests use it.)"""
     from wisecondorx_amd import prep
     from wisecondorx_amd.synth import Cohort
     co = Cohort(binsize, struct_seed=1234 + seed)
@@ -58,6 +63,30 @@ def make_workload(binsize, n_samples, seed=0, device=0):
     p = prep.prepare(samples, "A", mask, bpc, ctx=_lib.default_context(device))
     test = co.sample(777 + seed, "F", cnv=[(3, 100, 100 + max(4, int(4e7 // binsize)), 1.5)])
     return co, p, test
+
+
+def make_full_workload(binsize, n_samples, seed=0, device=0):
+    """The inputs of the WHOLE newref (main.py:82-130): gender-corrected cohort, the shared mask,
+    and the prepared (masked, depth-normalised, PCA-corrected) matrices of the A, F and M passes;
+    + one female test sample with a planted gain.  Host + PCA on this rank's GPU, untimed."""
+    from wisecondorx_amd import _lib, prep
+    from wisecondorx_amd.overall_tools import gender_correct
+    from wisecondorx_amd.synth import Cohort
+    # (female chrY coverage 10 % of normal: with the default 0.2 % every chrY bin fails the
+    # female-only mask and the M pass has no chrY target rows, SURVEY.md 8d)
+    co = Cohort(binsize, struct_seed=1234 + seed, female_y=0.1)
+    samples, genders = co.cohort(n_samples, seed0=100 + seed)
+    samples = np.array([gender_correct(s_, g_) for s_, g_ in zip(samples, genders)])
+    g = np.array(genders)
+    total_mask, bpc = prep.get_mask(samples)
+    total_mask = total_mask & prep.get_mask(samples[g == "F"])[0] & prep.get_mask(samples[g == "M"])[0]
+    ctx = _lib.default_context(device)
+    n_aut = int(np.sum(bpc[:22]))
+    passes = {"A": prep.prepare(samples, "A", total_mask, bpc, ctx=ctx)}
+    passes["F"] = prep.prepare(samples[g == "F"], "F", total_mask, bpc, ctx=ctx, frozen=n_aut)
+    passes["M"] = prep.prepare(samples[g == "M"], "M", total_mask, bpc, ctx=ctx, frozen=n_aut)
+    test = gender_correct(co.sample(777 + seed, "F", cnv=[(3, 100, 100 + max(4, int(4e7 // binsize)), 1.5)]), "F")
+    return co, passes, test
 
 
 def cpu_baseline(Xs, chr_cum, k, budget_s=10.0):
@@ -150,104 +179,140 @@ class Workload:
         from wisecondorx_amd.newref_tools import _get_part
         self.torch, self.wd, self.pt = torch, wd, predict_tools
         self.rank, self.world, self.args = rank, world, args
-        co, p, test = make_workload(args.binsize, n_samples, device=dev_index)
-        self.p = p
-        X = p["X"]                                   # (B, S) Fortran order
-        self.Xs_host = np.ascontiguousarray(X.T)     # [S][B]
-        self.S, self.B = self.Xs_host.shape
+        co, passes, test = make_full_workload(args.binsize, n_samples, device=dev_index)
         self.k = args.refsize
-        self.cum = np.asarray(p["masked_bins_per_chr_cum"], dtype=np.int64)
-        mb = np.asarray(p["masked_bins_per_chr"], dtype=np.int64)
-        self.pairs_total = int(np.sum(mb * (self.B - mb)))
-        self.row_begin, self.row_end = _get_part(rank, world, self.B)
-        n_rows = self.row_end - self.row_begin
-        shard_rows = wd.max_shard_rows(world, self.B)
-        # this rank's row shard of X (what it would have produced itself), resident in HBM
-        self.Xrow = torch.zeros((shard_rows, self.S), dtype=torch.float64, device=dev)
-        self.Xrow[:n_rows] = torch.from_numpy(
-            np.ascontiguousarray(X[self.row_begin:self.row_end])).to(dev)
-        x_test = predict_tools.project_pc(
-            predict_tools.coverage_normalize_and_mask(test, p, ""), p, "")
-        self.d_x = torch.from_numpy(np.ascontiguousarray(x_test)).to(dev)
-        self.null_ids = np.ascontiguousarray(
-            np.random.default_rng(5).permutation(self.S)[:min(self.S, 100)], dtype=np.int32)
-        m = len(self.null_ids)
         stream = torch.cuda.current_stream().cuda_stream
         self.ctx = _lib.Context(dev_index, stream)
         if args.debug_flags:
             self.ctx.lib.wcx_debug_flags(self.ctx.h, args.debug_flags)
-        self.out_bufs = (torch.empty((shard_rows, self.k), dtype=torch.int32, device=dev),
-                         torch.empty((shard_rows, self.k), dtype=torch.float64, device=dev),
-                         torch.empty((shard_rows, m), dtype=torch.float64, device=dev))
         self.backend = wd.GpuBackend(self.ctx)
+        self.P = {}
+        self.pairs_total = 0
+        for tag in ("A", "F", "M"):
+            p = passes[tag]
+            X = p["X"]                                   # (B, S) Fortran order
+            B, S = X.shape
+            cum = np.asarray(p["masked_bins_per_chr_cum"], dtype=np.int64)
+            mb = np.asarray(p["masked_bins_per_chr"], dtype=np.int64)
+            tgt = mb if tag == "A" else mb * (np.arange(len(mb)) >= 22)     # searched chromosomes
+            pairs = int(np.sum(tgt * (B - mb)))
+            self.pairs_total += pairs
+            rb, re_ = _get_part(rank, world, B)
+            shard_rows = wd.max_shard_rows(world, B)
+            Xrow = torch.zeros((shard_rows, S), dtype=torch.float64, device=dev)
+            Xrow[:re_ - rb] = torch.from_numpy(np.ascontiguousarray(X[rb:re_])).to(dev)
+            m = min(S, 100)
+            ids = np.ascontiguousarray(np.random.default_rng(5).permutation(S)[:m], dtype=np.int32)
+            full_rows = shard_rows if tag == "A" else B
+            self.P[tag] = {"p": p, "B": B, "S": S, "cum": cum, "pairs": pairs, "Xrow": Xrow, "ids": ids,
+                           "bufs": (torch.empty((full_rows, self.k), dtype=torch.int32, device=dev),
+                                    torch.empty((full_rows, self.k), dtype=torch.float64, device=dev),
+                                    torch.empty((full_rows, m), dtype=torch.float64, device=dev))}
+        pa = passes["A"]
+        self.p = pa
+        self.Xs_host = np.ascontiguousarray(pa["X"].T)   # [S][B] of the autosomal pass (verify, cpu_baseline)
+        self.S, self.B = self.Xs_host.shape
+        self.cum = self.P["A"]["cum"]
+        ref = dict(pa)
+        ref.update({k_ + ".F": v for k_, v in passes["F"].items()})
+        pt = predict_tools
+        xA = pt.project_pc(pt.coverage_normalize_and_mask(test, ref, ""), ref, "")
+        xG = pt.project_pc(pt.coverage_normalize_and_mask(test, ref, ".F"), ref, ".F")
+        self.d_xA = torch.from_numpy(np.ascontiguousarray(xA)).to(dev)
+        self.d_xG = torch.from_numpy(np.ascontiguousarray(xG)).to(dev)
         self.pargs = argparse.Namespace(minrefbins=150, alpha=1e-4, seed=1, maskrepeats=5)
-        self.rem = {"args": self.pargs, "mask": p["mask"], "bins_per_chr": p["bins_per_chr"],
+        self.rem = {"args": self.pargs, "mask": passes["F"]["mask"], "bins_per_chr": passes["F"]["bins_per_chr"],
                     "binsize": args.binsize, "ref_gender": "F"}
-        self.ms = {k_: [] for k_ in ("topk", "null_ratios", "normalize", "cbs", "segment_z",
-                                     "predict_full", "gather_ref")}
+        self.names = ("topk", "topk_screen", "topk_prep", "topk_refine", "null_ratios")
+        self.ms = {"{}:{}".format(t, n_): [] for t in ("A", "F", "M") for n_ in self.names}
+        for n_ in ("normalize", "cbs", "segment_z", "predict_full", "gather_ref"):
+            self.ms[n_] = []
         self.fb_rows = []
         self.n_segments = 0
-        self.last = None                             # (idx, dist) of the last step, for verify_rows
+        self.last = None                             # (idx, dist) of the last step's A pass, for verify_rows
+        self.stats_A = None
 
     def step(self, record):
         wd, ctx, torch = self.wd, self.ctx, self.torch
-        # (1) ONE exchange (all-gather of the row shards of X over RCCL/xGMI), then the search +
-        # null ratios of this rank's target rows
-        idx_l, dist_l, nr_l, _ = wd.newref_sharded(self.Xrow, self.B, self.cum, self.k,
-                                                   self.null_ids, self.backend, self.rank,
-                                                   self.world, out=self.out_bufs)
-        if self.args.debug_flags & 3:                # (ablations leave garbage neighbour tables)
-            ctx.sync()
-            if record:
-                self.ms["topk"].append(ctx.kernel_ms("topk"))
-            return
-        # (2) every rank gets the whole reference (rank 0 would write it to disk)
-        if record and self.world > 1:
-            torch.cuda.synchronize()
+        ref = {}
+        for tag in ("A", "F", "M"):
+            P = self.P[tag]
+            ctx.timer_tag(tag + ":")
+            if tag == "A":
+                # ONE exchange (all-gather of the row shards of X over RCCL/xGMI), the search + null
+                # ratios of this rank's target rows, then every rank gets the whole tables
+                idx_l, dist_l, nr_l, _ = wd.newref_sharded(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
+                                                           self.backend, self.rank, self.world, out=P["bufs"])
+                if self.args.debug_flags & 3:            # (ablations leave garbage neighbour tables)
+                    ctx.timer_tag("")
+                    ctx.sync()
+                    if record:
+                        self.ms["A:topk"].append(ctx.kernel_ms("A:topk"))
+                        self.ms["A:topk_screen"].append(ctx.kernel_ms("A:topk_screen"))
+                    return
+                t0 = time.perf_counter()
+                idx, dist_, nr = wd.gather_reference3(idx_l, dist_l, nr_l, P["B"], self.world, self.backend)
+                if record and self.world > 1:
+                    torch.cuda.synchronize()
+                    self.ms["gather_ref"].append(1e3 * (time.perf_counter() - t0))
+                self.last = (idx, dist_)
+                if record and self.stats_A is None:
+                    # counters of the A pass (rows, appends, fallbacks): read once, in the first timed
+                    # step, before the F pass resets them (this read synchronises)
+                    self.stats_A = ctx.topk_stats()
+            else:
+                idx, dist_, nr = wd.newref_gonosomal_sharded(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
+                                                             self.backend, self.rank, self.world, P["bufs"])
+            ref[tag] = {"idx": idx, "dist": dist_, "nr": nr, "cum": P["cum"]}
+        ctx.timer_tag("")
+        # predict ONE sample, complete (replica on every rank): autosomes vs A, gonosomes vs F
         t0 = time.perf_counter()
-        idx, dist_, nr = wd.gather_reference3(idx_l, dist_l, nr_l, self.B, self.world, self.backend)
-        self.last = (idx, dist_)
-        if record and self.world > 1:
-            torch.cuda.synchronize()
-            self.ms["gather_ref"].append(1e3 * (time.perf_counter() - t0))
-        # (3) predict ONE sample, complete (replica on every rank)
-        t0 = time.perf_counter()
-        res = wd.predict_one_dev(self.backend, idx, dist_, nr, self.d_x, self.B, self.k, self.cum,
-                                 self.rem, self.pt)
+        res = wd.predict_full_dev(self.backend, ref["A"], ref["F"], self.d_xA, self.d_xG, self.rem, self.pt)
         self.n_segments = len(res)
         if record:
             self.ms["predict_full"].append(1e3 * (time.perf_counter() - t0))
-            for name in ("topk", "null_ratios", "normalize", "cbs", "segment_z"):
+            self.ms["normalize"].append(ctx.kernel_ms("aut:normalize") + max(0.0, ctx.kernel_ms("normalize")))
+            for name in ("cbs", "segment_z"):
                 self.ms[name].append(ctx.kernel_ms(name))
-            self.fb_rows.append(ctx.topk_stats()["fallback_rows"])
+            for tag in ("A", "F", "M"):
+                for n_ in self.names:
+                    self.ms["{}:{}".format(tag, n_)].append(ctx.kernel_ms("{}:{}".format(tag, n_)))
+            self.fb_rows.append(self.stats_A["fallback_rows"] if self.stats_A else -1)
+
+    def mean_ms(self, name):
+        v = [x for x in self.ms.get(name, []) if x is not None and x >= 0]
+        return float(np.mean(v)) if v else -1.0
 
     def roofline(self):
-        ctx, S = self.ctx, self.S
-        stats = ctx.topk_stats()
-        k_ms = float(np.mean(self.ms["topk"])) if self.ms["topk"] else ctx.kernel_ms("topk")
-        screen_ms = ctx.kernel_ms("topk_screen")
+        S = self.S
+        stats = self.stats_A or self.ctx.topk_stats()
+        k_ms = self.mean_ms("A:topk")
+        screen_ms = self.mean_ms("A:topk_screen")
+        pairs_A = self.P["A"]["pairs"]
+        if self.world > 1:
+            pairs_A = stats["pairs"]                     # this rank's share
         if screen_ms >= 0:
             # MFMA screen: algorithmic work = the -2 X^T X Gram GEMM, 2*S flop per candidate pair
             # (SURVEY.md §8d).  The kernel executes one fp16 product over K = 16*NK >= S + 4 (four
             # augmented columns carry the norm and the threshold), reported as executed_tflops.
             nk_list = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32]
             nk = next(v for v in nk_list if 16 * v >= S + 4)   # same rule as wcx_topk_screen_launch
-            flops = 2.0 * S * stats["pairs"]
+            flops = 2.0 * S * pairs_A
             achieved = flops / (screen_ms * 1e-3) / 1e12
-            r = {"kernel": "k_screen (v_mfma_f32_32x32x16_f16, fp16 hi plane, fp32 acc) + fused "
-                           "top-k filter", "bound": "mfma", "achieved": achieved,
+            r = {"kernel": "k_screen of the autosomal pass (v_mfma_f32_32x32x16_f16, fp16 hi plane, fp32 "
+                           "acc) + fused top-k filter", "bound": "mfma", "achieved": achieved,
                  "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": screen_ms,
-                 "executed_tflops": 2.0 * nk * 16 * stats["pairs"] / (screen_ms * 1e-3) / 1e12,
-                 "prep_ms": ctx.kernel_ms("topk_prep"), "refine_ms": ctx.kernel_ms("topk_refine"),
-                 "topk_total_ms": k_ms, "pairs_per_launch": stats["pairs"],
+                 "executed_tflops": 2.0 * nk * 16 * pairs_A / (screen_ms * 1e-3) / 1e12,
+                 "prep_ms": self.mean_ms("A:topk_prep"), "refine_ms": self.mean_ms("A:topk_refine"),
+                 "topk_total_ms": k_ms, "pairs_per_launch": pairs_A,
                  "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": self.fb_rows,
                  "compactions": stats["compactions"], "appends": stats["appends"],
                  "refined_pairs": stats["refined"],
-                 "kernel_ms_note": "wall time of one whole sweep (HIP events on the launch stream, second "
-                                   "stream joined by an event); the target blocks sweep in two halves "
-                                   "on two concurrent streams, so rocprofv3's average launch duration x "
-                                   "launches per sweep / 2 is the figure to compare with",
+                 "kernel_ms_note": "wall time of one whole sweep of the A pass (HIP events on the launch "
+                                   "stream, second stream joined by an event); the target blocks sweep in "
+                                   "two halves on two concurrent streams, so rocprofv3's average launch "
+                                   "duration x launches per sweep / 2 is the figure to compare with",
                  "attainable_note": "the dense-f16 peak is not attainable on random data: a bare "
                                     "LDS-fed MFMA loop with DMA staging and no epilogue is power-limited "
                                     "to 1.1-1.35 PFLOP/s on this chip, box to box (1.9-2.0 on all-zero "
@@ -255,15 +320,21 @@ class Workload:
             if any(stats["phase_cycles"]):          # only with --debug-flags 4
                 r["phase_cycles"] = stats["phase_cycles"]
         else:
-            flops = 3.0 * S * stats["pairs"]         # exact path: sub, mul, add per (pair, sample)
+            flops = 3.0 * S * pairs_A                # exact path: sub, mul, add per (pair, sample)
             achieved = flops / (k_ms * 1e-3) / 1e12
             r = {"kernel": "k_topk_exact (fp64 VALU, 3 flop per pair-sample)", "bound": "mfma",
                  "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel_ms": k_ms,
-                 "pairs_per_launch": stats["pairs"], "compactions": stats["compactions"]}
-        for name in ("null_ratios", "normalize", "cbs", "segment_z", "predict_full", "gather_ref"):
+                 "pairs_per_launch": pairs_A, "compactions": stats["compactions"]}
+        r["null_ratios_ms"] = self.mean_ms("A:null_ratios")
+        for name in ("normalize", "cbs", "segment_z", "predict_full", "gather_ref"):
             if self.ms[name]:
-                r[name + "_ms"] = float(np.mean(self.ms[name]))
+                r[name + "_ms"] = self.mean_ms(name)
+        r["gonosomal_passes"] = {
+            tag: {"rows": int(self.P[tag]["B"] - int(self.P[tag]["cum"][21])), "samples": int(self.P[tag]["S"]),
+                  "pairs": self.P[tag]["pairs"], "topk_ms": self.mean_ms(tag + ":topk"),
+                  "screen_ms": self.mean_ms(tag + ":topk_screen"), "refine_ms": self.mean_ms(tag + ":topk_refine"),
+                  "null_ratios_ms": self.mean_ms(tag + ":null_ratios")} for tag in ("F", "M")}
         return r, screen_ms
 
 
@@ -358,19 +429,23 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "newref {} kb bins: B={} masked autosomal bins x S={} samples, "
-                               "refsize={} (search + null ratios + gather of the reference), + "
-                               "predict of 1 sample (cut-off, weights, 3 normalisation passes, "
-                               "post-processing, CBS, segment z)".format(
-                                   args.binsize // 1000, w.B, w.S, w.k),
+        "config": {"workload": "newref {} kb bins, {} samples, refsize={}: A pass (B={} masked autosomal "
+                               "bins x S={}) + F pass ({} chrX rows x S={}) + M pass ({} chrX/Y rows x "
+                               "S={}), each search + null ratios + gather of the reference; + predict of "
+                               "1 sample (cut-off, weights, 3 normalisation passes for autosomes and "
+                               "gonosomes, merge, post-processing, CBS of 23 chromosomes, segment z)".format(
+                                   args.binsize // 1000, w.S, w.k,
+                                   w.B, w.S, w.P["F"]["B"] - int(w.P["F"]["cum"][21]), w.P["F"]["S"],
+                                   w.P["M"]["B"] - int(w.P["M"]["cum"][21]), w.P["M"]["S"]),
                    "bins": int(w.B), "samples": int(w.S), "refsize": int(w.k),
                    "pairs": w.pairs_total, "bin_samples_per_s": w.B * w.S / (ms_per_step * 1e-3),
                    "spinup_steps_untimed": SPINUP_STEPS, "predict_segments": w.n_segments,
                    "precision": "indices and distances bit-identical to the reference's fp64 path; the "
                                 "fp16 MFMA product is only a rigorously bounded pre-filter, every "
                                 "kept pair is re-evaluated in sequential fp64",
-                   "partition": "target rows x{} (_get_part): one all-gather(X) for the search, one "
-                                "all-gather of the finished row blocks; predict replicated".format(world)},
+                   "partition": "target rows x{} (A: _get_part over all rows; F / M: over their gonosomal "
+                                "rows): per pass one all-gather(X) for the search and one all-gather of "
+                                "the finished row blocks; predict replicated".format(world)},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_secondary and not args.debug_flags \

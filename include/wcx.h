@@ -64,6 +64,10 @@ int wcx_memcpy_d2h(wcx_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
  * with hipEvents on the context's stream ("topk", "null_ratios", "normalize", "cutoff",
  * "weights", "cbs", "segment_z"); synchronises the stream.  <0 if never launched. */
 double wcx_last_kernel_ms(wcx_ctx *ctx, const char *name);
+/* Prefix for the timer names of the calls that follow ("A:" -> "A:topk", ...; NULL or "" = none), so
+ * that a caller running several passes per step (newref's A / F / M) can read each pass's timers at
+ * the end without synchronising in between. */
+int wcx_timer_tag(wcx_ctx *ctx, const char *tag);
 /* Counters of the last wcx_newref_topk*: [0] rows searched, [1] candidate pairs evaluated,
  * [2] shortlist compactions, [3] rows that fell back to the exact brute-force path,
  * [4] pairs that passed the MFMA screen (shortlist appends), [5..7] reserved (0),

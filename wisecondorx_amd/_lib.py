@@ -22,6 +22,7 @@ vp = C.c_void_p
 SIGNATURES = {
     "wcx_version": (C.c_int, []),
     "wcx_debug_flags": (C.c_int, [vp, C.c_int]),
+    "wcx_timer_tag": (C.c_int, [vp, C.c_char_p]),
     "wcx_last_error": (C.c_char_p, []),
     "wcx_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
     "wcx_ctx_destroy": (C.c_int, [vp]),
@@ -172,6 +173,9 @@ class Context:
 
     def sync(self):
         check(self.lib.wcx_sync(self.h))
+
+    def timer_tag(self, tag):
+        check(self.lib.wcx_timer_tag(self.h, (tag or "").encode()))
 
     def kernel_ms(self, name):
         return float(self.lib.wcx_last_kernel_ms(self.h, name.encode()))

@@ -84,7 +84,7 @@ int wcx_upload_small(wcx_ctx *ctx, void *dst_dev, const void *src_host, size_t b
 }
 
 int wcx_timer_begin(wcx_ctx *ctx, const char *name) {
-  KernelTimer &t = ctx->timers[name];
+  KernelTimer &t = ctx->timers[ctx->timer_tag + name];
   if (!t.start) {
     WCX_HIP(hipEventCreate(&t.start));
     WCX_HIP(hipEventCreate(&t.stop));
@@ -94,7 +94,7 @@ int wcx_timer_begin(wcx_ctx *ctx, const char *name) {
 }
 
 int wcx_timer_end(wcx_ctx *ctx, const char *name) {
-  KernelTimer &t = ctx->timers[name];
+  KernelTimer &t = ctx->timers[ctx->timer_tag + name];
   WCX_HIP(hipEventRecord(t.stop, ctx->stream));
   t.used = true;
   return WCX_OK;
@@ -112,6 +112,12 @@ int wcx_debug_flags(wcx_ctx *ctx, int flags) {
 }
 
 const char *wcx_last_error(void) { return g_err; }
+
+int wcx_timer_tag(wcx_ctx *ctx, const char *tag) {
+  WCX_ARG(ctx, "ctx is NULL");
+  ctx->timer_tag = tag ? tag : "";
+  return WCX_OK;
+}
 
 int wcx_ctx_create(int device, void *stream, wcx_ctx **out) {
   WCX_ARG(out != nullptr, "out is NULL");

@@ -583,7 +583,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // the sampled pre-pass and 2-3 resident workgroups per CU the split no longer pays -- 1 segment
   // is as fast or faster down to 178 blocks -- so it is off unless asked for)
   int n_seg = 1;
-  (void)slots;
+  // ... except for very small shards: the gonosomal passes search ~80-100 blocks of chrX / chrY
+  // rows on 512 slots; 1 / 2 / 4 segments: F pass 7.7 / 6.8 / 6.4 ms, M pass 8.8 / 7.6 / 7.4 ms
+  // (15 kb, 250 samples each, profiles/r03)
+  if ((int)blocks.size() * 4 <= slots) n_seg = env_int("WCX_SCREEN_SEGMENTS_SMALL", 4);
   n_seg = env_int("WCX_SCREEN_SEGMENTS", n_seg);
   if (n_seg < 1) n_seg = 1;
   if (n_seg > 8) n_seg = 8;

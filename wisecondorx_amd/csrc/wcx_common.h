@@ -41,6 +41,7 @@ struct wcx_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::map<std::string, KernelTimer> timers;
+  std::string timer_tag;                  // prefix of the timer names (wcx_timer_tag)
   int debug_flags = 0;                    // diagnostics (wcx_debug_flags): per context
   int64_t topk_stats[4] = {0, 0, 0, 0};
   unsigned long long *d_stats = nullptr;  // 16 device counters

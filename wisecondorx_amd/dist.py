@@ -200,6 +200,43 @@ def newref_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, wo
     return out[0][:n], out[1][:n], out[2][:n], Xs
 
 
+def newref_gonosomal_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, world, full):
+    """A gonosomal pass (F: 23 chromosomes, M: 24) of the sharded reference build.  Only the X (and Y)
+    rows are searched (newref_tools.py:186-191); with the reference's own _get_part over ALL rows
+    they would sit in the last rank(s), so the GONOSOMAL rows [ct, n_rows) are what is split over
+    the ranks here.  One all-gather of this pass's X, the search + null ratios of this rank's
+    gonosomal rows, one all-gather of those (small) row blocks; the dummy autosomal rows (index 0,
+    distance 1, null ratio log2(x / x[0])) are written by every rank itself.
+    full = (idx [n_rows,k] int32, dist [n_rows,k] f64, nr [n_rows,m] f64) device buffers that
+    receive the complete tables of the pass.  Returns them."""
+    import torch
+    if world > 1 and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
+        Xs = backend.gather_transpose(gather_padded(local_rows, world), world, local_rows.shape[0], n_rows)
+    else:
+        fullX = allgather_rows(local_rows, n_rows, world).contiguous()
+        Xs = backend.transpose(fullX) if hasattr(backend, "transpose") else fullX.t().contiguous()
+    S = Xs.shape[0]
+    ct = int(chr_cum[21])
+    if world == 1:
+        backend.search(Xs, n_rows, S, chr_cum, 0, n_rows, k, sample_ids, full[0], full[1], full[2])
+        return full
+    n_g = n_rows - ct
+    a, b = _get_part(rank, world, n_g)
+    pad = max_shard_rows(world, n_g)
+    dev = local_rows.device
+    loc = (torch.empty((pad, k), dtype=torch.int32, device=dev),
+           torch.empty((pad, k), dtype=torch.float64, device=dev),
+           torch.empty((pad, len(sample_ids)), dtype=torch.float64, device=dev))
+    if b > a:
+        backend.search(Xs, n_rows, S, chr_cum, ct + a, ct + b, k, sample_ids, loc[0], loc[1], loc[2])
+    gathered = tuple(allgather_rows(t, n_g, world, backend=backend) for t in loc)
+    if ct:
+        backend.search(Xs, n_rows, S, chr_cum, 0, ct, k, sample_ids, full[0], full[1], full[2])   # dummies
+    for dst, src in zip(full, gathered):
+        dst[ct:n_rows].copy_(src)
+    return full
+
+
 def _padded(t, pad):
     import torch
     if t.shape[0] == pad:
@@ -337,9 +374,11 @@ def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
         cutoff = _lib.C.c_double()
         _lib.check(lib.wcx_cutoff(ctx.h, hA, int(args.maskrepeats), _lib.C.byref(cutoff)))
         _lib.check(lib.wcx_weights_dev(ctx.h, hA, a[3].data_ptr()))
+        ctx.timer_tag("aut:")
         _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hA, d_xA.data_ptr(), 1, cutoff.value, 0, 0,
                                                  a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
                                                  med[0:].data_ptr(), med[1:].data_ptr()))
+        ctx.timer_tag("")
         if G is not None:
             _lib.check(lib.wcx_ref_wrap_dev(ctx.h, G["idx"].data_ptr(), G["dist"].data_ptr(), BG_all, k,
                                             cumG_p, len(cumG), _lib.C.byref(hG)))
