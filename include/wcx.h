@@ -193,6 +193,18 @@ int wcx_post_process_dev(wcx_ctx *ctx, const double *d_z, const double *d_r, con
                          double minrefbins, const int32_t *d_pos, int64_t n_bins, double *out_r,
                          double *out_z, double *out_w);
 
+/* Sample preparation of a batch on the device: predict_tools.coverage_normalize_and_mask
+ * (predict_tools.py:32-48: counts / total read count over the bins of this pass, masked bins dropped)
+ * followed by predict_tools.project_pc (predict_tools.py:56-65 with the scikit-learn <= 1.4 transform
+ * the reference pins: x / (((x - mean) . C^T) . C + mean)).  d_counts int32[n_samples][n_bins]: the
+ * samples' bin counts laid out over the reference's bins (each chromosome truncated or zero-padded to
+ * bins_per_chr{ap}: a host memcpy per chromosome); d_pos int32[B] = unmasked position of masked bin i;
+ * d_mean double[B], d_comps double[n_comp][B] = pca_mean{ap}, pca_components{ap} (n_comp must be 5).
+ * d_x double[n_samples][B] receives the projected vectors wcx_predict_normalize_dev takes. */
+int wcx_predict_prep_dev(wcx_ctx *ctx, const int32_t *d_counts, int n_samples, int64_t n_bins,
+                         const int32_t *d_pos, int64_t B, const double *d_mean, const double *d_comps,
+                         int n_comp, double *d_x);
+
 /* The general, batched form: main.py:242-257 (autosomal + gonosomal results appended, z - m_z of the
  * autosomal pass, w = append(wA * nanmean(wG), wG * nanmean(wA)) / nanmean(...), all weights 1 if any
  * is NaN / inf), predict_control.get_post_processed_result for r, z, w (predict_control.py:49-63)
@@ -297,6 +309,12 @@ int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *
  * and the attached null matrix. */
 int wcx_segment_z_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, const int64_t *chr_off,
                       int n_chr, const double *seg, int n_seg, double *out_z, double *out_nnull);
+/* ... and for a batch in ONE call: d_r, d_w double[n_samples][chr_off[n_chr]], the segments of all
+ * samples listed sample by sample (seg_count[i] of them for sample i, as wcx_cbs_batch_dev leaves them
+ * after compaction), out_z / out_nnull in the same order. */
+int wcx_segment_z_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_samples,
+                            const int64_t *chr_off, int n_chr, const double *seg,
+                            const int *seg_count, double *out_z, double *out_nnull);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,31 @@ def main():
                            tests))
     t_host_prep_threaded = time.perf_counter() - t
     assert np.array_equal(np.stack(xs_t), xs)
+    # ---- the same batch DEVICE-RESIDENT end to end (dist.predict_batch_dev): normalisation outputs
+    # stay in HBM through the merge / post-processing kernel, the batched CBS and the batched segment z
+    import torch
+    from wisecondorx_amd import dist as wd
+    dev = torch.device("cuda", 0)
+    ctx_t = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx_t)
+    tt = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    A = {"idx": tt(idx), "dist": tt(dist), "nr": tt(nr), "cum": cum}
+    rem_dev = dict(rem, args=argparse.Namespace(minrefbins=150, alpha=1e-4, seed=1, maskrepeats=5))
+    t_dev, t_prep_dev = [], []
+    prep_cache = {}
+    for _ in range(3):
+        t = time.perf_counter()
+        # sample preparation on the device too: counts laid out over the reference's bins (host
+        # memcpys), one H2D, coverage normalisation + mask + PCA projection in three kernels
+        d_counts = torch.from_numpy(pt.sample_counts_matrix(tests, ref, "")).to(dev)
+        d_x = pt.prepare_batch_dev(d_counts, ref, "", ctx_t, prep_cache)
+        ctx_t.sync()
+        t_prep_dev.append(time.perf_counter() - t)
+        rows_dev = wd.predict_batch_dev(be, A, None, d_x, None, rem_dev, pt)
+        t_dev.append(time.perf_counter() - t)
+    x_err = float(np.max(np.abs(d_x.cpu().numpy() / xs - 1.0)))
+    same = [[r_[:3] for r_ in rows_dev[i]] == [r_[:3] for r_ in all_segs[i]] for i in range(a.batch)]
+    dev_ms = {k_: ctx_t.kernel_ms(k_) for k_ in ("aut:normalize", "cbs", "segment_z")}
     print(json.dumps({
         "workload": "predict batch: {} samples, {} kb bins, B={}, k=300".format(a.batch, a.binsize // 1000, cum[-1]),
         "newref_host_api_s": t_newref, "host_prep_per_sample_ms": 1e3 * t_host_prep / a.batch,
@@ -107,6 +132,10 @@ def main():
         "post_cbs_segz_per_sample_ms_threaded": 1e3 * t_batch / a.batch,
         "host_prep_threaded_per_sample_ms": 1e3 * t_host_prep_threaded / a.batch,
         "whole_batch_s": t_host_prep_threaded + t_norm + t_batch,
+        "device_resident_batch_s": min(t_dev), "device_resident_runs_s": t_dev,
+        "device_resident_kernel_ms": dev_ms, "device_resident_same_segments": int(sum(same)),
+        "device_prep_s": min(t_prep_dev), "device_prep_max_rel_err_vs_host": x_err,
+        "whole_batch_device_resident_s": min(t_dev),
         "batch_segments": int(sum(len(x) for x in all_segs))}))
 
 

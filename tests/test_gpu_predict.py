@@ -260,3 +260,39 @@ def test_device_resident_full_predict_golden(pt, g_pipe, name):
         assert np.array_equal(nn == 0, g[name + "_segz_isstr"])
         got = np.where(nn == 0, np.nan, z)
         np.testing.assert_allclose(got, g[name + "_segz"], rtol=1e-9, atol=1e-9, equal_nan=True)
+
+
+def test_device_prep_and_batch_equals_single(pt, g_pipe):
+    """wcx_predict_prep_dev (coverage normalisation + mask + PCA projection on the device) against
+    coverage_normalize_and_mask + project_pc (pinned to the reference through the golden normalise
+    test); predict_batch_dev of the three golden samples (female reference) == three single-sample
+    calls, bit for bit (per-bin vectors and result rows)."""
+    import torch
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd import dist as wd
+    g = g_pipe
+    ref = ref_dict_from_golden(g)
+    samples = [sample_from_counts(g[n + "_counts"], g["cohort_bpc"]) for n in ("t0", "t1", "t2")]
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xs = {}
+    for ap in ("", ".F"):
+        d_counts = t(pt.sample_counts_matrix(samples, ref, ap))
+        x = pt.prepare_batch_dev(d_counts, ref, ap, ctx)
+        host = np.stack([pt.project_pc(pt.coverage_normalize_and_mask(s, ref, ap), ref, ap) for s in samples])
+        np.testing.assert_allclose(x.cpu().numpy(), host, rtol=1e-12)
+        xs[ap] = x
+    A = {"idx": t(ref["indexes"]), "dist": t(ref["distances"]), "nr": t(ref["null_ratios"]),
+         "cum": ref["masked_bins_per_chr_cum"]}
+    G = {"idx": t(ref["indexes.F"]), "dist": t(ref["distances.F"]), "nr": t(ref["null_ratios.F"]),
+         "cum": ref["masked_bins_per_chr_cum.F"]}
+    args = argparse.Namespace(minrefbins=20, maskrepeats=5, alpha=1e-3, seed=3)
+    rem = {"args": args, "mask": ref["mask.F"], "bins_per_chr": ref["bins_per_chr.F"],
+           "binsize": int(ref["binsize"]), "ref_gender": "F"}
+    rows_b, host_b = wd.predict_batch_dev(be, A, G, xs[""], xs[".F"], rem, pt, want_host=True)
+    for i in range(3):
+        rows_1, host_1 = wd.predict_full_dev(be, A, G, xs[""][i], xs[".F"][i], rem, pt, want_host=True)
+        assert rows_1 == rows_b[i]
+        assert np.array_equal(host_1, host_b[:, i, :], equal_nan=True)

@@ -23,6 +23,7 @@ SIGNATURES = {
     "wcx_version": (C.c_int, []),
     "wcx_debug_flags": (C.c_int, [vp, C.c_int]),
     "wcx_timer_tag": (C.c_int, [vp, C.c_char_p]),
+    "wcx_predict_prep_dev": (C.c_int, [vp, vp, C.c_int, c_i64, vp, c_i64, vp, vp, C.c_int, vp]),
     "wcx_last_error": (C.c_char_p, []),
     "wcx_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
     "wcx_ctx_destroy": (C.c_int, [vp]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "wcx_cbs_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, c_i64, c_i64p, C.c_int, C.c_double, c_i64, C.c_uint64,
                                     vp, C.c_int, vp]),
     "wcx_segment_z_dev": (C.c_int, [vp, vp, vp, c_i64p, C.c_int, vp, C.c_int, vp, vp]),
+    "wcx_segment_z_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, c_i64p, C.c_int, vp, vp, vp, vp]),
     "wcx_post_process_merge_dev": (C.c_int, [vp, vp, vp, vp, vp, c_i64, vp, vp, vp, vp, c_i64, C.c_int, vp, vp,
                                              C.c_double, vp, c_i64, vp, vp, vp, vp]),
     "wcx_null_ratios_dummy_dev": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64, c_i64, c_i32p, C.c_int, vp]),

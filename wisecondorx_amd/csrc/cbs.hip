@@ -19,6 +19,7 @@ constexpr int SZ_CHUNK = 256;
 __global__ __launch_bounds__(128) void k_segz_partial(const double *__restrict__ r,
                                                       const double *__restrict__ w,
                                                       const double *__restrict__ nr, int m,
+                                                      int64_t nb,   // rows of nr: bin = b mod nb (batches)
                                                       const int64_t *__restrict__ cb0,
                                                       const int64_t *__restrict__ cb1,
                                                       double *__restrict__ pnum,
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(128) void k_segz_partial(const double *__restrict__
   int any = 0;
   for (int64_t b = cb0[c]; b < cb1[c]; ++b) {
     if (r[b] == 0.0) continue;                      // overall_tools.py:98-100
-    const double v = nr[b * m + j];
+    const double v = nr[(b % nb) * m + j];
     if (fabs(v) < HUGE_VAL) { num += v * w[b]; den += w[b]; any = 1; }   // :101-110
   }
   pnum[(int64_t)c * m + j] = num;
@@ -153,7 +154,8 @@ int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
 
 static int segment_z_impl(wcx_ctx *ctx, const double *r, const double *w, bool rw_on_device,
                           const double *nr, int m, const int64_t *chr_off, int n_chr,
-                          const double *seg, int n_seg, double *out_z, double *out_nnull) {
+                          const double *seg, int n_seg, double *out_z, double *out_nnull,
+                          int n_samples = 1, const int *seg_count = nullptr) {
   WCX_ARG(ctx && r && w && chr_off && seg && out_z, "NULL argument");
   WCX_ARG(n_chr > 0 && n_seg >= 0, "bad sizes");
   if (n_seg == 0) return WCX_OK;
@@ -167,12 +169,17 @@ static int segment_z_impl(wcx_ctx *ctx, const double *r, const double *w, bool r
   WCX_ARG(m > 0 && m <= 128, "bad sizes (m <= 128)");
   std::vector<int64_t> b0(n_seg), b1(n_seg);
   std::vector<double> sr(n_seg);
+  int smp = 0, left = seg_count ? seg_count[0] : n_seg;      // batches: segments listed sample by sample
   for (int s = 0; s < n_seg; ++s) {
+    while (seg_count && left == 0 && smp + 1 < n_samples) left = seg_count[++smp];
+    --left;
     const int c = (int)seg[s * 4];
     WCX_ARG(c >= 0 && c < n_chr, "segment chromosome out of range");
     b0[s] = chr_off[c] + (int64_t)seg[s * 4 + 1];
     b1[s] = chr_off[c] + (int64_t)seg[s * 4 + 2];
     WCX_ARG(b0[s] >= chr_off[c] && b1[s] <= chr_off[c + 1] && b0[s] <= b1[s], "segment out of range");
+    b0[s] += (int64_t)smp * nb;
+    b1[s] += (int64_t)smp * nb;
     sr[s] = seg[s * 4 + 3];
   }
   // chunk table: segment s owns chunks [chunk0[s], chunk0[s+1])
@@ -187,7 +194,7 @@ static int segment_z_impl(wcx_ctx *ctx, const double *r, const double *w, bool r
   }
   chunk0[n_seg] = (int)cb0.size();
   const size_t n_chunks = cb0.size();
-  const size_t vb = (size_t)nb * 8, nrb = attached ? 0 : (size_t)nb * m * 8, sb = (size_t)n_seg * 8;
+  const size_t vb = rw_on_device ? 8 : (size_t)nb * 8, nrb = attached ? 0 : (size_t)nb * m * 8, sb = (size_t)n_seg * 8;
   const size_t cb = (n_chunks + 1) * 8, pb = (n_chunks + 1) * (size_t)m * 8;
   void *scr = nullptr;
   int rc = wcx_scratch(ctx, 2 * vb + nrb + 4 * sb + 2 * cb + 3 * pb + 4096, &scr);
@@ -223,7 +230,7 @@ static int segment_z_impl(wcx_ctx *ctx, const double *r, const double *w, bool r
   rc = wcx_timer_begin(ctx, "segment_z");
   if (rc) return rc;
   if (n_chunks)
-    k_segz_partial<<<(unsigned)n_chunks, 128, 0, st>>>(dr, dw, attached ? ctx->d_nullm : dnr, m, dcb0,
+    k_segz_partial<<<(unsigned)n_chunks, 128, 0, st>>>(dr, dw, attached ? ctx->d_nullm : dnr, m, nb, dcb0,
                                                        dcb1, dpnum, dpden, dpany);
   k_segment_z<<<n_seg, 128, 0, st>>>(dpnum, dpden, dpany, m, dchunk0, dsr, n_seg, dz, dn);
   WCX_HIP(hipGetLastError());
@@ -244,6 +251,16 @@ int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *
 int wcx_segment_z_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, const int64_t *chr_off,
                       int n_chr, const double *seg, int n_seg, double *out_z, double *out_nnull) {
   return segment_z_impl(ctx, d_r, d_w, true, nullptr, 0, chr_off, n_chr, seg, n_seg, out_z, out_nnull);
+}
+
+int wcx_segment_z_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_samples,
+                            const int64_t *chr_off, int n_chr, const double *seg,
+                            const int *seg_count, double *out_z, double *out_nnull) {
+  WCX_ARG(n_samples > 0 && seg_count, "bad parameters");
+  int n_seg = 0;
+  for (int s = 0; s < n_samples; ++s) n_seg += seg_count[s];
+  return segment_z_impl(ctx, d_r, d_w, true, nullptr, 0, chr_off, n_chr, seg, n_seg, out_z, out_nnull,
+                        n_samples, seg_count);
 }
 
 }  // extern "C"

@@ -579,6 +579,82 @@ __global__ __launch_bounds__(256) void k_post_process(
   full[2 * n_bins + p] = good ? (wmean[1] != 0.0 ? 1.0 : w[i] / wmean[0]) : 0.0;
 }
 
+// ---- sample preparation of a batch on the device (wcx_predict_prep_dev) -----------------------------
+// total read count of a sample over the bins of this pass (predict_tools.py:46: before masking)
+__global__ __launch_bounds__(1024) void k_prep_total(const int32_t *__restrict__ counts, int64_t n_bins,
+                                                     double *__restrict__ total) {
+  __shared__ double red[16];
+  const int32_t *c = counts + (int64_t)blockIdx.x * n_bins;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n_bins; i += 1024) s += (double)c[i];   // (integers: exact below 2^53)
+  s = wcx::wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int q = 0; q < 16; ++q) t += red[q];
+    total[blockIdx.x] = t;
+  }
+}
+
+// x[s][i] = counts[s][pos[i]] / total[s]; partial dot products of (x - mean) with the NC components
+// (PSL fixed slices of the bins per sample, reduced in order by k_prep_project: deterministic)
+constexpr int PSL = 64;
+template <int NC>
+__global__ __launch_bounds__(256) void k_prep_depth(const int32_t *__restrict__ counts, int64_t n_bins,
+                                                    const double *__restrict__ total,
+                                                    const int32_t *__restrict__ pos, int64_t B,
+                                                    const double *__restrict__ mean,
+                                                    const double *__restrict__ comps,
+                                                    double *__restrict__ x, double *__restrict__ part) {
+  __shared__ double red[NC][4];
+  const int s = blockIdx.y, sl = blockIdx.x;
+  const int64_t per = (B + PSL - 1) / PSL, lo = sl * per, hi = lo + per < B ? lo + per : B;
+  const int32_t *c = counts + (int64_t)s * n_bins;
+  const double tot = total[s];
+  double acc[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const double v = (double)c[pos[i]] / tot;
+    x[(int64_t)s * B + i] = v;
+    const double e = v - mean[i];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] += comps[(int64_t)q * B + i] * e;
+  }
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    const double t = wcx::wave_sum(acc[q]);
+    if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NC)
+    part[((int64_t)s * PSL + sl) * NC + threadIdx.x] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// predict_tools.py:56-65 (scikit-learn <= 1.4 transform): x / ((t . C) + mean), t = (x - mean) . C^T
+template <int NC>
+__global__ __launch_bounds__(256) void k_prep_project(const double *__restrict__ part, int64_t B,
+                                                      const double *__restrict__ mean,
+                                                      const double *__restrict__ comps,
+                                                      double *__restrict__ x) {
+  const int s = blockIdx.y;
+  double t[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    double a = 0.0;
+    for (int sl = 0; sl < PSL; ++sl) a += part[((int64_t)s * PSL + sl) * NC + q];
+    t[q] = a;
+  }
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  double rec = mean[i];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) rec += t[q] * comps[(int64_t)q * B + i];
+  x[(int64_t)s * B + i] = x[(int64_t)s * B + i] / rec;
+}
+
 // ---- A + gonosome merge + post-processing of a batch (wcx_post_process_merge_dev) ----------------
 // weight statistics of one weight vector: {nanmean, count of non-NaN, non-finite entries}
 __global__ __launch_bounds__(1024) void k_wstats(const double *__restrict__ w, int64_t n,
@@ -785,6 +861,28 @@ int wcx_post_process_dev(wcx_ctx *ctx, const double *d_z, const double *d_r, con
   WCX_HIP(hipMemcpyAsync(out_z, full + n_bins, (size_t)n_bins * 8, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipMemcpyAsync(out_w, full + 2 * n_bins, (size_t)n_bins * 8, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipStreamSynchronize(st));
+  return WCX_OK;
+}
+
+int wcx_predict_prep_dev(wcx_ctx *ctx, const int32_t *d_counts, int n_samples, int64_t n_bins,
+                         const int32_t *d_pos, int64_t B, const double *d_mean, const double *d_comps,
+                         int n_comp, double *d_x) {
+  WCX_ARG(ctx && d_counts && d_pos && d_mean && d_comps && d_x, "NULL argument");
+  WCX_ARG(n_samples > 0 && n_bins >= B && B > 0, "bad sizes");
+  WCX_ARG(n_comp == 5, "this build instantiates 5 components (newref_tools.py:138: pcacomp=5)");
+  WCX_HIP(hipSetDevice(ctx->device));
+  void *scr = nullptr;
+  int rc = wcx_scratch2(ctx, (size_t)n_samples * (8 + (size_t)PSL * 5 * 8) + 256, &scr);
+  if (rc) return rc;
+  double *d_total = reinterpret_cast<double *>(scr);
+  double *d_part = d_total + n_samples;
+  hipStream_t st = ctx->stream;
+  k_prep_total<<<(unsigned)n_samples, 1024, 0, st>>>(d_counts, n_bins, d_total);
+  k_prep_depth<5><<<dim3(PSL, (unsigned)n_samples), 256, 0, st>>>(d_counts, n_bins, d_total, d_pos, B,
+                                                                  d_mean, d_comps, d_x, d_part);
+  k_prep_project<5><<<dim3((unsigned)((B + 255) / 256), (unsigned)n_samples), 256, 0, st>>>(
+      d_part, B, d_mean, d_comps, d_x);
+  WCX_HIP(hipGetLastError());
   return WCX_OK;
 }
 

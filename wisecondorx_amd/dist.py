@@ -325,17 +325,18 @@ def predict_one_dev(backend, idx, dist, nr, d_x, B, k, chr_cum, rem_input, pt):
     return pt.exec_cbs(rem_input, results, ctx)
 
 
-def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
-    """predict of ONE sample, complete and device-resident (main.py:191-279): autosomal pass against
-    A = {"idx", "dist", "nr", "cum"} (device tensors of the autosomal reference + its cumulative bin
-    counts), gonosomal pass against G (the .F / .M reference: all its rows; None = autosomes only),
-    cut-off on the AUTOSOMAL distances (predict_tools.py:75), the A + gonosome merge, minrefbins /
-    inflation / log2 transform (wcx_post_process_merge_dev), CBS (wcx_cbs_batch_dev) and segment z
-    (wcx_segment_z_dev) -- no NumPy between the normalisation and the segments.
-    d_xA / d_xG: the projected coverage vectors of the sample for the two references.
+def predict_batch_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
+    """predict of a BATCH of samples, complete and device-resident (main.py:191-279): autosomal pass
+    against A = {"idx", "dist", "nr", "cum"} (device tensors of the autosomal reference + its
+    cumulative bin counts), gonosomal pass against G (the .F / .M reference: all its rows; None =
+    autosomes only), cut-off on the AUTOSOMAL distances (predict_tools.py:75), the A + gonosome merge,
+    minrefbins / inflation / log2 transform (wcx_post_process_merge_dev), CBS of all samples in one
+    level-synchronous pass (wcx_cbs_batch_dev) and their segment z (wcx_segment_z_batch_dev) -- no
+    NumPy between the normalisation and the segments.
+    d_xA [ns][BA] / d_xG [ns][B of G]: the projected coverage vectors for the two references.
     rem_input["mask"] / ["bins_per_chr"] are those of the reference the gonosomes come from.
-    Returns the reference's result rows [chr, start, end, z, ratio] (+ the host copies of the
-    per-bin r, z, w if want_host)."""
+    Returns per sample the reference's result rows [chr, start, end, z, ratio] (+ the host copy of
+    the per-bin r, z, w [3][ns][n_bins] if want_host)."""
     import numpy as np
     import torch
     from . import _lib
@@ -345,6 +346,8 @@ def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
     args = rem_input["args"]
     mask = np.asarray(rem_input["mask"], dtype=bool)
     n_bins = len(mask)
+    d_xA = d_xA.view(-1, d_xA.shape[-1])
+    ns = int(d_xA.shape[0])
     BA, k = A["idx"].shape
     cumA, cumA_p = _lib.i64_array(A["cum"])
     ct = BG_all = BG = 0
@@ -353,18 +356,20 @@ def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
         cumG, cumG_p = _lib.i64_array(G["cum"])
         ct = int(cumG[21])
         BG = BG_all - ct
+        d_xG = d_xG.view(-1, d_xG.shape[-1])
     cache = getattr(backend, "_predict_full_bufs", None)
-    key = (BA, BG, n_bins, hash(mask.tobytes()))
+    key = (ns, BA, BG, n_bins, hash(mask.tobytes()))
     if cache is None or cache["key"] != key:
         pos = np.flatnonzero(mask).astype(np.int32)
         if len(pos) != BA + BG:
             raise ValueError("mask selects {} bins, the references hold {} + {}".format(len(pos), BA, BG))
         cache = {"key": key, "pos": torch.from_numpy(pos).to(dev),
-                 "a": torch.empty((4, BA), dtype=torch.float64, device=dev),
-                 "g": torch.empty((4, max(BG_all, 1)), dtype=torch.float64, device=dev),
-                 "med": torch.empty(4, dtype=torch.float64, device=dev),
-                 "out": torch.empty((3, n_bins), dtype=torch.float64, device=dev),
-                 "host": torch.empty((3, n_bins), dtype=torch.float64).pin_memory()}
+                 "a": torch.empty((3, ns, BA), dtype=torch.float64, device=dev),
+                 "g": torch.empty((3, ns, max(BG, 1)), dtype=torch.float64, device=dev),
+                 "wa": torch.empty(BA, dtype=torch.float64, device=dev),
+                 "wg": torch.empty(max(BG_all, 1), dtype=torch.float64, device=dev),
+                 "med": torch.empty((4, ns), dtype=torch.float64, device=dev),
+                 "out": torch.empty((3, ns, n_bins), dtype=torch.float64, device=dev)}
         backend._predict_full_bufs = cache
     a, g, med, out = cache["a"], cache["g"], cache["med"], cache["out"]
     hA, hG = _lib.vp(), _lib.vp()
@@ -373,25 +378,24 @@ def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
     try:
         cutoff = _lib.C.c_double()
         _lib.check(lib.wcx_cutoff(ctx.h, hA, int(args.maskrepeats), _lib.C.byref(cutoff)))
-        _lib.check(lib.wcx_weights_dev(ctx.h, hA, a[3].data_ptr()))
+        _lib.check(lib.wcx_weights_dev(ctx.h, hA, cache["wa"].data_ptr()))
         ctx.timer_tag("aut:")
-        _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hA, d_xA.data_ptr(), 1, cutoff.value, 0, 0,
+        _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hA, d_xA.data_ptr(), ns, cutoff.value, 0, 0,
                                                  a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
-                                                 med[0:].data_ptr(), med[1:].data_ptr()))
+                                                 med[0].data_ptr(), med[1].data_ptr()))
         ctx.timer_tag("")
         if G is not None:
             _lib.check(lib.wcx_ref_wrap_dev(ctx.h, G["idx"].data_ptr(), G["dist"].data_ptr(), BG_all, k,
                                             cumG_p, len(cumG), _lib.C.byref(hG)))
-            _lib.check(lib.wcx_weights_dev(ctx.h, hG, g[3].data_ptr()))
-            _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hG, d_xG.data_ptr(), 1, cutoff.value, ct, 22,
+            _lib.check(lib.wcx_weights_dev(ctx.h, hG, cache["wg"].data_ptr()))
+            _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hG, d_xG.data_ptr(), ns, cutoff.value, ct, 22,
                                                      g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
-                                                     med[2:].data_ptr(), med[3:].data_ptr()))
-        fb = _lib.C.c_int(0)
+                                                     med[2].data_ptr(), med[3].data_ptr()))
         _lib.check(lib.wcx_post_process_merge_dev(
-            ctx.h, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), BA,
+            ctx.h, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), cache["wa"].data_ptr(), BA,
             g[0].data_ptr() if BG else None, g[1].data_ptr() if BG else None,
-            g[2].data_ptr() if BG else None, g[3].data_ptr() + 8 * ct if BG else None, BG, 1,
-            med[0:].data_ptr(), med[1:].data_ptr(), float(args.minrefbins), cache["pos"].data_ptr(),
+            g[2].data_ptr() if BG else None, cache["wg"].data_ptr() + 8 * ct if BG else None, BG, ns,
+            med[0].data_ptr(), med[1].data_ptr(), float(args.minrefbins), cache["pos"].data_ptr(),
             n_bins, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None))
     finally:
         lib.wcx_ref_free(ctx.h, hA)
@@ -408,11 +412,18 @@ def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
                                            device=p_.device)), 1) for p_ in parts]
         nr = torch.cat(parts, 0)
     pt.attach_null_matrix_dev(nr, rem_input["mask"], ctx)
-    rows = pt.exec_cbs_dev(rem_input, out[0], out[2], ctx)
+    rows = pt.exec_cbs_batch_dev(rem_input, out[0], out[2], ctx)
     if want_host:
-        cache["host"].copy_(out, non_blocking=False)
-        return rows, cache["host"].numpy()
+        return rows, out.cpu().numpy()
     return rows
+
+
+def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
+    """One sample of predict_batch_dev (d_xA [BA], d_xG [B of G])."""
+    res = predict_batch_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host)
+    if want_host:
+        return res[0][0], res[1][:, 0, :]
+    return res[0]
 
 
 def _allreduce2(a, b, world):

@@ -60,6 +60,44 @@ def coverage_normalize_and_mask(sample, ref_file, ap):
     return depth[ref_file["mask{}".format(ap)]]
 
 
+def sample_counts_matrix(samples, ref_file, ap):
+    """The bin counts of a batch of samples laid out over the reference's bins (each chromosome
+    truncated or zero-padded to bins_per_chr{ap}, predict_tools.py:36-44) as int32 [ns][n_bins]: the
+    input of prepare_batch_dev."""
+    bpc = np.asarray(ref_file["bins_per_chr{}".format(ap)], dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(bpc)))
+    out = np.zeros((len(samples), int(starts[-1])), dtype=np.int32)
+    for i, sample in enumerate(samples):
+        for c, n_ref in enumerate(bpc):
+            counts = sample[str(c + 1)]
+            n = min(int(n_ref), len(counts))
+            out[i, starts[c]:starts[c] + n] = counts[:n]
+    return out
+
+
+def prepare_batch_dev(d_counts, ref_file, ap, ctx, cache=None):
+    """coverage_normalize_and_mask + project_pc of a batch ON THE DEVICE (wcx_predict_prep_dev).
+    d_counts: torch int32 tensor [ns][n_bins] on the device (sample_counts_matrix, uploaded).  Returns
+    the projected vectors as a torch float64 tensor [ns][B].  The reference-side operands (mask
+    positions, PCA mean and components) are uploaded once per (reference, suffix) into `cache`."""
+    import torch
+    cache = cache if cache is not None else {}
+    key = ("prep", ap)
+    if key not in cache:
+        dev = d_counts.device
+        mask = np.asarray(ref_file["mask{}".format(ap)], dtype=bool)
+        cache[key] = (torch.from_numpy(np.flatnonzero(mask).astype(np.int32)).to(dev),
+                      torch.from_numpy(np.ascontiguousarray(ref_file["pca_mean{}".format(ap)], dtype=np.float64)).to(dev),
+                      torch.from_numpy(np.ascontiguousarray(ref_file["pca_components{}".format(ap)], dtype=np.float64)).to(dev))
+    pos, mean, comps = cache[key]
+    ns, n_bins = d_counts.shape
+    B = int(pos.numel())
+    x = torch.empty((ns, B), dtype=torch.float64, device=d_counts.device)
+    _lib.check(ctx.lib.wcx_predict_prep_dev(ctx.h, d_counts.data_ptr(), int(ns), int(n_bins), pos.data_ptr(), B,
+                                            mean.data_ptr(), comps.data_ptr(), int(comps.shape[0]), x.data_ptr()))
+    return x
+
+
 def project_pc(sample_data, ref_file, ap):
     """predict_tools.py:56-65 with the scikit-learn<=1.4.2 transform the reference pins
     (setup.cfg:42): x / (((x - mean) . C^T) . C + mean)."""
@@ -364,34 +402,44 @@ def exec_cbs(rem_input, results, ctx=None):
     return [results_c[i][:3] + [segment_z[i]] + [results_c[i][3]] for i in range(len(results_c))]
 
 
-def exec_cbs_dev(rem_input, d_r, d_w, ctx=None):
-    """exec_cbs on DEVICE-resident per-bin vectors (torch tensors [n_bins] of one sample, as
-    wcx_post_process_merge_dev leaves them; the null matrix attached): CBS + segment z without a
-    NumPy hop.  Returns the rows [chr0, start, end, z, ratio]."""
+def exec_cbs_batch_dev(rem_input, d_r, d_w, ctx=None):
+    """exec_cbs for a BATCH on DEVICE-resident per-bin vectors (torch tensors [n_samples][n_bins] as
+    wcx_post_process_merge_dev leaves them; the null matrix attached): one level-synchronous CBS pass
+    over all samples (wcx_cbs_batch_dev) and one segment-z call for all their segments
+    (wcx_segment_z_batch_dev) -- no NumPy hop.  Returns per sample the rows [chr0, start, end, z, ratio]."""
     ctx = ctx or _lib.default_context()
+    ns, n_bins = int(d_r.shape[0]), int(d_r.shape[1])
     bpc = [int(v) for v in rem_input["bins_per_chr"]]
     n_chr = min(24 if rem_input["ref_gender"] == "M" else 23, len(bpc))      # CBS.R:30-34
     off, off_p = _lib.i64_array(np.concatenate(([0], np.cumsum(bpc[:n_chr]))))
-    n_bins = int(d_r.numel())
     cap = 4096
-    seg = np.empty((cap, 4))
-    cnt = np.zeros(1, dtype=np.int32)
+    seg = np.empty((ns, cap, 4))
+    cnt = np.zeros(ns, dtype=np.int32)
     seed = rem_input["args"].seed
-    _lib.check(ctx.lib.wcx_cbs_batch_dev(ctx.h, d_r.data_ptr(), d_w.data_ptr(), 1, n_bins, off_p, n_chr,
+    _lib.check(ctx.lib.wcx_cbs_batch_dev(ctx.h, d_r.data_ptr(), d_w.data_ptr(), ns, n_bins, off_p, n_chr,
                                          float(rem_input["args"].alpha), int(rem_input["binsize"]),
                                          0 if seed is None else int(seed), _lib.ptr(seg), cap,
                                          _lib.ptr(cnt)))
-    n_seg = int(cnt[0])
-    seg = np.ascontiguousarray(seg[:n_seg])
-    z = np.empty(n_seg)
-    nn = np.empty(n_seg)
-    # segment z sees every chromosome of the result vectors (24 for the reference's lists)
+    flat = np.ascontiguousarray(np.concatenate([seg[i, :cnt[i]] for i in range(ns)]))
+    z = np.empty(len(flat))
+    nn = np.empty(len(flat))
+    # segment z sees every chromosome of the result vectors (24 for the male reference's lists)
     off_all, off_all_p = _lib.i64_array(np.concatenate(([0], np.cumsum(bpc))))
-    if n_seg:
-        _lib.check(ctx.lib.wcx_segment_z_dev(ctx.h, d_r.data_ptr(), d_w.data_ptr(), off_all_p, len(bpc),
-                                             _lib.ptr(seg), n_seg, _lib.ptr(z), _lib.ptr(nn)))
-    return [[int(s[0]), int(s[1]), int(s[2]), "nan" if nn[i] == 0 else float(z[i]), float(s[3])]
-            for i, s in enumerate(seg)]
+    if len(flat):
+        _lib.check(ctx.lib.wcx_segment_z_batch_dev(ctx.h, d_r.data_ptr(), d_w.data_ptr(), ns, off_all_p,
+                                                   len(bpc), _lib.ptr(flat), _lib.ptr(cnt), _lib.ptr(z),
+                                                   _lib.ptr(nn)))
+    out, o = [], 0
+    for i in range(ns):
+        out.append([[int(s[0]), int(s[1]), int(s[2]), "nan" if nn[o + j] == 0 else float(z[o + j]), float(s[3])]
+                    for j, s in enumerate(flat[o:o + cnt[i]])])
+        o += int(cnt[i])
+    return out
+
+
+def exec_cbs_dev(rem_input, d_r, d_w, ctx=None):
+    """One sample of exec_cbs_batch_dev (d_r, d_w: [n_bins])."""
+    return exec_cbs_batch_dev(rem_input, d_r.view(1, -1), d_w.view(1, -1), ctx)[0]
 
 
 def run_cbs_batch(results_list, ref_gender, alpha, binsize, seed, ctx=None):
