@@ -190,3 +190,23 @@ def test_config5_predict_batch_of_96_at_15kb(ref15):
                 assert isinstance(s[3], str)
             else:
                 np.testing.assert_allclose(s[3], ozv, rtol=1e-9, atol=1e-9)
+    # the SAME batch device-resident end to end (dist.predict_batch_dev: normalisation outputs stay in
+    # HBM through merge / post-processing, ONE batched CBS and ONE batched segment-z call): the same
+    # segments, z-scores and ratios as the striped host-orchestrated path above
+    import torch
+    from wisecondorx_amd import dist as wd
+    dev = torch.device("cuda", 0)
+    ctx_t = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx_t)
+    tt = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    A = {"idx": tt(ref["indexes"]), "dist": tt(ref["distances"]), "nr": tt(ref["null_ratios"]), "cum": cum}
+    rem_dev = dict(rem, args=argparse.Namespace(minrefbins=150, alpha=1e-4, seed=7, maskrepeats=5))
+    rows_dev = wd.predict_batch_dev(be, A, None, tt(xs), None, rem_dev, pt)
+    assert len(rows_dev) == n_batch
+    for i in range(n_batch):
+        assert [s[:3] for s in rows_dev[i]] == [s[:3] for s in rows[i]], i
+        for s, t in zip(rows_dev[i], rows[i]):
+            if isinstance(t[3], str):
+                assert isinstance(s[3], str)
+            else:
+                np.testing.assert_allclose([s[3], s[4]], [t[3], t[4]], rtol=1e-9, atol=1e-9)
