@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 vector == matrix (not in the guide)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA
 SPINUP_STEPS = int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "0"))   # extra untimed steps (0: only --warmup)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "screen_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "screen_traffic.json")
 
 
 def screen_source_sha():
@@ -415,7 +415,7 @@ def main():
                 and (args.binsize, args.refsize) == (15000, 300):
             e = tj["workloads"][key]
             rf["traffic"] = e["fetch_bytes_per_sweep_corrected_x2"] + e["write_bytes_per_sweep"]
-            rf["traffic_source"] = "profiles/r02/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
+            rf["traffic_source"] = "profiles/r03/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
                                    "WRITE_SIZE; bytes per screen sweep; kernel_sha {})".format(
                                        tj["kernel_sha"])
     if screen_ms >= 0:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_r02 (scripts/measure_traffic.sh) into profiles/r02/:
+"""Condense gpurun_out/prof_r03 (scripts/measure_traffic.sh) into profiles/r03/:
   kernel_stats_S<S>.csv     rocprofv3 --kernel-trace --stats summary of the bench command
   pmc_S<S>.csv              per-kernel sums of every counter (all PMC passes) + dispatch counts
   screen_traffic.json       per-sweep HBM bytes and SQ breakdown of k_screen, keyed by workload, with
@@ -16,8 +16,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
-DST = os.path.join(ROOT, "profiles", "r02")
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r03")
+DST = os.path.join(ROOT, "profiles", "r03")
 
 
 def short_name(full):
@@ -59,7 +59,12 @@ def main():
                 for r in csv.DictReader(open(f)):
                     name = short_name(r["Kernel_Name"])
                     if "k_screen<" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]:
-                        name = "k_screen"
+                        # the step runs three passes: the autosomal one (all S samples: the largest
+                        # NK of the run) is the dominant kernel, the two gonosomal ones (S / 2
+                        # samples) are kept apart
+                        import re
+                        nk = int(re.search(r"k_screen<(\d+)", r["Kernel_Name"]).group(1))
+                        name = "k_screen" if nk == (32 if S == 500 else 7) else "k_screen (gonosomal passes)"
                     agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
                     disp[(name, n)].add(r["Dispatch_Id"])
         if not agg:
