@@ -277,7 +277,8 @@ int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]);
 /* Per-test records of the LAST wcx_cbs / wcx_cbs_batch call on this context, kept when
  * wcx_debug_flags(ctx, 128) was set before it (what tests/test_gpu_cbs_oracle.py compares with the
  * NumPy oracle).  One record = 20 doubles: sample, chromosome, lo, hi (segment in the chromosome's
- * NA-free series), n, best arc bi, bj, t^2, tail p (NaN if n <= 200), delta, why (1 constant /
+ * NA-free series), n, best arc bi, bj, t^2, tail p (NaN if n <= 200; NEGATIVE = "at least |value|": a
+ * proven lower bound that already exceeds alpha, the series was not evaluated), delta, why (1 constant /
  * invalid, 2 t <= 0.1, 3 t >= 7, 4 tail p > alpha, 5 permutations, 6 short-arc bound), budget nrejc,
  * exceedances nrej and permutations np at the stop (-1 without permutations), significant,
  * change-points kept, then (kept, nrej; -1 = t^2 > 25 rule, -2 = no test) of the two edge tests.

@@ -94,6 +94,15 @@ def test_tail_probability_against_monte_carlo():
         assert 0.85 < 2.0 * approx / emp < 1.5, (b, emp, approx)
 
 
+def test_cheap_lower_bound_of_nu():
+    """cbs_seg.hip skips the nu(x) series of clearly-null segments with nu(x) >= exp(-0.583 x) / 2:
+    checked against the series on a dense grid (the bound is in fact within [0.5, 0.62] of nu up to
+    x = 3 and ever looser beyond, where nu ~ 2 / x^2 decays polynomially)."""
+    import math
+    for x in np.concatenate((np.linspace(0.0101, 3.0, 120), np.linspace(3.0, 40.0, 75))):
+        assert 0.5 * math.exp(-0.583 * x) <= CO.nu(float(x)) <= 1.0 + 1e-12, x
+
+
 def test_hybrid_statistic_covers_exactly_the_short_arcs():
     rng = np.random.default_rng(2)
     n = 230
