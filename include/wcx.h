@@ -272,7 +272,8 @@ int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_
                       int64_t n_bins, const int64_t *chr_off, int n_chr, double alpha, int64_t binsize,
                       uint64_t seed, double *out_seg, int cap, int *out_count);
 /* Diagnostics of the CBS calls on this context since its creation: out[0] = hybrid tests decided
- * by the short-arc bound (their permutations were not run), out[1..3] reserved. */
+ * by the short-arc bound (their permutations were not run), out[1] / out[2] = block pairs of the arc
+ * search evaluated arc by arc / existing (block-bound pruning), out[3] reserved. */
 int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]);
 /* Per-test records of the LAST wcx_cbs / wcx_cbs_batch call on this context, kept when
  * wcx_debug_flags(ctx, 128) was set before it (what tests/test_gpu_cbs_oracle.py compares with the

@@ -185,7 +185,7 @@ class Context:
     def cbs_stats(self):
         out = (C.c_int64 * 4)()
         check(self.lib.wcx_cbs_stats(self.h, out))
-        return {"bound_shortcuts": out[0]}
+        return {"bound_shortcuts": out[0], "arc_pairs_listed": out[1], "arc_pairs_total": out[2]}
 
     def cbs_trace(self):
         """Per-test records of the last CBS call (needs wcx_debug_flags(h, 128) before it); rows of

@@ -343,6 +343,220 @@ __global__ __launch_bounds__(256) void k_cbs_arcmax(const double *__restrict__ S
   if (threadIdx.x == 0) { best[blockIdx.x].b = sb[0]; best[blockIdx.x].i = si_[0]; best[blockIdx.x].j = sj_[0]; }
 }
 
+// ---- (2b) the same maximum with BLOCK BOUNDS: exact, but only block pairs that can hold it ------
+// Positions 0 .. n of a segment are cut into blocks of PBS; per block the extremes of S (with their
+// positions) and the range of the prefix weight.  For a pair of blocks (I <= J) every arc (i, j],
+// i in I, j in J, has |S_j - S_i| <= D = max(max S_J - min S_I, max S_I - min S_J) and an arc weight
+// in [wlo, whi] = [W_first(J) - W_last(I), W_last(J) - W_first(I)]; w (W - w) / W is concave, so it
+// is at least the smaller end-point value: bss <= D^2 / that.  A lower bound L of the maximum comes
+// from the arcs between the blocks' extreme positions.  Only pairs whose bound reaches L are
+// evaluated arc by arc (the same fp32 screen + fp64 formula as k_cbs_arcmax); on noise that is the
+// few diagonals next to the main one, ~2-3 % of the pairs.  Ties -> smallest (i, j) as before.
+constexpr int PBS = 64;
+struct BlkStat { double smin, smax, wlo, whi; int amin, amax; };
+struct WorkItem { int seg, I, J; };
+
+__device__ __forceinline__ int find_seg(const int *__restrict__ boff, int ns, int blk) {
+  int lo = 0, hi = ns - 1;                      // largest s with boff[s] <= blk
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (boff[mid] <= blk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__device__ __forceinline__ double arc_bss(double si, double wi, double sj, double wj, double W) {
+  const double d = sj - si, wa = wj - wi;
+  return d * d / (wa * (W - wa) / W);
+}
+
+__global__ __launch_bounds__(256) void k_cbs_blockstats(const double *__restrict__ S,
+                                                        const double *__restrict__ Wp,
+                                                        const SegIn *__restrict__ segs,
+                                                        const SegOut *__restrict__ so,
+                                                        const int *__restrict__ boff, int ns,
+                                                        int total_blocks, BlkStat *__restrict__ bs) {
+  const int blk = (int)blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blk >= total_blocks) return;
+  const int s = find_seg(boff, ns, blk);
+  const SegIn sg = segs[s];
+  const double W = so[s].W;
+  const int p0 = (blk - boff[s]) * PBS, p = p0 + lane;
+  const bool in = p <= sg.n;
+  const double sv = in ? seg_S(S, sg, p) : 0.0;
+  const double vmin = wcx::wave_min_f64(in ? sv : HUGE_VAL), vmax = wcx::wave_max_f64(in ? sv : -HUGE_VAL);
+  const unsigned long long bmin = __ballot(in && sv == vmin), bmax = __ballot(in && sv == vmax);
+  if (lane == 0) {
+    const int plast = p0 + PBS - 1 < sg.n ? p0 + PBS - 1 : sg.n;
+    BlkStat b;
+    b.smin = vmin; b.smax = vmax;
+    b.amin = p0 + __ffsll((long long)bmin) - 1; b.amax = p0 + __ffsll((long long)bmax) - 1;
+    b.wlo = seg_W(Wp, sg, W, p0); b.whi = seg_W(Wp, sg, W, plast);
+    bs[blk] = b;
+  }
+}
+
+// lower bound L[s] of the maximum: arcs between the extreme positions of every block pair
+__global__ __launch_bounds__(256) void k_cbs_coarse(const double *__restrict__ S,
+                                                    const double *__restrict__ Wp,
+                                                    const SegIn *__restrict__ segs,
+                                                    const SegOut *__restrict__ so,
+                                                    const int *__restrict__ boff, int ns,
+                                                    const BlkStat *__restrict__ bs, int minw,
+                                                    unsigned int *__restrict__ L) {
+  __shared__ float red[4];
+  const int blk = blockIdx.x;
+  const int s = find_seg(boff, ns, blk);
+  const SegIn sg = segs[s];
+  const double W = so[s].W;
+  const int n = sg.n, I = blk - boff[s], nb = boff[s + 1] - boff[s];
+  const BlkStat bi = bs[blk];
+  float best = 0.f;
+  for (int J = I + (int)threadIdx.x; J < nb; J += 256) {
+    const BlkStat bj = bs[boff[s] + J];
+    const int pa[2] = {bi.amin, bi.amax}, pb[2] = {bj.amin, bj.amax};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int i = pa[q & 1], j = pb[q >> 1];
+      if (i > j) { const int t = i; i = j; j = t; }
+      const int a = j - i;
+      if (a < minw || n - a < minw) continue;
+      const double b = arc_bss(seg_S(S, sg, i), seg_W(Wp, sg, W, i), seg_S(S, sg, j), seg_W(Wp, sg, W, j), W);
+      const float bf = __double2float_rd(b);
+      best = bf > best ? bf : best;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(best, m, 64); best = o > best ? o : best; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float b = red[0];
+    for (int q = 1; q < 4; ++q) b = red[q] > b ? red[q] : b;
+    if (b > 0.f) atomicMax(&L[s], __float_as_uint(b));
+  }
+}
+
+// block pairs whose bound reaches L -> work list
+__global__ __launch_bounds__(256) void k_cbs_prune(const SegOut *__restrict__ so,
+                                                   const int *__restrict__ boff, int ns,
+                                                   const BlkStat *__restrict__ bs,
+                                                   const unsigned int *__restrict__ L,
+                                                   WorkItem *__restrict__ work, unsigned int cap,
+                                                   unsigned int *__restrict__ count) {
+  const int blk = blockIdx.x;
+  const int s = find_seg(boff, ns, blk);
+  const double W = so[s].W;
+  const int I = blk - boff[s], nb = boff[s + 1] - boff[s];
+  const BlkStat bi = bs[blk];
+  const double Ls = (double)__uint_as_float(L[s]) * (1.0 - 1e-9);
+  for (int J = I + (int)threadIdx.x; J < nb; J += 256) {
+    const BlkStat bj = bs[boff[s] + J];
+    const double d1 = bj.smax - bi.smin, d2 = bi.smax - bj.smin;
+    const double D = d1 > d2 ? d1 : d2;
+    const double wlo = bj.wlo - bi.whi, whi = bj.whi - bi.wlo;
+    const double g1 = wlo * (W - wlo) / W, g2 = whi * (W - whi) / W;
+    const double g = g1 < g2 ? g1 : g2;
+    const bool keep = !(g > 0.0) || D * D / g >= Ls;     // (g <= 0: same / touching blocks, or the whole series)
+    if (keep) {
+      const unsigned int at = atomicAdd(count, 1u);
+      if (at < cap) { work[at].seg = s; work[at].I = I; work[at].J = J; }
+    }
+  }
+}
+
+// the arcs of the listed block pairs, exactly (fp32 screen, fp64 formula, ties -> smallest (i, j))
+__global__ __launch_bounds__(256) void k_cbs_pairmax(const double *__restrict__ S,
+                                                     const double *__restrict__ Wp,
+                                                     const SegIn *__restrict__ segs,
+                                                     const SegOut *__restrict__ so,
+                                                     const WorkItem *__restrict__ work, unsigned int cap,
+                                                     const unsigned int *__restrict__ count, int minw,
+                                                     ArcBest *__restrict__ res,
+                                                     unsigned long long *__restrict__ bbits) {
+  __shared__ double sI[PBS], wI[PBS], sJ[PBS], wJ[PBS];
+  __shared__ double sb[256];
+  __shared__ int si_[256], sj_[256];
+  const unsigned int nitem = *count < cap ? *count : cap;
+  const int tid = threadIdx.x;
+  for (unsigned int it = blockIdx.x; it < nitem; it += gridDim.x) {
+    const WorkItem wk = work[it];
+    const SegIn sg = segs[wk.seg];
+    const double W = so[wk.seg].W;
+    const float Wf = (float)W;
+    const int n = sg.n, i0 = wk.I * PBS, j0 = wk.J * PBS;
+    __syncthreads();
+    if (tid < PBS) {
+      const int p = i0 + tid;
+      sI[tid] = p <= n ? seg_S(S, sg, p) : 0.0; wI[tid] = p <= n ? seg_W(Wp, sg, W, p) : 0.0;
+    } else if (tid < 2 * PBS) {
+      const int q = tid - PBS, p = j0 + q;
+      sJ[q] = p <= n ? seg_S(S, sg, p) : 0.0; wJ[q] = p <= n ? seg_W(Wp, sg, W, p) : 0.0;
+    }
+    __syncthreads();
+    double bb = -1.0;
+    float bf = -1.f;
+    int bi = 0, bj = 0;
+    const int qi = tid >> 2, i = i0 + qi;
+    if (i <= n) {
+      const double si = sI[qi], wi = wI[qi];
+      for (int qj = (tid & 3); qj < PBS; qj += 4) {
+        const int j = j0 + qj, a = j - i;
+        if (j > n || a < minw || n - a < minw) continue;
+        const double d = sJ[qj] - si, wa = wJ[qj] - wi;
+        const float df = (float)d, waf = (float)wa;
+        const float b32 = df * df * Wf * __builtin_amdgcn_rcpf(waf * (Wf - waf));
+        if (b32 >= bf) {
+          const double b = d * d / (wa * (W - wa) / W);
+          if (b > bb || (b == bb && (i < bi || (i == bi && j < bj)))) {
+            bb = b; bi = i; bj = j; bf = (float)b * 0.999996f;
+          }
+        }
+      }
+    }
+    sb[tid] = bb; si_[tid] = bi; sj_[tid] = bj;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if (tid < off) {
+        const int o = tid + off;
+        const bool take = sb[o] > sb[tid] ||
+                          (sb[o] == sb[tid] && (si_[o] < si_[tid] || (si_[o] == si_[tid] && sj_[o] < sj_[tid])));
+        if (take) { sb[tid] = sb[o]; si_[tid] = si_[o]; sj_[tid] = sj_[o]; }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      res[it].b = sb[0]; res[it].i = si_[0]; res[it].j = sj_[0];
+      if (sb[0] > 0.0) atomicMax(&bbits[wk.seg], (unsigned long long)__double_as_longlong(sb[0]));
+    }
+  }
+}
+// among the pairs that reached the segment's maximum: the smallest (i, j)
+__global__ __launch_bounds__(256) void k_cbs_pairtie(const WorkItem *__restrict__ work, unsigned int cap,
+                                                     const unsigned int *__restrict__ count,
+                                                     const ArcBest *__restrict__ res,
+                                                     const unsigned long long *__restrict__ bbits,
+                                                     unsigned long long *__restrict__ bij) {
+  const unsigned int nitem = *count < cap ? *count : cap;
+  for (unsigned int it = blockIdx.x * 256 + threadIdx.x; it < nitem; it += gridDim.x * 256) {
+    const ArcBest r = res[it];
+    const int s = work[it].seg;
+    if (r.b > 0.0 && (unsigned long long)__double_as_longlong(r.b) == bbits[s])
+      atomicMin(&bij[s], ((unsigned long long)(unsigned int)r.i << 32) | (unsigned int)r.j);
+  }
+}
+__global__ __launch_bounds__(256) void k_cbs_pairfinal(int ns, const unsigned long long *__restrict__ bbits,
+                                                       const unsigned long long *__restrict__ bij,
+                                                       ArcBest *__restrict__ best, int *__restrict__ first) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s > ns) return;
+  first[s] = s;
+  if (s == ns) return;
+  ArcBest b;
+  b.b = bbits[s] ? __longlong_as_double((long long)bbits[s]) : -1.0;
+  b.i = (int)(bij[s] >> 32); b.j = (int)(bij[s] & 0xffffffffull);
+  best[s] = b;
+}
+
 __device__ __forceinline__ double it1tsq(double x, double a) {   // integral of 1/(t(1-t))^2 over [x, x+a]
   double y = x + a - 0.5;
   double r = 8.0 * y / (1.0 - 4.0 * y * y) + 2.0 * log((1.0 + 2.0 * y) / (1.0 - 2.0 * y));
@@ -1114,6 +1328,8 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     const int npad_max = (max_n + NTP - 1) / NTP * NTP;
     const bool any_big = max_n > LDS_KEYS_MAX;
     const size_t max_items = (size_t)max_segs + (size_t)(N / 4) + 6144 + 64;
+    const size_t max_blocks = (size_t)(N / PBS) + 2 * (size_t)max_segs + 64;
+    const unsigned int work_cap = 1u << 22;                  // block pairs evaluated per round at most
     const size_t qtab_floats = (size_t)(KMAXC - 1) * ((size_t)N + (size_t)NTP * max_segs) +
                                (size_t)max_segs * (KMAXC + 1) * QC_W;
     const size_t need = (size_t)N * (8 * 5 + 4 * 2) + (size_t)max_segs * (sizeof(SegIn) + sizeof(SegOut) + 8) +
@@ -1121,7 +1337,8 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
                         (size_t)max_jobs * (2 * sizeof(PermJob) + (size_t)(nw + NCH) * 4) +
                         (any_big ? (size_t)BIG_GRID * (npad_max + 64) * 4 : 0) +
                         (size_t)EXACT_GRID * npad_max * 8 + FLAG_CAP * sizeof(uint2) + qtab_floats * 4 +
-                        (1 << 16);
+                        max_blocks * sizeof(BlkStat) + (size_t)work_cap * (sizeof(WorkItem) + sizeof(ArcBest)) +
+                        (size_t)max_segs * 32 + (1 << 16);
     void *scr = nullptr;
     rc = wcx_scratch(ctx, need, &scr);
     if (rc) return rc;
@@ -1144,6 +1361,14 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     double *dexact = A.take<double>((size_t)EXACT_GRID * npad_max);
     uint2 *dflags = A.take<uint2>(FLAG_CAP);
     float *dq = A.take<float>(qtab_floats);
+    BlkStat *dbs = A.take<BlkStat>(max_blocks);
+    WorkItem *dwork = A.take<WorkItem>(work_cap);
+    ArcBest *dres = A.take<ArcBest>(work_cap);
+    int *dboff = A.take<int>(max_segs + 1);
+    unsigned int *dL = A.take<unsigned int>(max_segs + 2);     // [ns] lower bounds | work count
+    unsigned long long *dbbits = A.take<unsigned long long>(max_segs);
+    unsigned long long *dbij = A.take<unsigned long long>(max_segs);
+    static const bool no_prune = getenv("WCX_CBS_NOPRUNE") && atoi(getenv("WCX_CBS_NOPRUNE"));
     WCX_HIP(hipMemcpyAsync(dX, hx, (size_t)N * 8, hipMemcpyHostToDevice, st));
     WCX_HIP(hipMemcpyAsync(dW, hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
     const size_t lds_small = (size_t)(std::min(npad_max, LDS_KEYS_MAX) + 32) * 4;
@@ -1294,7 +1519,40 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       WCX_HIP(hipMemcpyAsync(ditems, items.data(), items.size() * sizeof(ArcItem), hipMemcpyHostToDevice, st));
       WCX_HIP(hipMemcpyAsync(dfirst, first.data(), (size_t)(ns + 1) * 4, hipMemcpyHostToDevice, st));
       k_cbs_prepare<<<ns, NTP, 0, st>>>(dX, dW, dseg, dS, dWp, dYd, dy, drw, dso);
-      k_cbs_arcmax<<<(unsigned)items.size(), 256, 0, st>>>(dS, dWp, dseg, dso, ditems, P.minw, dbest);
+      // best arc of every segment: block-bound pruning (k_cbs_blockstats .. k_cbs_pairfinal); the
+      // striped full search (k_cbs_arcmax) is the fallback when the work list overflows
+      std::vector<int> boff(ns + 1);
+      boff[0] = 0;
+      for (int a = 0; a < ns; ++a) boff[a + 1] = boff[a] + (hseg[a].n + 1 + PBS - 1) / PBS;
+      const int total_blocks = boff[ns];
+      // (a single sample's ~1e9 arcs take the striped search 0.1 ms per round: the six launches and
+      // the count read-back of the pruned search only pay from a few samples on)
+      bool pruned = !no_prune && (size_t)total_blocks <= max_blocks && arc_total > 4e9;
+      unsigned int *dcount = dL + ns;
+      if (pruned) {
+        WCX_HIP(hipMemcpyAsync(dboff, boff.data(), (size_t)(ns + 1) * 4, hipMemcpyHostToDevice, st));
+        WCX_HIP(hipMemsetAsync(dL, 0, (size_t)(ns + 1) * 4, st));
+        WCX_HIP(hipMemsetAsync(dbbits, 0, (size_t)ns * 8, st));
+        WCX_HIP(hipMemsetAsync(dbij, 0xff, (size_t)ns * 8, st));
+        k_cbs_blockstats<<<(unsigned)((total_blocks + 3) / 4), 256, 0, st>>>(dS, dWp, dseg, dso, dboff, ns,
+                                                                             total_blocks, dbs);
+        k_cbs_coarse<<<(unsigned)total_blocks, 256, 0, st>>>(dS, dWp, dseg, dso, dboff, ns, dbs, P.minw, dL);
+        k_cbs_prune<<<(unsigned)total_blocks, 256, 0, st>>>(dso, dboff, ns, dbs, dL, dwork, work_cap, dcount);
+        k_cbs_pairmax<<<8192, 256, 0, st>>>(dS, dWp, dseg, dso, dwork, work_cap, dcount, P.minw, dres, dbbits);
+        k_cbs_pairtie<<<2048, 256, 0, st>>>(dwork, work_cap, dcount, dres, dbbits, dbij);
+        k_cbs_pairfinal<<<(unsigned)((ns + 256) / 256), 256, 0, st>>>(ns, dbbits, dbij, dbest, dfirst);
+        WCX_HIP(hipGetLastError());
+        unsigned int hcount = 0;
+        WCX_HIP(hipMemcpyAsync(&hcount, dcount, 4, hipMemcpyDeviceToHost, st));
+        WCX_HIP(hipStreamSynchronize(st));
+        ctx->cbs_pairs_listed += hcount;
+        ctx->cbs_pairs_total += [&] { long long t = 0; for (int a = 0; a < ns; ++a) { const long long nb = boff[a + 1] - boff[a]; t += nb * (nb + 1) / 2; } return t; }();
+        if (hcount > work_cap) pruned = false;           // (never on real data; keeps the result exact)
+      }
+      if (!pruned) {
+        WCX_HIP(hipMemcpyAsync(dfirst, first.data(), (size_t)(ns + 1) * 4, hipMemcpyHostToDevice, st));
+        k_cbs_arcmax<<<(unsigned)items.size(), 256, 0, st>>>(dS, dWp, dseg, dso, ditems, P.minw, dbest);
+      }
       // (the bound must clear alpha with room: nu_lo^2 is 4x below the expansion it halves)
       const double alpha_skip = (ctx->debug_flags & 2) ? HUGE_VAL : 4.0 * P.alpha;
       k_cbs_arcfinish<<<ns, 128, 0, st>>>(dbest, dfirst, dseg, dWp, dso, P.kmax, P.ngrid, alpha_skip, dtx);
@@ -1552,7 +1810,7 @@ int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_
 
 int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]) {
   WCX_ARG(ctx && out, "NULL argument");
-  out[0] = ctx->cbs_shortcuts; out[1] = out[2] = out[3] = 0;
+  out[0] = ctx->cbs_shortcuts; out[1] = ctx->cbs_pairs_listed; out[2] = ctx->cbs_pairs_total; out[3] = 0;
   return WCX_OK;
 }
 

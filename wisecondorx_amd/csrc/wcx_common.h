@@ -50,6 +50,7 @@ struct wcx_ctx {
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
   std::vector<double> cbs_trace;     // per-test records of the last wcx_cbs_batch (wcx_debug_flags & 128)
+  long long cbs_pairs_listed = 0, cbs_pairs_total = 0;   // block pairs evaluated / existing (arc search)
   long long cbs_shortcuts = 0;       // hybrid CBS tests decided by the short-arc bound (no permutations)
   void *host_scratch = nullptr;      // pinned host staging (wcx_host_scratch)
   size_t host_scratch_bytes = 0;
