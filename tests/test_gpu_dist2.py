@@ -93,9 +93,11 @@ def test_ranks_on_one_device_real_kernels(world):
         np.testing.assert_allclose([mlr, mz], [emlr, emz], rtol=1e-9, atol=1e-12)
 
 
-def test_bench_two_ranks_smoke():
-    """bench.py's N > 1 code path end to end (launcher contract, sharding, collectives, JSON line)
-    with two gloo ranks on one device and a small problem."""
+@pytest.mark.parametrize("mode", ["strong", "replicas"])
+def test_bench_two_ranks_smoke(mode):
+    """bench.py's N > 1 code path end to end (launcher contract, sharding of the A pass and of the
+    gonosomal passes, collectives, replica predict, JSON line) with two gloo ranks on one device and
+    a small problem; and the --replicas throughput mode (one whole reference per rank)."""
     import json
     import subprocess
     env = dict(os.environ, WCX_DIST_BACKEND="gloo", WCX_BENCH_SPINUP_STEPS="1", MASTER_ADDR="127.0.0.1")
@@ -105,7 +107,7 @@ def test_bench_two_ranks_smoke():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--binsize", "100000", "--samples", "40",
-           "--refsize", "100"]
+           "--refsize", "100"] + (["--replicas"] if mode == "replicas" else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -113,3 +115,5 @@ def test_bench_two_ranks_smoke():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
     assert d["roofline"]["frac"] > 0
+    assert d["scaling"] == ("weak" if mode == "replicas" else "strong")
+    assert d["verified"]["mismatches"] == 0 and d["verified"]["rows"] > 100
