@@ -109,6 +109,31 @@ int wcx_pca_finish(wcx_ctx *ctx, const double *u, const double *sv, int ncomp, d
                    double *X_out, double *dist_to_med_out);
 int wcx_pca_end(wcx_ctx *ctx);
 
+/* ---- newref: bin mask and depth normalisation from device-resident bin counts ---------- */
+/* d_counts int32 [S_all][n_bins]: every sample's per-chromosome bin counts (after the gender
+ * correction) laid out over the longest sample's bins per chromosome, zero padded -- the matrix
+ * the reference's np.zeros + copy loops build (newref_tools.py:80-91, :113-122), before any
+ * division.  sel int32[ns] (host): the samples of the call (a pass's gender subset), in order.
+ *   wcx_prep_mask_dev         replaces newref_tools.get_mask (newref_tools.py:77-102): counts /
+ *                             per-sample total, summed per bin over the selected samples, mask =
+ *                             sum > 5 % of the median of the positive sums -> mask_out uint8[n_bins]
+ *                             (host).
+ *   wcx_pca_begin_counts_dev  replaces newref_tools.normalize_and_mask (newref_tools.py:110-129) +
+ *                             wcx_pca_begin: counts of bins pos[0..B) (host int32: the kept bins of
+ *                             the pass, all < n_bins_pass) divided by the sample's total over bins
+ *                             [0, n_bins_pass) (the chromosomes of the pass) are written straight
+ *                             into the PCA stage's device matrix; then as wcx_pca_begin.
+ *   wcx_pca_corrected_dev             device pointer of the corrected matrix X double[S][B] (sample-major)
+ *                             wcx_pca_finish left in HBM: the input of wcx_newref_topk_dev /
+ *                             wcx_null_ratios_dev without a host round trip.  Valid until the next
+ *                             wcx_pca_begin* / wcx_pca_end on this context. */
+int wcx_prep_mask_dev(wcx_ctx *ctx, const int32_t *d_counts, int64_t n_bins, const int32_t *sel, int ns,
+                      unsigned char *mask_out);
+int wcx_pca_begin_counts_dev(wcx_ctx *ctx, const int32_t *d_counts, int64_t n_bins, const int32_t *sel,
+                             int ns, int64_t n_bins_pass, const int32_t *pos, int64_t B, double *mean_out,
+                             double *gram_out);
+int wcx_pca_corrected_dev(wcx_ctx *ctx, double **dX_out);
+
 /* ---- newref: reference-bin search ------------------------------------------------- */
 /* Replaces newref_tools.get_ref_for_bins (newref_tools.py:255-278) as driven by
  * newref_tools.get_reference (newref_tools.py:176-206) for target rows

@@ -21,12 +21,14 @@ sys.path.insert(0, ROOT)
 class Phases:
     def __init__(self):
         self.t = {}
+        self.first = {}          # wall-clock of the first entry of each phase
 
     def wrap(self, module, name, key):
         fn = getattr(module, name)
 
         def timed(*a, **k):
             t0 = time.perf_counter()
+            self.first.setdefault(key, t0)
             try:
                 return fn(*a, **k)
             finally:
@@ -41,6 +43,7 @@ def main():
     ap.add_argument("--refsize", type=int, default=300)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--workdir", default="/tmp/wcx_e2e")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the newref call -> stderr")
     a = ap.parse_args()
 
     os.environ.setdefault("WCX_NO_TORCH_PRELOAD", "1")     # like `python -m wisecondorx_amd.main`
@@ -69,16 +72,32 @@ def main():
     ph.wrap(newref_tools, "get_reference_parts", "gpu_search_nullratios")
     ph.wrap(npz_io, "save_npz", "write_reference")
     ph.wrap(cli, "train_gender_model", "gender_model")
+    from wisecondorx_amd import ref_qc
+    ph.wrap(prep.DeviceCounts, "__init__", "counts_to_device")
+    ph.wrap(prep.DeviceCounts, "get_mask", "masks")
+    ph.wrap(prep, "prepare_dev", "prep_pca")
+    ph.wrap(newref_tools, "get_reference_dev", "gpu_search_nullratios")
+    ph.wrap(ref_qc, "qc_reference", "reference_qc")
 
     ref_file = os.path.join(a.workdir, "ref.npz")
     import random
     random.seed(1)
+    newref_argv = ["--loglevel", "warning", "newref"] + files + [
+        ref_file, "--binsize", str(a.binsize), "--refsize", str(a.refsize), "--yfrac", "0.004",
+        "--gpus", str(a.gpus)]
     t0 = time.perf_counter()
-    cli.main(["--loglevel", "warning", "newref"] + files +
-             [ref_file, "--binsize", str(a.binsize), "--refsize", str(a.refsize), "--yfrac", "0.004",
-              "--gpus", str(a.gpus)])
+    if a.profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.runcall(cli.main, newref_argv)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+    else:
+        cli.main(newref_argv)
     t_newref = time.perf_counter() - t0
     newref_phases = dict(ph.t)
+    if "gender_model" in ph.first:       # wall-clock of the 8-thread import (up to the gender model)
+        newref_phases["load_samples_wall"] = ph.first["gender_model"] - t0
 
     ph.t = {}
     ph.wrap(npz_io, "load_reference", "load_reference")

@@ -67,6 +67,24 @@ def test_npz_roundtrip(tmp_path):
     npz_io.save_sample(p, sample, 5000)
     s2, b = npz_io.load_sample(p)
     assert b == 5000 and all(np.array_equal(s2[k], sample[k]) for k in sample)
+    assert all(s2[k].dtype == np.int32 for k in sample)
+    # the direct reader (one inflate call per member) checks what np.load's zipfile would: a flipped
+    # byte in the deflated sample, a truncated file; an uncompressed np.savez file loads as well
+    import zipfile
+    raw = bytearray(open(p, "rb").read())
+    at = raw.find(b"sample.npy") + 200
+    raw[at] ^= 0x5A
+    bad = str(tmp_path / "bad.npz")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(zipfile.BadZipFile):
+        npz_io.load_sample(bad)
+    open(bad, "wb").write(bytes(raw[:len(raw) // 2]))
+    with pytest.raises(zipfile.BadZipFile):
+        npz_io.load_sample(bad)
+    stored = str(tmp_path / "stored.npz")
+    np.savez(stored, binsize=7000, sample=sample, quality={})
+    s3, b3 = npz_io.load_sample(stored)
+    assert b3 == 7000 and all(np.array_equal(s3[k], sample[k]) for k in sample)
     ref = {"indexes": np.zeros((3000, 300), np.int32), "distances": np.ones((3000, 300)),
            "mask": np.ones(10, bool), "binsize": 100000, "is_nipt": False, "trained_cutoff": 0.004}
     rp = npz_io.save_npz(str(tmp_path / "r.npz"), ref)
@@ -430,6 +448,8 @@ def test_reference_npz_reader_detects_corruption(tmp_path):
     from wisecondorx_amd import npz_io
     a, b = os.urandom(1000), os.urandom(777)
     assert npz_io.crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    assert npz_io.crc32_combine_py(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    assert npz_io.crc32_combine_py(zlib.crc32(a), zlib.crc32(b""), 0) == zlib.crc32(a)
     assert npz_io.crc32_combine(zlib.crc32(a), zlib.crc32(b""), 0) == zlib.crc32(a)
     rng = np.random.default_rng(0)
     arrs = {"indexes": rng.integers(0, 1000, (30000, 100)).astype(np.int32),

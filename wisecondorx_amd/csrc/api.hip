@@ -2,6 +2,9 @@
 // orchestration of the newref search.  Kernels live in the sibling .hip files.
 #include "wcx_common.h"
 
+#include <cstring>
+#include <thread>
+
 static thread_local char g_err[1024] = "";
 
 void wcx_set_error(const char *fmt, ...) {
@@ -99,6 +102,58 @@ int wcx_timer_end(wcx_ctx *ctx, const char *name) {
   t.used = true;
   return WCX_OK;
 }
+
+// Large copies between PAGEABLE host memory and the device.  The runtime stages those through its
+// own pinned buffer with a single-threaded host memcpy (8 GB/s measured on the 0.8 GB result tables
+// of a 15 kb reference); here the DMA runs between HBM and two pinned halves of the context's
+// staging area while COPY_THREADS host threads move the other half to / from the caller's pages
+// (which, when fresh, they also fault in -- in parallel).
+namespace {
+constexpr size_t STAGED_MIN = (size_t)32 << 20;
+constexpr size_t STAGED_CHUNK = (size_t)32 << 20;
+constexpr int COPY_THREADS = 8;
+
+void host_copy_mt(char *dst, const char *src, size_t n) {
+  const size_t per = ((n + COPY_THREADS - 1) / COPY_THREADS + 4095) & ~(size_t)4095;
+  std::thread th[COPY_THREADS];
+  int used = 0;
+  for (size_t o = per; o < n; o += per)
+    th[used++] = std::thread([=] { memcpy(dst + o, src + o, o + per <= n ? per : n - o); });
+  memcpy(dst, src, per <= n ? per : n);
+  for (int i = 0; i < used; ++i) th[i].join();
+}
+
+int staged_copy(wcx_ctx *ctx, void *dst, const void *src, size_t bytes, bool to_host) {
+  void *pin = nullptr;
+  int rc = wcx_host_scratch(ctx, 2 * STAGED_CHUNK, &pin);
+  if (rc) return rc;
+  char *half[2] = {reinterpret_cast<char *>(pin), reinterpret_cast<char *>(pin) + STAGED_CHUNK};
+  char *d = reinterpret_cast<char *>(dst);
+  const char *s = reinterpret_cast<const char *>(src);
+  hipStream_t st = ctx->stream;
+  const size_t n_chunks = (bytes + STAGED_CHUNK - 1) / STAGED_CHUNK;
+  auto len = [&](size_t i) { return i + 1 < n_chunks ? STAGED_CHUNK : bytes - i * STAGED_CHUNK; };
+  if (to_host) {
+    WCX_HIP(hipMemcpyAsync(half[0], s, len(0), hipMemcpyDeviceToHost, st));
+    WCX_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n_chunks; ++i) {
+      if (i + 1 < n_chunks)
+        WCX_HIP(hipMemcpyAsync(half[(i + 1) & 1], s + (i + 1) * STAGED_CHUNK, len(i + 1),
+                               hipMemcpyDeviceToHost, st));
+      host_copy_mt(d + i * STAGED_CHUNK, half[i & 1], len(i));
+      WCX_HIP(hipStreamSynchronize(st));
+    }
+  } else {
+    host_copy_mt(half[0], s, len(0));
+    for (size_t i = 0; i < n_chunks; ++i) {
+      WCX_HIP(hipMemcpyAsync(d + i * STAGED_CHUNK, half[i & 1], len(i), hipMemcpyHostToDevice, st));
+      if (i + 1 < n_chunks) host_copy_mt(half[(i + 1) & 1], s + (i + 1) * STAGED_CHUNK, len(i + 1));
+      WCX_HIP(hipStreamSynchronize(st));
+    }
+  }
+  return WCX_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -211,6 +266,8 @@ int wcx_free(wcx_ctx *ctx, void *dptr) {
 
 int wcx_memcpy_h2d(wcx_ctx *ctx, void *dst, const void *src, size_t bytes) {
   WCX_ARG(ctx && dst && src, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  if (bytes >= STAGED_MIN) return staged_copy(ctx, dst, src, bytes, false);
   WCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   WCX_HIP(hipStreamSynchronize(ctx->stream));
   return WCX_OK;
@@ -218,6 +275,8 @@ int wcx_memcpy_h2d(wcx_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 int wcx_memcpy_d2h(wcx_ctx *ctx, void *dst, const void *src, size_t bytes) {
   WCX_ARG(ctx && dst && src, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  if (bytes >= STAGED_MIN) return staged_copy(ctx, dst, src, bytes, true);
   WCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   WCX_HIP(hipStreamSynchronize(ctx->stream));
   return WCX_OK;

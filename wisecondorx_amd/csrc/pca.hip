@@ -185,15 +185,10 @@ __global__ __launch_bounds__(256) void k_pca_dist2med(const double *__restrict__
 int wcx_nanmedian_rows_launch(wcx_ctx *ctx, const double *d_a, int64_t n, int64_t stride, int count,
                               double *d_out);   // predict.hip
 
-extern "C" {
-
-int wcx_pca_begin(wcx_ctx *ctx, const double *t_data, int64_t B, int S, double *mean_out,
-                  double *gram_out) {
-  WCX_ARG(ctx && t_data && mean_out && gram_out, "NULL argument");
+// persistent buffers of the context: t | X | mean | comps | dist (freed by wcx_pca_end / ctx destroy)
+int wcx_pca_alloc(wcx_ctx *ctx, int64_t B, int S, double **dt_out) {
   WCX_ARG(B > 0 && S > 1 && S <= 4096, "bad sizes (2 <= S <= 4096)");
-  WCX_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  // persistent buffers of the context: t | mean | X | comps (freed by wcx_pca_end / ctx destroy)
   const size_t tb = (size_t)S * B * 8;
   if (ctx->pca_bytes < 2 * tb + (size_t)B * 8 * 18) {
     WCX_HIP(hipStreamSynchronize(st));
@@ -207,6 +202,15 @@ int wcx_pca_begin(wcx_ctx *ctx, const double *t_data, int64_t B, int S, double *
   }
   ctx->pca_B = B;
   ctx->pca_S = S;
+  *dt_out = reinterpret_cast<double *>(ctx->d_pca);
+  return WCX_OK;
+}
+
+// per-bin mean and the S x S Gram matrix of the centred data in the context's t buffer
+int wcx_pca_gram_from_dt(wcx_ctx *ctx, double *mean_out, double *gram_out) {
+  hipStream_t st = ctx->stream;
+  const int64_t B = ctx->pca_B;
+  const int S = ctx->pca_S;
   double *dt = reinterpret_cast<double *>(ctx->d_pca);
   double *dmean = dt + (size_t)S * B * 2;
   const int ntile = (S + GT - 1) / GT;
@@ -220,7 +224,6 @@ int wcx_pca_begin(wcx_ctx *ctx, const double *t_data, int64_t B, int S, double *
   if (rc) return rc;
   double *dpart = reinterpret_cast<double *>(scr);
   double *dgram = dpart + (size_t)slices * S * S;
-  WCX_HIP(hipMemcpyAsync(dt, t_data, tb, hipMemcpyHostToDevice, st));
   rc = wcx_timer_begin(ctx, "pca_gram");
   if (rc) return rc;
   k_pca_mean<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(dt, B, S, dmean);
@@ -233,6 +236,27 @@ int wcx_pca_begin(wcx_ctx *ctx, const double *t_data, int64_t B, int S, double *
   WCX_HIP(hipMemcpyAsync(mean_out, dmean, (size_t)B * 8, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipMemcpyAsync(gram_out, dgram, (size_t)S * S * 8, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipStreamSynchronize(st));
+  return WCX_OK;
+}
+
+extern "C" {
+
+int wcx_pca_begin(wcx_ctx *ctx, const double *t_data, int64_t B, int S, double *mean_out,
+                  double *gram_out) {
+  WCX_ARG(ctx && t_data && mean_out && gram_out, "NULL argument");
+  WCX_ARG(B > 0 && S > 1 && S <= 4096, "bad sizes (2 <= S <= 4096)");
+  WCX_HIP(hipSetDevice(ctx->device));
+  double *dt = nullptr;
+  int rc = wcx_pca_alloc(ctx, B, S, &dt);
+  if (rc) return rc;
+  WCX_HIP(hipMemcpyAsync(dt, t_data, (size_t)S * B * 8, hipMemcpyHostToDevice, ctx->stream));
+  return wcx_pca_gram_from_dt(ctx, mean_out, gram_out);
+}
+
+int wcx_pca_corrected_dev(wcx_ctx *ctx, double **dX_out) {
+  WCX_ARG(ctx && dX_out, "NULL argument");
+  WCX_ARG(ctx->d_pca && ctx->pca_B > 0, "wcx_pca_begin / wcx_pca_finish must come first");
+  *dX_out = reinterpret_cast<double *>(ctx->d_pca) + (size_t)ctx->pca_S * ctx->pca_B;
   return WCX_OK;
 }
 

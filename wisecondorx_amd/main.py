@@ -84,9 +84,12 @@ def train_gender_model(args, samples):
     return genders.tolist(), cut_off
 
 
-def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, contexts):
+def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, contexts, dc=None, sel=None):
     """One of the A / F / M passes: tool_newref_prep + tool_newref_main + tool_newref_post
-    (newref_control.py:24-189) without the temp-file round trips."""
+    (newref_control.py:24-189) without the temp-file round trips.
+    dc / sel: the cohort's device-resident counts (prep.DeviceCounts) and this pass's sample
+    indexes -- normalisation, masking and the PCA then run from HBM, and on one GPU the corrected
+    matrix never leaves it."""
     from . import newref_tools
     # PCA on the device.  In the gonosomal passes the autosomal part of the mask is frozen: the
     # reference lets their PCA-distance filter drop autosomal bins the A reference still holds and
@@ -95,12 +98,20 @@ def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, context
     frozen = 0
     if gender != "A" and not getattr(args, "reference_mask_skew", False):
         frozen = int(np.sum(bins_per_chr[:22]))
-    p = prep.prepare(samples, gender, total_mask, bins_per_chr, ctx=contexts[0], frozen=frozen)
-    X = p.pop("X")
-    cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
     n_parts = len(contexts)
-    sample_ids = random.sample(range(X.shape[1]), min(X.shape[1], 100))   # newref_tools.py:214-217
-    parts = newref_tools.get_reference_parts(X, cum, args.refsize, n_parts, sample_ids, contexts)
+    if dc is not None:
+        p = prep.prepare_dev(dc, sel, gender, total_mask, bins_per_chr, frozen=frozen,
+                             want_host_X=n_parts > 1)
+    else:
+        p = prep.prepare(samples, gender, total_mask, bins_per_chr, ctx=contexts[0], frozen=frozen)
+    X = p.pop("X")
+    n_samples = p.pop("n_samples") if "n_samples" in p else X.shape[1]
+    cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
+    sample_ids = random.sample(range(n_samples), min(n_samples, 100))     # newref_tools.py:214-217
+    if X is None:
+        parts = [newref_tools.get_reference_dev(contexts[0], n_samples, cum, args.refsize, sample_ids)]
+    else:
+        parts = newref_tools.get_reference_parts(X, cum, args.refsize, n_parts, sample_ids, contexts)
     out = dict(p)
     out["binsize"] = args.binsize
     cat = (lambda seq: seq[0]) if len(parts) == 1 else np.concatenate     # (no 0.8 GB copy for one part)
@@ -125,7 +136,7 @@ def tool_newref(args):
         sample, binsize = npz_io.load_sample(infile)
         return scale_sample(sample, binsize, args.binsize), int(binsize)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=8) as ex:
+    with ThreadPoolExecutor(max_workers=npz_io._THREADS) as ex:
         for infile, (sample, binsize) in zip(args.infiles, ex.map(load_one, args.infiles)):
             logging.info("Loading: {}".format(infile))
             logging.info("Binsize: {}".format(binsize))
@@ -142,23 +153,34 @@ def tool_newref(args):
             samples[i] = gender_correct(sample, genders[i])
 
     g = np.array(genders)
-    total_mask, bins_per_chr = prep.get_mask(samples)
+    # the (gender-corrected) counts go to the device once; masks, every pass's normalisation and
+    # PCA read them there.  Non-integer counts (not something `convert` writes) take the host path.
+    dc = None
+    try:
+        dc = prep.DeviceCounts(contexts[0], samples)
+    except TypeError as e:
+        logging.info("Host-side masks / normalisation: {}".format(e))
+    sel_of = {"A": np.arange(len(genders)), "F": np.flatnonzero(g == "F"), "M": np.flatnonzero(g == "M")}
+    get_mask = (lambda k: dc.get_mask(sel_of[k])) if dc is not None else \
+        (lambda k: prep.get_mask(samples[sel_of[k]]))
+    total_mask, bins_per_chr = get_mask("A")
     if genders.count("F") > 4:
-        total_mask = total_mask & prep.get_mask(samples[g == "F"])[0]
+        total_mask = total_mask & get_mask("F")[0]
     if genders.count("M") > 4 and not args.nipt:
-        total_mask = total_mask & prep.get_mask(samples[g == "M"])[0]
+        total_mask = total_mask & get_mask("M")[0]
 
     final_ref = {"has_female": False, "has_male": False}
     if len(genders) > 9:
         logging.info("Starting autosomal reference creation ...")
-        sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts)
+        sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts, dc, sel_of["A"])
         final_ref.update({k: v for k, v in sub.items() if k != "gender"})
     else:
         logging.critical("Provide at least 10 samples to enable the generation of a reference.")
         sys.exit()
     if genders.count("F") > 4:
         logging.info("Starting female gonosomal reference creation ...")
-        sub = build_sub_reference(args, samples[g == "F"], "F", total_mask, bins_per_chr, contexts)
+        sub = build_sub_reference(args, samples[g == "F"], "F", total_mask, bins_per_chr, contexts, dc,
+                                  sel_of["F"])
         final_ref["has_female"] = True
         final_ref.update({k + ".F": v for k, v in sub.items() if k != "gender"})
     else:
@@ -166,11 +188,15 @@ def tool_newref(args):
     if not args.nipt:
         if genders.count("M") > 4:
             logging.info("Starting male gonosomal reference creation ...")
-            sub = build_sub_reference(args, samples[g == "M"], "M", total_mask, bins_per_chr, contexts)
+            sub = build_sub_reference(args, samples[g == "M"], "M", total_mask, bins_per_chr, contexts, dc,
+                                      sel_of["M"])
             final_ref["has_male"] = True
             final_ref.update({k + ".M": v for k, v in sub.items() if k != "gender"})
         else:
             logging.warning("Provide at least 5 male samples to enable normalization of male gonosomes.")
+    if dc is not None:
+        dc.close()
+        contexts[0].lib.wcx_pca_end(contexts[0].h)
     final_ref["is_nipt"] = args.nipt
     final_ref["trained_cutoff"] = trained_cutoff
     n_aut = int(np.sum(final_ref["bins_per_chr"]))

@@ -134,3 +134,55 @@ def get_reference_parts(pca_corrected_data, masked_bins_per_chr_cum, ref_size, n
             for p, res in part:
                 out[p] = res
     return out
+
+
+def get_reference_dev(ctx, n_samples, masked_bins_per_chr_cum, ref_size, sample_ids, mode=0):
+    """The whole pass (every row: indexes, distances, null ratios) on ONE device from the corrected
+    matrix the PCA stage left in HBM (wcx_pca_corrected_dev; prep.prepare_dev): no host copy of X, only
+    the three result tables come back.  Same device sequence as dist.GpuBackend.search -- the
+    gonosomal passes' autosomal rows are the reference's dummies (newref_tools.py:186-191)."""
+    import ctypes as C
+    lib = ctx.lib
+    cum, cum_p = _lib.i64_array(masked_bins_per_chr_cum)
+    ids, ids_p = _lib.i32_array(sample_ids)
+    B, S, k, m = int(cum[-1]), int(n_samples), int(ref_size), len(ids)
+    dX = C.c_void_p()
+    _lib.check(lib.wcx_pca_corrected_dev(ctx.h, C.byref(dX)))
+    idx = np.empty((B, k), dtype=np.int32)
+    dist = np.empty((B, k), dtype=np.float64)
+    nr = np.empty((B, m), dtype=np.float64)
+    bufs = [C.c_void_p() for _ in range(3)]
+    # the result tables are 0.8 GB of fresh host pages at 15 kb: worker threads touch them (page
+    # faults, the expensive part of a device -> pageable-host copy) while the device searches
+    from concurrent.futures import ThreadPoolExecutor
+    from .npz_io import _THREADS
+    ex = ThreadPoolExecutor(max_workers=_THREADS)
+    touched = []
+    for a in (idx, dist, nr):
+        flat = a.reshape(-1).view(np.uint8)
+        touched += [ex.submit(flat[o:o + (32 << 20)].fill, 0) for o in range(0, flat.size, 32 << 20)]
+    try:
+        for b, a in zip(bufs, (idx, dist, nr)):
+            _lib.check(lib.wcx_malloc(ctx.h, max(a.nbytes, 8), C.byref(b)))
+        d_idx, d_dist, d_nr = (b.value for b in bufs)
+        ct = int(cum[21]) if len(cum) > 22 else 0
+        if ct < B:
+            _lib.check(lib.wcx_null_rank_prepare_dev(ctx.h, dX, B, S, ids_p, m))
+        _lib.check(lib.wcx_newref_topk_dev(ctx.h, dX, B, S, cum_p, len(cum), 0, B, k, int(mode),
+                                           d_idx, d_dist))
+        if ct > 0:
+            _lib.check(lib.wcx_null_ratios_dummy_dev(ctx.h, dX, B, S, 0, min(B, ct), ids_p, m, d_nr))
+        if ct < B:
+            _lib.check(lib.wcx_null_ratios_dev(ctx.h, dX, B, S, d_idx + ct * k * 4, ct, B, k, ids_p, m,
+                                               d_nr + ct * m * 8))
+        for f in touched:
+            f.result()
+        for b, a in zip(bufs, (idx, dist, nr)):
+            if a.nbytes:
+                _lib.check(lib.wcx_memcpy_d2h(ctx.h, _lib.ptr(a), b, a.nbytes))
+    finally:
+        ex.shutdown(wait=True)
+        for b in bufs:
+            if b.value:
+                lib.wcx_free(ctx.h, b)
+    return idx, dist, nr

@@ -26,7 +26,23 @@ import numpy as np
 
 _BIG = 8 << 20            # stored by the direct writer / read by the direct reader
 _DEFLATE_MAX = 1 << 20    # anything larger is mostly incompressible doubles: stored as is
-_THREADS = 8
+
+
+def _cpu_budget():
+    """CPUs this process may really use: the cgroup quota when there is one (a container sees every
+    core of the host in os.cpu_count()), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+_THREADS = max(2, min(16, _cpu_budget()))
 _Z64 = 0xFFFFFFFF           # sizes / offsets from here on go into ZIP64 extra fields
 _DOS_TIME, _DOS_DATE = 0, (1980 - 1980) << 9 | 1 << 5 | 1      # 1980-01-01 00:00, like np.savez
 
@@ -100,15 +116,25 @@ def save_npz(path, arrays, compress_small=True):
         with ThreadPoolExecutor(max_workers=_THREADS) as ex:
             # payload writes (positional, in pieces) and the CRC-32 of each stored member run side
             # by side on the worker threads (zlib and os.pwrite release the GIL)
-            futs, crcs = [], []
+            # every chunk of a stored member: CRC-32 and positional write on one worker (zlib and
+            # os.pwrite release the GIL); the member's CRC is the chunks' combined in order
+            jobs = []
             for m in members:
-                if "crc" not in m:
-                    crcs.append((m, ex.submit(_crc_of, m["head"], m["raw"])))
+                if "crc" in m:
+                    jobs.append((m, [ex.submit(_pwrite_all, fd, m["raw"], m["data_off"])]))
+                    continue
                 base = m["data_off"] + len(m["head"])
-                for a, b in _crc_chunks(m["raw"], _THREADS):
-                    futs.append(ex.submit(_pwrite_all, fd, m["raw"][a:b], base + a))
-            for m, fut in crcs:
-                m["crc"] = fut.result()
+                jobs.append((m, [ex.submit(_crc_and_write, fd, m["raw"][a:b], base + a)
+                                 for a, b in _crc_chunks(m["raw"], 4 * _THREADS)]))
+            for m, fs in jobs:
+                if "crc" in m:
+                    fs[0].result()
+                    continue
+                crc = zlib.crc32(m["head"])
+                for f in fs:
+                    c, n = f.result()
+                    crc = crc32_combine(crc, c, n)
+                m["crc"] = crc
             # ---- headers and central directory
             cd = b""
             for m in members:
@@ -145,8 +171,6 @@ def save_npz(path, arrays, compress_small=True):
                                 0xFFFFFFFF if len(cd) >= _Z64 else len(cd),
                                 0xFFFFFFFF if cd_off >= _Z64 else cd_off, 0)
             _pwrite_all(fd, memoryview(cd + tail), cd_off)
-            for f in futs:
-                f.result()
         ok = True
     finally:
         os.close(fd)
@@ -166,18 +190,56 @@ def _pwrite_all(fd, view, offset):
         done += os.pwrite(fd, view[done:done + (64 << 20)], offset + done)
 
 
-def _crc_of(head, raw):
-    crc = zlib.crc32(head)
-    for o in range(0, len(raw), 256 << 20):
-        crc = zlib.crc32(raw[o:o + (256 << 20)], crc)
-    return crc
+def _crc_and_write(fd, view, offset):
+    crc = 0
+    for o in range(0, len(view), 16 << 20):           # (the piece is still in cache when written)
+        piece = view[o:o + (16 << 20)]
+        crc = zlib.crc32(piece, crc)
+        _pwrite_all(fd, piece, offset + o)
+    return crc, len(view)
+
+
+def _member_bytes(data, zf, name):
+    """One member of an in-memory ZIP, inflated in ONE zlib call (which releases the GIL: np.load's
+    ZipExtFile inflates in small pieces under it) and CRC-checked.  None = leave it to np.load."""
+    try:
+        zi = zf.getinfo(name)
+    except KeyError:
+        return None
+    if zi.compress_type not in (0, 8) or zi.flag_bits & 0x1:
+        return None
+    o = zi.header_offset
+    if bytes(data[o:o + 4]) != b"PK\x03\x04":
+        return None
+    nlen, elen = struct.unpack_from("<HH", data, o + 26)
+    start = o + 30 + nlen + elen
+    raw = data[start:start + zi.compress_size]
+    if len(raw) != zi.compress_size:
+        raise zipfile.BadZipFile("truncated member {!r}".format(name))
+    out = zlib.decompress(raw, -15) if zi.compress_type == 8 else bytes(raw)
+    if len(out) != zi.file_size or zlib.crc32(out) != zi.CRC:
+        raise zipfile.BadZipFile("Bad CRC-32 for file {!r}".format(name))
+    return out
 
 
 def load_sample(path):
     """-> (sample dict "1".."24" -> int32 array, binsize) as written by `convert`
-    (main.py:33-35, convert_tools.py:110-119)."""
-    npz = np.load(path, encoding="latin1", allow_pickle=True)
-    return npz["sample"].item(), int(npz["binsize"])
+    (main.py:33-35, convert_tools.py:110-119).  The file is read whole and its two members are
+    inflated by one zlib call each, so loader threads really run side by side (newref imports
+    hundreds of samples); anything unusual about the archive goes through np.load."""
+    with open(path, "rb") as fh:
+        data = memoryview(fh.read())
+    try:
+        zf = zipfile.ZipFile(io.BytesIO(data))
+        parts = [_member_bytes(data, zf, n) for n in ("sample.npy", "binsize.npy")]
+    except (zipfile.BadZipFile, struct.error, zlib.error) as e:
+        raise zipfile.BadZipFile("{}: {}".format(path, e))
+    if any(p is None for p in parts):
+        npz = np.load(path, encoding="latin1", allow_pickle=True)
+        return npz["sample"].item(), int(npz["binsize"])
+    sample, binsize = (np.lib.format.read_array(io.BytesIO(p), allow_pickle=True,
+                                                pickle_kwargs={"encoding": "latin1"}) for p in parts)
+    return sample.item(), int(binsize)
 
 
 def save_sample(path, sample, binsize, quality=None):
@@ -209,9 +271,34 @@ def _gf2_times(mat, vec):
     return s
 
 
+def _libz_combine():
+    """zlib's own crc32_combine (the Python module does not export it), if libz can be loaded."""
+    try:
+        import ctypes
+        import ctypes.util
+        z = ctypes.CDLL(ctypes.util.find_library("z") or "libz.so.1")
+        fn = z.crc32_combine
+        fn.argtypes = [ctypes.c_ulong, ctypes.c_ulong, ctypes.c_long]
+        fn.restype = ctypes.c_ulong
+        return fn if fn(zlib.crc32(b"ab"), zlib.crc32(b"cde"), 3) == zlib.crc32(b"abcde") else None
+    except (OSError, AttributeError):
+        return None
+
+
+_LIBZ_COMBINE = _libz_combine()
+
+
 def crc32_combine(crc1, crc2, len2):
-    """CRC-32 of A + B from crc32(A), crc32(B) and len(B) (zlib's crc32_combine: the operator that
-    appends len2 zero bytes, by repeated squaring in GF(2))."""
+    """CRC-32 of A + B from crc32(A), crc32(B) and len(B): libz's crc32_combine when loadable, else
+    the same operator here."""
+    if _LIBZ_COMBINE is not None and len2 > 0:
+        return int(_LIBZ_COMBINE(crc1, crc2, len2)) & 0xFFFFFFFF
+    return crc32_combine_py(crc1, crc2, len2)
+
+
+def crc32_combine_py(crc1, crc2, len2):
+    """zlib's crc32_combine restated: the operator that appends len2 zero bytes, by repeated squaring
+    in GF(2)."""
     if len2 <= 0:
         return crc1
     odd = [0xEDB88320] + [1 << n for n in range(31)]          # one zero BIT

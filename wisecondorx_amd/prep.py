@@ -105,6 +105,26 @@ def train_pca(ref_data, pcacomp=5):
     return corrected.T, PCAModel(comps, mean)
 
 
+def _pca_finish(ctx, S, B, mean, gram, pcacomp, want_dist, want_X):
+    """The host half of the device PCA: the S x S symmetric eigenproblem (LAPACK) between
+    wcx_pca_begin* and wcx_pca_finish, then scikit-learn's sign convention."""
+    from . import _lib
+    w, v = np.linalg.eigh(gram)
+    order = np.argsort(w)[::-1][:pcacomp]
+    sv = np.ascontiguousarray(np.sqrt(np.maximum(w[order], 0.0)))
+    u = np.ascontiguousarray(v[:, order])                             # (S, pcacomp)
+    comps = np.empty((pcacomp, B))
+    Xs = np.empty((S, B)) if want_X else None
+    d2m = np.empty(B) if want_dist else None
+    _lib.check(ctx.lib.wcx_pca_finish(ctx.h, _lib.ptr(u), _lib.ptr(sv), pcacomp, _lib.ptr(comps),
+                                      _lib.ptr(Xs), _lib.ptr(d2m)))
+    # sklearn's svd_flip convention: largest |loading| of each component is positive
+    signs = np.sign(comps[np.arange(pcacomp), np.argmax(np.abs(comps), axis=1)])
+    signs[signs == 0] = 1.0
+    comps = comps * signs[:, None]
+    return Xs, PCAModel(comps, mean), d2m
+
+
 def train_pca_gpu(ref_data, ctx, pcacomp=5, want_dist=False, sample_major=False):
     """train_pca on the MI355X (libwcx_hip.so: wcx_pca_begin / wcx_pca_finish): Gram matrix,
     components, reconstruction and ratio on the device, the S x S eigenproblem here (LAPACK).
@@ -120,23 +140,73 @@ def train_pca_gpu(ref_data, ctx, pcacomp=5, want_dist=False, sample_major=False)
     gram = np.empty((S, S))
     _lib.check(ctx.lib.wcx_pca_begin(ctx.h, _lib.ptr(t_data), B, S, _lib.ptr(mean), _lib.ptr(gram)))
     try:
-        w, v = np.linalg.eigh(gram)
-        order = np.argsort(w)[::-1][:pcacomp]
-        sv = np.ascontiguousarray(np.sqrt(np.maximum(w[order], 0.0)))
-        u = np.ascontiguousarray(v[:, order])                             # (S, pcacomp)
-        comps = np.empty((pcacomp, B))
-        Xs = np.empty((S, B))
-        d2m = np.empty(B) if want_dist else None
-        _lib.check(ctx.lib.wcx_pca_finish(ctx.h, _lib.ptr(u), _lib.ptr(sv), pcacomp, _lib.ptr(comps),
-                                          _lib.ptr(Xs), _lib.ptr(d2m)))
+        Xs, pca, d2m = _pca_finish(ctx, S, B, mean, gram, pcacomp, want_dist, True)
     finally:
         ctx.lib.wcx_pca_end(ctx.h)
-    # sklearn's svd_flip convention: largest |loading| of each component is positive
-    signs = np.sign(comps[np.arange(pcacomp), np.argmax(np.abs(comps), axis=1)])
-    signs[signs == 0] = 1.0
-    comps = comps * signs[:, None]
-    out = (Xs.T, PCAModel(comps, mean))                                   # X: F-ordered (B, S) view
+    out = (Xs.T, pca)                                                     # X: F-ordered (B, S) view
     return out + (d2m,) if want_dist else out
+
+
+class DeviceCounts:
+    """The cohort's bin counts resident in HBM: int32 [S][n_bins], every sample's chromosomes 1..24
+    laid out over the longest sample's bins per chromosome, zero padded (what the reference's
+    np.zeros + copy loops build, newref_tools.py:80-91).  The masks (get_mask) and every pass's
+    normalised matrix (prepare_dev) are computed from it on the device: the 729 MB float matrix of
+    a 15 kb x 500 cohort is never built on the host."""
+
+    def __init__(self, ctx, samples):
+        from . import _lib
+        import ctypes as C
+        self.ctx = ctx
+        self.S = len(samples)
+        self.bins_per_chr = [max(len(s[str(c)]) for s in samples) for c in range(1, 25)]
+        off = np.concatenate(([0], np.cumsum(self.bins_per_chr))).astype(np.int64)
+        self.off = off
+        self.n_bins = int(off[-1])
+        counts = np.zeros((self.S, self.n_bins), dtype=np.int32)
+        for i, s in enumerate(samples):
+            row = counts[i]
+            for c in range(24):
+                v = np.asarray(s[str(c + 1)])
+                if not np.issubdtype(v.dtype, np.integer):
+                    raise TypeError("bin counts must be integers (sample {}, chromosome {}: {})".format(
+                        i, c + 1, v.dtype))
+                if v.dtype.itemsize > 4 or v.dtype == np.uint32:        # (convert writes int32)
+                    if len(v) and (v.max() > 2 ** 31 - 1 or v.min() < -2 ** 31):
+                        raise ValueError("bin count outside int32 (sample {}, chromosome {})".format(
+                            i, c + 1))
+                row[off[c]:off[c] + len(v)] = v
+        self.d = C.c_void_p()
+        _lib.check(ctx.lib.wcx_malloc(ctx.h, counts.nbytes, C.byref(self.d)))
+        _lib.check(ctx.lib.wcx_memcpy_h2d(ctx.h, self.d, _lib.ptr(counts), counts.nbytes))
+
+    def close(self):
+        if self.d is not None and self.d.value:
+            self.ctx.lib.wcx_free(self.ctx.h, self.d)
+        self.d = None
+
+    def get_mask(self, sel=None):
+        """get_mask (newref_tools.py:77-102) of the samples `sel` (default: all) on the device."""
+        from . import _lib
+        sel, sel_p = _lib.i32_array(range(self.S) if sel is None else sel)
+        mask = np.empty(self.n_bins, dtype=np.uint8)
+        _lib.check(self.ctx.lib.wcx_prep_mask_dev(self.ctx.h, self.d, self.n_bins, sel_p, len(sel),
+                                                  _lib.ptr(mask)))
+        return mask.astype(bool), list(self.bins_per_chr)
+
+    def pca_begin(self, sel, last_chr, mask):
+        """normalize_and_mask of the pass (chromosomes 1..last_chr, kept bins of `mask`) written into
+        the PCA stage's device buffer + its Gram step.  Returns (S, B, mean, gram)."""
+        from . import _lib
+        sel, sel_p = _lib.i32_array(sel)
+        n_pass = int(self.off[last_chr])
+        pos, pos_p = _lib.i32_array(np.flatnonzero(mask[:n_pass]))
+        S, B = len(sel), len(pos)
+        mean = np.empty(B)
+        gram = np.empty((S, S))
+        _lib.check(self.ctx.lib.wcx_pca_begin_counts_dev(self.ctx.h, self.d, self.n_bins, sel_p, S, n_pass,
+                                                         pos_p, B, _lib.ptr(mean), _lib.ptr(gram)))
+        return S, B, mean, gram
 
 
 def filter_from_dist(dist_to_med):
@@ -197,5 +267,47 @@ def prepare(samples, gender, mask, bins_per_chr, ctx=None, frozen=0):
         "X": X, "mask": mask.copy(), "bins_per_chr": np.array(bins_per_chr),
         "masked_bins_per_chr": np.array(masked_bins_per_chr),
         "masked_bins_per_chr_cum": np.array(masked_bins_per_chr_cum),
+        "pca_components": pca.components_, "pca_mean": pca.mean_, "gender": gender,
+    }
+
+
+def prepare_dev(dc, sel, gender, mask, bins_per_chr, frozen=0, want_host_X=False):
+    """prepare() from device-resident counts (DeviceCounts): same steps, same in-place mask update,
+    same return value -- except that "X" is None unless want_host_X: the corrected matrix stays in
+    HBM (wcx_pca_corrected_dev) for the search of this pass.  The caller ends the PCA stage
+    (wcx_pca_end) when the last pass is done."""
+    ctx = dc.ctx
+    last_chr = {"A": 22, "F": 23}.get(gender, 24)
+    bins_per_chr = list(bins_per_chr[:last_chr])
+    mask = mask[:int(np.sum(bins_per_chr))]
+    S, B, mean, gram = dc.pca_begin(sel, last_chr, mask)
+    Xs, pca, d2m = _pca_finish(ctx, S, B, mean, gram, 5, True, False)
+    bad, cutoff = filter_from_dist(d2m)
+    if np.any(bad) and frozen:
+        kept = bad & (np.where(mask)[0] < frozen)
+        if np.any(kept):
+            logging.info("Keeping {} anomalous autosomal bins (PCA distance): the autosomal reference "
+                         "of this file already holds them".format(int(np.sum(kept))))
+            bad = bad & ~kept
+    if np.any(bad):
+        logging.info("Removing {} anomalous bins based on PCA distance (cutoff={:.4f})".format(
+            int(np.sum(bad)), cutoff))
+        mask[np.where(mask)[0][bad]] = False
+        S, B, mean, gram = dc.pca_begin(sel, last_chr, mask)
+        Xs, pca, _ = _pca_finish(ctx, S, B, mean, gram, 5, False, False)
+    if want_host_X:
+        from . import _lib
+        import ctypes as C
+        dX = C.c_void_p()
+        _lib.check(ctx.lib.wcx_pca_corrected_dev(ctx.h, C.byref(dX)))
+        Xs = np.empty((S, B))
+        _lib.check(ctx.lib.wcx_memcpy_d2h(ctx.h, _lib.ptr(Xs), dX, Xs.nbytes))
+    off = np.concatenate(([0], np.cumsum(bins_per_chr)))
+    masked_bins_per_chr = [int(np.sum(mask[off[i]:off[i + 1]])) for i in range(len(bins_per_chr))]
+    return {
+        "X": Xs.T if want_host_X else None, "n_samples": S, "mask": mask.copy(),
+        "bins_per_chr": np.array(bins_per_chr),
+        "masked_bins_per_chr": np.array(masked_bins_per_chr),
+        "masked_bins_per_chr_cum": np.array(np.cumsum(masked_bins_per_chr).tolist()),
         "pca_components": pca.components_, "pca_mean": pca.mean_, "gender": gender,
     }
