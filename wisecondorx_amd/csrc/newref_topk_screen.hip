@@ -739,6 +739,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // (every launch costs ~30 us of prologue per round of workgroups -- target fragments, visit
   // list --, so large K, whose groups are big, takes bigger chunks: L2 misses go to the MALL)
   int64_t chunk_groups = ((int64_t)env_int("WCX_SCREEN_CHUNK_KB", NK > 16 ? 8192 : 3072) << 10) / group_bytes;
+  // (small shards swept in candidate segments -- the gonosomal passes: ~300 workgroups, less than one
+  // round -- have no tail to hide and no L2 to share in step; their launches only cost: 3 / 6 / 12 /
+  // 24 MB chunks: F pass screen 4.56 / 3.73 / 3.43 / 3.22 ms, M pass 5.33 / 4.87 / 4.34 / 4.16 ms)
+  if (n_seg > 1) chunk_groups = ((int64_t)env_int("WCX_SCREEN_CHUNK_KB_SMALL", 24576) << 10) / group_bytes;
   if (chunk_groups < 16) chunk_groups = 16;
   if (chunk_groups > 4096) chunk_groups = 4096;
   const size_t lds = (size_t)(cfg.ring >= 2 ? cfg.ring : 2) * (size_t)(CTG * NK * 64) * 16 +
