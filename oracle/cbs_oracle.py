@@ -6,8 +6,13 @@ product (wisecondorx_amd/) never does.
 What this restates.  The reference delegates the segmentation to Bioconductor DNAcopy 1.76.0
 (`segment(CNA.object, alpha=..., verbose=1, weights=...)`, /root/reference/src/wisecondorx/include/
 CBS.R:70-73, called from predict_tools.py:242-257 / main.py:279; version pin conda.yml:14).  DNAcopy's
-source is NOT under /root/reference and R cannot be installed here, so there is nothing to run and no
-golden vector to pin against: PARITY UNPINNED for breakpoints.  This file is an independent plain
+source is NOT under /root/reference and R cannot be installed here, so there is nothing to run.
+PIN: the ONE DNAcopy output the reference repository ships -- docs/include/example.bed, a real 100 kb
+NIPT trisomy-21 run: 30 321 bin ratios in, 50 segments out -- is reproduced bin for bin, all 50
+segments (tests/test_oracle_cbs.py::test_oracle_reproduces_the_references_shipped_dnacopy_segments,
+fixture tests/golden/example_bed.npz made by tests/golden/make_golden.py example).  That run's
+weights are not shipped (unit weights are used), and one sample exercises few borderline decisions,
+so beyond that example the breakpoints remain PARITY UNPINNED.  This file is an independent plain
 NumPy statement of the algorithm DNAcopy implements, written from
 
   [O04]  Olshen, Venkatraman, Lucito, Wigler, "Circular binary segmentation for the analysis of

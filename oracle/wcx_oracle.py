@@ -11,7 +11,9 @@ Pinning status:
     /root/reference in the build container, on the fixtures in tests/golden/ (generator:
     tests/golden/make_golden.py; checks: tests/test_oracle_golden.py).
   * a16 CBS breakpoints (DNAcopy::segment, Bioconductor DNAcopy 1.76.0 -- conda.yml:14 --
-    not vendored, R absent): PARITY UNPINNED against DNAcopy.  The segmentation algorithm
+    not vendored, R absent): pinned on the one DNAcopy run the reference ships
+    (docs/include/example.bed, 50 segments reproduced bin for bin), otherwise PARITY UNPINNED
+    against DNAcopy.  The segmentation algorithm
     is restated in oracle/cbs_oracle.py (cbs_segment() there plugs into cbs_r_wrapper()
     below as its segment_fn); the reference-owned code around the DNAcopy call
     (CBS.R:41-63,84-129) is restated exactly in cbs_r_wrapper().

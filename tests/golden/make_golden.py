@@ -523,7 +523,35 @@ def golden_cbs_bdry():
     save("cbs_bdry.npz", eta=0.05, nperm=10000, max_ones=101, table=tab)
 
 
+def golden_example_bed():
+    """The one DNAcopy output the reference repository ships: docs/include/example.bed (a 100 kb NIPT
+    trisomy-21 case) -- ID_bins.bed holds the per-bin log2 ratios CBS.R was given (NaN = blacklisted,
+    i.e. ratio 0 on input), ID_segments.bed what DNAcopy + CBS.R's NA-gap split made of them.  Data
+    only: ratios per chromosome (1..22, X), and the segments as (chr0, first bin, end bin exclusive,
+    ratio to 4 decimals, z).  The weights of that run (1 / mean sqrt reference distance) are not
+    shipped, so tests run the segmentation with unit weights and compare the BOUNDARIES."""
+    d = "/root/reference/docs/include/example.bed"
+    names = [str(i) for i in range(1, 23)] + ["X"]
+    ratios = {n: [] for n in names}
+    binsize = None
+    for line in open(os.path.join(d, "ID_bins.bed")).read().splitlines()[1:]:
+        c, a, b, _, r, _ = line.split("\t")
+        binsize = binsize or int(b) - int(a) + 1
+        assert (int(a) - 1) // binsize == len(ratios[c])
+        ratios[c].append(float("nan") if r == "NaN" else float(r))
+    segs = []
+    for line in open(os.path.join(d, "ID_segments.bed")).read().splitlines()[1:]:
+        c, a, b, r, z = line.split("\t")
+        segs.append([names.index(c), (int(a) - 1) // binsize, int(b) // binsize, float(r), float(z)])
+    flat = np.concatenate([np.array(ratios[n]) for n in names])
+    save("example_bed.npz", binsize=binsize, bins_per_chr=np.array([len(ratios[n]) for n in names]),
+         ratios=flat, segments=np.array(segs))
+
+
 if __name__ == "__main__":
+    if "example" in sys.argv[1:]:
+        golden_example_bed()
+        sys.exit(0)
     if "bdry" in sys.argv[1:]:
         golden_cbs_bdry()
     if "gender" in sys.argv[1:]:

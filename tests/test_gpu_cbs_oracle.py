@@ -3,8 +3,9 @@ against the NumPy oracle (oracle/cbs_oracle.py) on a fuzz of > 200 series -- n f
 weights, NA runs, planted / borderline / absent effects, heavy tails, alpha in {1e-4, 1e-3, 1e-2} --
 asserting IDENTICAL change-points, identical decisions of every single test (why it stopped, best
 arc, exceedance count nrej and stopping point np under the sequential boundary, edge tests) and the
-reference-owned CBS.R wrapper output.  DNAcopy itself stays unpinned (no R here): this pins the device
-code to an independent statement of the same algorithm, not to DNAcopy's binaries."""
+reference-owned CBS.R wrapper output.  DNAcopy itself cannot be run here; the one DNAcopy output the
+reference ships (docs/include/example.bed) is reproduced bin for bin by the last test of this file,
+everything else pins the device code to an independent statement of the same algorithm."""
 import multiprocessing as mp
 import os
 from concurrent.futures import ProcessPoolExecutor
@@ -262,3 +263,19 @@ def test_batch_equals_single_and_is_seed_keyed(pt):
     assert np.array_equal(t9, t9b, equal_nan=True)
     perm9, perm10 = t9[t9[:, 10] == 5], t10[t10[:, 10] == 5]
     assert len(perm9) and not (len(perm9) == len(perm10) and np.array_equal(perm9[:, 12:14], perm10[:, 12:14]))
+
+
+def test_device_reproduces_the_references_shipped_dnacopy_segments(bdry):
+    """wcx_cbs on the reference's own example run (docs/include/example.bed -> example_bed.npz; unit
+    weights): the same 50 segments as DNAcopy + CBS.R produced, bin for bin, and the oracle's
+    segment ratios to 1e-12."""
+    from test_oracle_cbs import example_case
+    from oracle import wcx_oracle as O
+    from wisecondorx_amd import _lib, predict_tools
+    CO.load_boundary_table(bdry)
+    results_r, results_w, binsize, want = example_case()
+    res = {"results_r": [v.tolist() for v in results_r], "results_w": [v.tolist() for v in results_w]}
+    got = predict_tools.run_cbs(res, "F", 1e-4, binsize, 1, _lib.default_context(0))
+    assert [tuple(s[:3]) for s in got] == [tuple(int(v) for v in s[:3]) for s in want]
+    ora = O.cbs_r_wrapper(results_r, results_w, "F", 1e-4, binsize, 1, CO.cbs_segment)
+    np.testing.assert_allclose([s[3] for s in got], [s[3] for s in ora], rtol=0, atol=1e-12)

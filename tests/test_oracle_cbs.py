@@ -1,6 +1,7 @@
 """CPU tests of the CBS oracle (oracle/cbs_oracle.py) and of the host-only part of the product's CBS
-(the sequential boundary, wcx_cbs_getbdry).  DNAcopy itself is not available (PARITY UNPINNED,
-SURVEY.md §8c shim 2), so the oracle is checked against the MATHEMATICS it restates: the tail
+(the sequential boundary, wcx_cbs_getbdry).  DNAcopy itself is not available (SURVEY.md §8c shim
+2): the oracle is pinned on the one DNAcopy run the reference ships (last test) and otherwise
+checked against the MATHEMATICS it restates: the tail
 approximation against a Monte-Carlo estimate, the sequential boundary against its defining error
 probability, the permutation stream against uniformity."""
 import os
@@ -162,3 +163,36 @@ def test_oracle_segments_planted_changes_and_leaves_noise_alone(bdry):
     # constant and tiny series
     assert CO.changepoints(np.full(50, 0.3), np.ones(50), 1e-2, 1, 0) == [50]
     assert CO.changepoints(np.array([0.1, 0.5, 0.2]), np.ones(3), 1e-2, 1, 0) == [3]
+
+
+def example_case():
+    """The reference's shipped DNAcopy run (tests/golden/example_bed.npz, see make_golden.py example):
+    per-chromosome ratios in CBS.R's input convention (0 = blacklisted), unit weights (the run's
+    weights are not shipped), and the segments it produced."""
+    g = np.load(os.path.join(GOLDEN, "example_bed.npz"))
+    off = np.concatenate(([0], np.cumsum(g["bins_per_chr"])))
+    r = np.nan_to_num(g["ratios"], nan=0.0)
+    results_r = [r[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+    results_w = [np.ones(len(v)) for v in results_r]
+    return results_r, results_w, int(g["binsize"]), g["segments"]
+
+
+def test_oracle_reproduces_the_references_shipped_dnacopy_segments(bdry):
+    """THE pin against DNAcopy itself: docs/include/example.bed of the reference is a real run of
+    CBS.R (DNAcopy, alpha = 1e-4, 100 kb bins, 30 321 bins of a trisomy-21 NIPT sample).  With unit
+    weights the oracle reproduces every one of its 50 segments bin for bin: 44 chromosomes / arms
+    left unsplit, the NA-gap splits of CBS.R:84-113, the change-points DNAcopy placed across short
+    (<= 20-bin) NA gaps (chr1 143.3 | 145.3 Mb, chr2 92.1 | 94.1 Mb, chr8, chr16) and the
+    chr21 13.1 Mb change-point of the trisomy.  The segment ratios agree to the 4 decimals printed
+    only approximately (3e-3): that run's weights are unknown."""
+    from oracle import wcx_oracle as O
+    CO.load_boundary_table(bdry)
+    results_r, results_w, binsize, want = example_case()
+    got = O.cbs_r_wrapper(results_r, results_w, "F", 1e-4, binsize, 1, CO.cbs_segment)
+    assert [tuple(s[:3]) for s in got] == [tuple(int(v) for v in s[:3]) for s in want]
+    assert np.max(np.abs(np.array([s[3] for s in got]) - want[:, 3])) < 3e-3
+    t21 = [s for s in got if s[0] == 20 and s[1] == 131][0]
+    assert abs(t21[3] - 0.0923) < 2e-4                      # ID_aberrations.bed: 21 gain 0.0923
+    # the outcome does not hinge on the permutation stream
+    again = O.cbs_r_wrapper(results_r, results_w, "F", 1e-4, binsize, 77, CO.cbs_segment)
+    assert [s[:3] for s in again] == [s[:3] for s in got]
