@@ -185,6 +185,179 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
   }
 }
 
+// ---- the same selection on 64-bit keys (order-preserving images of the doubles themselves) --------
+// For a FEW target rows -- the chrX / chrY rows of a gonosomal pass, one rank's shard of a multi-GPU
+// build -- ranking every bin of every null sample first (two radix sorts over n_ids * B elements:
+// 6.7 ms of device work at 15 kb) costs more than it saves: the direct kernel below gathers the
+// doubles, maps them to dkey() and selects the two middle keys of each (row, sample) with the
+// bucket scheme of wave_middle_u32.  Same bits as the rank path (a zero median is +0 on both, as
+// np.median's mean makes it).
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)v, o, 64);
+    const unsigned int hi = (unsigned int)__shfl_xor((int)(unsigned int)(v >> 32), o, 64);
+    const unsigned long long p = ((unsigned long long)hi << 32) | lo;
+    v = p < v ? p : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int IPL>
+__device__ __forceinline__ unsigned long long select_u64_bisect(const unsigned long long (&v)[IPL],
+                                                                unsigned int act, int rank) {
+  unsigned long long prefix = 0;
+  for (int bit = 63; bit >= 0; --bit) {
+    const unsigned long long trial = prefix | (1ull << bit);
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) c += __popcll(__ballot(((act >> q) & 1u) && v[q] < trial));
+    if (c <= rank) prefix = trial;
+  }
+  return prefix;
+}
+
+// hist: int[64], slots: u64[64], wave-private LDS
+template <int IPL>
+__device__ __forceinline__ void wave_middle_u64(const unsigned long long (&v)[IPL], unsigned int act,
+                                                int n, int *hist, unsigned long long *slots,
+                                                unsigned long long &a0, unsigned long long &a1,
+                                                unsigned long long &hi_out) {
+  const int lane = wcx::lane_id();
+  const int r0 = (n - 1) >> 1, r1 = n >> 1;
+  unsigned long long lo = ~0ull, nhi = ~0ull;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q)
+    if ((act >> q) & 1u) { lo = v[q] < lo ? v[q] : lo; nhi = ~v[q] < nhi ? ~v[q] : nhi; }
+  lo = wave_min_u64(lo);
+  const unsigned long long hi = ~wave_min_u64(nhi);
+  hi_out = hi;
+  if (hi == lo) { a0 = lo; a1 = lo; return; }
+  // (float of a u64 difference is monotone; 1.0000002f keeps bucket(hi) <= 63 after rounding)
+  const float scale = 64.0f / ((float)(hi - lo) * 1.0000002f + 1.0f);
+  hist[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  int b[IPL];
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    b[q] = 0;
+    if ((act >> q) & 1u) {
+      int bb = (int)((float)(v[q] - lo) * scale);          // monotone in v
+      bb = bb > 63 ? 63 : bb;
+      b[q] = bb;
+      atomicAdd(&hist[bb], 1);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int h = hist[lane];
+  const int cum = wcx::wave_incl_scan_i(h);
+  const unsigned long long gt = __ballot(cum > r0);
+  const int B0 = __ffsll((long long)gt) - 1;
+  const int before = B0 > 0 ? __builtin_amdgcn_readlane(cum, B0 - 1) : 0;
+  const int need = r0 - before;
+  const int cB = __builtin_amdgcn_readlane(h, B0);
+  if (cB > 64) {
+    a0 = select_u64_bisect<IPL>(v, act, r0);
+    a1 = r1 == r0 ? a0 : select_u64_bisect<IPL>(v, act, r1);
+    return;
+  }
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const bool m = ((act >> q) & 1u) && b[q] == B0;
+    const unsigned long long mm = __ballot(m);
+    if (m) slots[base + __popcll(mm & ((1ull << lane) - 1ull))] = v[q];
+    base += __popcll(mm);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long w = lane < cB ? slots[lane] : ~0ull;
+  int rk = 0;
+  for (int L = 0; L < cB; ++L) {
+    const unsigned long long p = readlane_u64(w, L);
+    rk += ((p < w) || (p == w && L < lane)) ? 1 : 0;
+  }
+  const unsigned long long hit = __ballot(lane < cB && rk == need);
+  a0 = readlane_u64(w, __ffsll((long long)hit) - 1);
+  a1 = a0;
+  if (r1 != r0) {
+    if (need + 1 < cB) {
+      const unsigned long long hit1 = __ballot(lane < cB && rk == need + 1);
+      a1 = readlane_u64(w, __ffsll((long long)hit1) - 1);
+    } else {
+      unsigned long long mn = ~0ull;
+#pragma unroll
+      for (int q = 0; q < IPL; ++q)
+        if (((act >> q) & 1u) && b[q] > B0 && v[q] < mn) mn = v[q];
+      a1 = wave_min_u64(mn);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// order-preserving image that keeps -0 apart from +0 (invertible); NaN sorts last
+__device__ __forceinline__ unsigned long long dkey_raw(double x) {
+  if (x != x) return ~0ull;
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ double dkey_inv(unsigned long long key) {
+  const unsigned long long u = (key >> 63) ? (key ^ 0x8000000000000000ull) : ~key;
+  return __longlong_as_double((long long)u);
+}
+
+// One wave per (row, group of 4 samples), straight from X.
+template <int IPL>
+__global__ __launch_bounds__(NT) void k_null_ratios_direct(
+    const double *__restrict__ Xs, const int32_t *__restrict__ sids, int64_t B,
+    const int32_t *__restrict__ idx, int64_t row_begin, int64_t n_rows, int k, int n_ids,
+    double *__restrict__ out) {
+  constexpr int SG = 4;
+  const int lane = wcx::lane_id();
+  const int wave = threadIdx.x >> 6;
+  __shared__ int s_hist[NT / 64][64];
+  __shared__ unsigned long long s_slots[NT / 64][64];
+  const int64_t r = (int64_t)blockIdx.x * (NT / 64) + wave;
+  if (r >= n_rows) return;
+  const int sg = blockIdx.y;
+  const double *xs[SG];
+#pragma unroll
+  for (int s = 0; s < SG; ++s) {
+    const int m = sg * SG + s;
+    xs[s] = Xs + (int64_t)sids[m < n_ids ? m : 0] * B;
+  }
+  unsigned long long v[SG][IPL];
+  unsigned int act = 0;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int t = q * 64 + lane;
+    const bool valid = t < k;
+    int64_t c = valid ? (int64_t)idx[r * (int64_t)k + t] : 0;
+    if (c < 0) c += B;  // NumPy negative index
+    act |= valid ? (1u << q) : 0u;
+#pragma unroll
+    for (int s = 0; s < SG; ++s) v[s][q] = dkey_raw(xs[s][c]);
+  }
+  double my_med = 0.0;
+#pragma unroll
+  for (int s = 0; s < SG; ++s) {
+    unsigned long long a0, a1, hi;
+    wave_middle_u64<IPL>(v[s], act, k, s_hist[wave], s_slots[wave], a0, a1, hi);
+    double med = (dkey_inv(a0) + dkey_inv(a1)) / 2.0 + 0.0;   // (np.median's mean: a zero median is +0)
+    if (hi == ~0ull) med = __builtin_nan("");              // np.median propagates NaN
+    if (lane == s) my_med = med;
+  }
+  const int m = sg * SG + lane;
+  if (lane < SG && m < n_ids)
+    out[r * (int64_t)n_ids + m] = log2(Xs[(int64_t)sids[m] * B + row_begin + r] / my_med);
+}
+
 // One wave per (row, group of 8 samples).  blockIdx.x (fastest in dispatch order) walks the rows,
 // blockIdx.y the sample groups: at any moment the whole chip gathers from ONE 32*B-byte slab.
 template <int IPL>
@@ -235,7 +408,7 @@ __global__ __launch_bounds__(NT) void k_null_ratios(
   if (lane < 8 && m < n_ids) {
     const double *Vm = V + (int64_t)m * B;
     if (dbg & 16) { my_a0 %= (unsigned int)B; my_a1 %= (unsigned int)B; }
-    double med = (Vm[my_a0] + Vm[my_a1]) / 2.0;
+    double med = (Vm[my_a0] + Vm[my_a1]) / 2.0 + 0.0;   // (np.median's mean: a zero median is +0)
     if ((int64_t)my_hi >= B - n_nan[m]) med = __builtin_nan("");   // np.median propagates NaN
     const double xr = Xs[(int64_t)sids[m] * B + row_begin + r];
     out[r * (int64_t)n_ids + m] = log2(xr / med);
@@ -367,6 +540,27 @@ __global__ __launch_bounds__(256) void k_null_dummy(const double *__restrict__ X
   out[r * n_ids + m] = log2(x[row_begin + r] / x[0]);
 }
 
+// Ranking costs ~0.37 ns per (null sample, bin) whatever the number of target rows; the direct
+// selection ~? ns per (null sample, target row): with few target rows -- the chrX / chrY rows of a
+// gonosomal pass, a rank's shard of an 8-GPU build -- ranking does not pay.  WCX_NR_DIRECT_RATIO
+// overrides the B / rows ratio from which the direct kernel is used (0 = never).
+bool wcx_null_ratios_direct_pays(int64_t B, int64_t n_rows) {
+  static const int ratio = [] {
+    const char *e = getenv("WCX_NR_DIRECT_RATIO");
+    return e && *e ? atoi(e) : 4;
+  }();
+  return ratio > 0 && n_rows * ratio <= B;
+}
+
+// The search knows how many rows it really searches: if they are few, the ranking announced by
+// wcx_null_rank_prepare_dev is dropped before it starts (wcx_null_ratios_dev then selects directly).
+void wcx_aux_cancel_if_few_rows(wcx_ctx *ctx, int64_t B, int64_t n_rows) {
+  if (ctx->rank_pending && wcx_null_ratios_direct_pays(B, n_rows)) {
+    ctx->rank_pending = false;
+    ctx->rank_X = nullptr;
+  }
+}
+
 // Starts the pending ranking on the auxiliary stream, behind the main stream's current position.
 // The search calls this between its sweep and its refine (see wcx_topk_screen_launch for the
 // measurements behind that choice); wcx_null_ratios_dev calls it as a catch-all.
@@ -412,6 +606,35 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                         std::equal(ctx->rank_ids.begin(), ctx->rank_ids.end(), sample_ids);
   rc = wcx_timer_begin(ctx, "null_ratios");
   if (rc) return rc;
+  if (!prepared && wcx_null_ratios_direct_pays(B, n_rows)) {
+    // few rows: select on the doubles themselves, no ranking of the n_ids x B matrix
+    ctx->rank_pending = false;
+    void *scr = nullptr;
+    rc = wcx_scratch(ctx, (size_t)n_ids * 4 + 256, &scr);
+    if (rc) return rc;
+    int32_t *d_sids = reinterpret_cast<int32_t *>(scr);
+    rc = wcx_upload_small(ctx, d_sids, sample_ids, (size_t)n_ids * 4);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)((n_ids + 3) / 4));
+#define WCX_NRD_LAUNCH(IPL)                                                                       \
+  k_null_ratios_direct<IPL><<<grid, NT, 0, st>>>(dXs, d_sids, B, d_idx, row_begin, n_rows, k, n_ids, d_out)
+    const int ipl = (k + 63) / 64;
+    if (ipl <= 1) WCX_NRD_LAUNCH(1);
+    else if (ipl <= 2) WCX_NRD_LAUNCH(2);
+    else if (ipl <= 3) WCX_NRD_LAUNCH(3);
+    else if (ipl <= 4) WCX_NRD_LAUNCH(4);
+    else if (ipl <= 5) WCX_NRD_LAUNCH(5);
+    else if (ipl <= 6) WCX_NRD_LAUNCH(6);
+    else if (ipl <= 8) WCX_NRD_LAUNCH(8);
+    else if (ipl <= 16) WCX_NRD_LAUNCH(16);
+    else {
+      wcx_set_error("refsize %d too large for the direct null-ratio kernel (max 1024)", k);
+      return WCX_ERR_UNSUPPORTED;
+    }
+#undef WCX_NRD_LAUNCH
+    WCX_HIP(hipGetLastError());
+    return wcx_timer_end(ctx, "null_ratios");
+  }
   if (prepared) {          // ranked ahead on the auxiliary stream (wcx_null_rank_prepare_dev)
     rc = wcx_aux_kick(ctx);
     if (rc) return rc;

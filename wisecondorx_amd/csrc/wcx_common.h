@@ -118,6 +118,8 @@ constexpr int WCX_REDO_FAST = 128;  // flagged rows that take the device-wide re
 size_t wcx_topk_redo_scratch_bytes(int k, int64_t B);
 int wcx_host_scratch(wcx_ctx *ctx, size_t bytes, void **out);
 int wcx_aux_kick(wcx_ctx *ctx);   // null_ratios.hip: start pending auxiliary-stream work
+bool wcx_null_ratios_direct_pays(int64_t B, int64_t n_rows);
+void wcx_aux_cancel_if_few_rows(wcx_ctx *ctx, int64_t B, int64_t n_rows);
 int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                                const TopkBlock *d_blocks, const unsigned int *d_count,
                                const TopkBlock *d_tiles, const unsigned int *d_ntiles,
