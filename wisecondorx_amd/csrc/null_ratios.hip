@@ -540,14 +540,18 @@ __global__ __launch_bounds__(256) void k_null_dummy(const double *__restrict__ X
   out[r * n_ids + m] = log2(x[row_begin + r] / x[0]);
 }
 
-// Ranking costs ~0.37 ns per (null sample, bin) whatever the number of target rows; the direct
-// selection ~? ns per (null sample, target row): with few target rows -- the chrX / chrY rows of a
-// gonosomal pass, a rank's shard of an 8-GPU build -- ranking does not pay.  WCX_NR_DIRECT_RATIO
-// overrides the B / rows ratio from which the direct kernel is used (0 = never).
+// Ranking costs ~0.37 ns per (null sample, bin) whatever the number of target rows -- but mostly
+// hidden beside the refine on the auxiliary stream; the direct selection ~1.0 ns per (null sample,
+// target row) on the main stream.  Measured at 15 kb (scripts/sweep_shard_nr.sh, scripts/
+// sweep_gonosomal.sh): the chrX / chrY rows of a gonosomal pass (B / rows = 16-20): F search + null
+// ratios 6.5 -> 5.7 ms, M 7.5 -> 6.9 ms with the direct kernel; a rank's shard of an 8-GPU build
+// (B / rows = 8): 14.7 vs 14.3 ms (S = 500), 7.6 vs 7.8 ms (S = 100) -- a wash; of a 4-GPU build:
+// 20.4 vs 22.1 ms -- worse.  Hence direct from B / rows >= 12 (WCX_NR_DIRECT_RATIO overrides;
+// 0 = never).
 bool wcx_null_ratios_direct_pays(int64_t B, int64_t n_rows) {
   static const int ratio = [] {
     const char *e = getenv("WCX_NR_DIRECT_RATIO");
-    return e && *e ? atoi(e) : 4;
+    return e && *e ? atoi(e) : 12;
   }();
   return ratio > 0 && n_rows * ratio <= B;
 }
