@@ -117,7 +117,9 @@ int wcx_pca_end(wcx_ctx *ctx);
  *   wcx_prep_mask_dev         replaces newref_tools.get_mask (newref_tools.py:77-102): counts /
  *                             per-sample total, summed per bin over the selected samples, mask =
  *                             sum > 5 % of the median of the positive sums -> mask_out uint8[n_bins]
- *                             (host).
+ *                             (host); the per-bin sums are formed in NumPy's pairwise order, so the
+ *                             threshold decision sees the bits the reference's np.sum produces;
+ *                             sum_per_bin_out double[n_bins] (host, may be NULL) returns them.
  *   wcx_pca_begin_counts_dev  replaces newref_tools.normalize_and_mask (newref_tools.py:110-129) +
  *                             wcx_pca_begin: counts of bins pos[0..B) (host int32: the kept bins of
  *                             the pass, all < n_bins_pass) divided by the sample's total over bins
@@ -128,7 +130,7 @@ int wcx_pca_end(wcx_ctx *ctx);
  *                             wcx_null_ratios_dev without a host round trip.  Valid until the next
  *                             wcx_pca_begin* / wcx_pca_end on this context. */
 int wcx_prep_mask_dev(wcx_ctx *ctx, const int32_t *d_counts, int64_t n_bins, const int32_t *sel, int ns,
-                      unsigned char *mask_out);
+                      unsigned char *mask_out, double *sum_per_bin_out);
 int wcx_pca_begin_counts_dev(wcx_ctx *ctx, const int32_t *d_counts, int64_t n_bins, const int32_t *sel,
                              int ns, int64_t n_bins_pass, const int32_t *pos, int64_t B, double *mean_out,
                              double *gram_out);

@@ -31,7 +31,11 @@ def test_mask_on_device_equals_host():
     try:
         for sel in (np.arange(len(samples)), np.flatnonzero(g == "F"), np.flatnonzero(g == "M")):
             mh, bh = prep.get_mask(samples[sel])
-            md, bd = dc.get_mask(sel)
+            md, bd, sums = dc.get_mask(sel, want_sums=True)
+            # the per-bin sums carry NumPy's own (pairwise) summation order: same bits as the host's
+            stacked = np.concatenate(prep._stack(samples[sel], range(1, 25)), axis=0)
+            host_sums = np.sum(stacked / np.sum(stacked, 0), 1)
+            off_s = np.concatenate(([0], np.cumsum([a.shape[0] for a in prep._stack(samples[sel], range(1, 25))])))
             # (a subset's own longest chromosome may be shorter than the cohort's: the device mask
             # is laid out over the cohort's bins, the extra bins hold zeros -> masked out)
             assert bd == dc.bins_per_chr and sum(bd) >= sum(bh)
@@ -41,6 +45,7 @@ def test_mask_on_device_equals_host():
                 n = bh[c]
                 assert np.array_equal(md[off_d[c]:off_d[c] + n], mh[off_h[c]:off_h[c + 1]]), c
                 assert not md[off_d[c] + n:off_d[c + 1]].any()
+                assert np.array_equal(sums[off_d[c]:off_d[c] + n], host_sums[off_s[c]:off_s[c + 1]]), c
             assert md.sum() > 100
     finally:
         dc.close()

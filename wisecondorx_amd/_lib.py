@@ -40,7 +40,7 @@ SIGNATURES = {
     "wcx_pca_begin": (C.c_int, [vp, vp, c_i64, C.c_int, vp, vp]),
     "wcx_pca_finish": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
     "wcx_pca_end": (C.c_int, [vp]),
-    "wcx_prep_mask_dev": (C.c_int, [vp, vp, c_i64, vp, C.c_int, vp]),
+    "wcx_prep_mask_dev": (C.c_int, [vp, vp, c_i64, vp, C.c_int, vp, vp]),
     "wcx_pca_begin_counts_dev": (C.c_int, [vp, vp, c_i64, vp, C.c_int, c_i64, vp, c_i64, vp, vp]),
     "wcx_pca_corrected_dev": (C.c_int, [vp, C.POINTER(vp)]),
     "wcx_newref_topk": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64p, C.c_int, c_i64, c_i64,

@@ -31,16 +31,78 @@ __global__ __launch_bounds__(1024) void k_counts_total(const int32_t *__restrict
   }
 }
 
-// sum_per_bin[b] = sum over the selected samples (in selection order) of counts[s][b] / total[s];
-// pos[b] = the same where positive, else NaN (for the median of the covered bins)
+// NumPy's pairwise summation of n terms term(lo) .. term(lo + n - 1), as np.sum runs it along a
+// contiguous axis (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum): fewer than 8 terms in
+// sequence; up to 128 terms in 8 interleaved accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+
+// (r6+r7)) plus the remainder in sequence; longer ranges split at n/2 rounded down to a multiple of 8.
+// The recursion is unrolled with a small explicit stack (depth <= log2(n / 128) + 1).
+template <typename F>
+__device__ double numpy_pairwise_sum(F term, int n) {
+  int lo_stack[16], n_stack[16];
+  double acc_stack[16];                 // value of the left half while the right one is summed
+  int state[16];                        // 0 = to do, 1 = left done (right pending), 2 = both done
+  int sp = 0;
+  lo_stack[0] = 0; n_stack[0] = n; state[0] = 0; acc_stack[0] = 0.0;
+  double ret = 0.0;
+  while (sp >= 0) {
+    const int lo = lo_stack[sp], m = n_stack[sp];
+    if (m <= 128) {
+      double res;
+      if (m < 8) {
+        res = 0.0;
+        for (int i = 0; i < m; ++i) res += term(lo + i);
+      } else {
+        double r0 = term(lo), r1 = term(lo + 1), r2 = term(lo + 2), r3 = term(lo + 3), r4 = term(lo + 4),
+               r5 = term(lo + 5), r6 = term(lo + 6), r7 = term(lo + 7);
+        int i = 8;
+        for (; i < m - (m % 8); i += 8) {
+          r0 += term(lo + i); r1 += term(lo + i + 1); r2 += term(lo + i + 2); r3 += term(lo + i + 3);
+          r4 += term(lo + i + 4); r5 += term(lo + i + 5); r6 += term(lo + i + 6); r7 += term(lo + i + 7);
+        }
+        res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < m; ++i) res += term(lo + i);
+      }
+      ret = res;
+      --sp;
+    } else if (state[sp] == 0) {
+      int n2 = m / 2;
+      n2 -= n2 % 8;
+      state[sp] = 1;
+      ++sp;
+      lo_stack[sp] = lo; n_stack[sp] = n2; state[sp] = 0;
+      continue;
+    }
+    // a child has just returned `ret` to the frame now on top
+    while (sp >= 0 && n_stack[sp] > 128) {
+      const int lo2 = lo_stack[sp], m2 = n_stack[sp];
+      int n2 = m2 / 2;
+      n2 -= n2 % 8;
+      if (state[sp] == 1) {             // left half done: start the right half
+        acc_stack[sp] = ret;
+        state[sp] = 2;
+        ++sp;
+        lo_stack[sp] = lo2 + n2; n_stack[sp] = m2 - n2; state[sp] = 0;
+        break;
+      }
+      ret = acc_stack[sp] + ret;        // both halves done
+      --sp;
+    }
+  }
+  return ret;
+}
+
+// sum_per_bin[b] = np.sum over the selected samples of counts[s][b] / total[s] -- in NumPy's own
+// summation order (the reduction runs along the contiguous sample axis of the (bins x samples) matrix,
+// newref_tools.py:97), starting from +0.0 like np.add.reduce; pos[b] = the same where positive, else
+// NaN (for the median of the covered bins)
 __global__ __launch_bounds__(256) void k_mask_colsum(const int32_t *__restrict__ counts, int64_t n_bins,
                                                      const int32_t *__restrict__ sel, int ns,
                                                      const double *__restrict__ total,
                                                      double *__restrict__ colsum, double *__restrict__ pos) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= n_bins) return;
-  double s = 0.0;
-  for (int q = 0; q < ns; ++q) s += (double)counts[(int64_t)sel[q] * n_bins + b] / total[q];
+  const double s = 0.0 + numpy_pairwise_sum(
+      [&](int q) { return (double)counts[(int64_t)sel[q] * n_bins + b] / total[q]; }, ns);
   colsum[b] = s;
   pos[b] = s > 0.0 ? s : __builtin_nan("");
 }
@@ -74,7 +136,7 @@ int wcx_pca_gram_from_dt(wcx_ctx *ctx, double *mean_out, double *gram_out);
 extern "C" {
 
 int wcx_prep_mask_dev(wcx_ctx *ctx, const int32_t *d_counts, int64_t n_bins, const int32_t *sel, int ns,
-                      unsigned char *mask_out) {
+                      unsigned char *mask_out, double *sum_per_bin_out) {
   WCX_ARG(ctx && d_counts && sel && mask_out && n_bins > 0 && ns > 0, "bad parameters");
   WCX_HIP(hipSetDevice(ctx->device));
   void *scr = nullptr;
@@ -97,6 +159,8 @@ int wcx_prep_mask_dev(wcx_ctx *ctx, const int32_t *d_counts, int64_t n_bins, con
   k_mask_apply<<<gb, 256, 0, st>>>(d_col, n_bins, d_med, d_mask);
   WCX_HIP(hipGetLastError());
   WCX_HIP(hipMemcpyAsync(mask_out, d_mask, (size_t)n_bins, hipMemcpyDeviceToHost, st));
+  if (sum_per_bin_out)
+    WCX_HIP(hipMemcpyAsync(sum_per_bin_out, d_col, (size_t)n_bins * 8, hipMemcpyDeviceToHost, st));
   WCX_HIP(hipStreamSynchronize(st));
   return WCX_OK;
 }

@@ -185,14 +185,17 @@ class DeviceCounts:
             self.ctx.lib.wcx_free(self.ctx.h, self.d)
         self.d = None
 
-    def get_mask(self, sel=None):
-        """get_mask (newref_tools.py:77-102) of the samples `sel` (default: all) on the device."""
+    def get_mask(self, sel=None, want_sums=False):
+        """get_mask (newref_tools.py:77-102) of the samples `sel` (default: all) on the device.
+        want_sums: also return the per-bin coverage sums the threshold was applied to."""
         from . import _lib
         sel, sel_p = _lib.i32_array(range(self.S) if sel is None else sel)
         mask = np.empty(self.n_bins, dtype=np.uint8)
+        sums = np.empty(self.n_bins) if want_sums else None
         _lib.check(self.ctx.lib.wcx_prep_mask_dev(self.ctx.h, self.d, self.n_bins, sel_p, len(sel),
-                                                  _lib.ptr(mask)))
-        return mask.astype(bool), list(self.bins_per_chr)
+                                                  _lib.ptr(mask), _lib.ptr(sums)))
+        out = (mask.astype(bool), list(self.bins_per_chr))
+        return out + (sums,) if want_sums else out
 
     def pca_begin(self, sel, last_chr, mask):
         """normalize_and_mask of the pass (chromosomes 1..last_chr, kept bins of `mask`) written into
