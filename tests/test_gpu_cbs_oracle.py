@@ -90,6 +90,11 @@ def _cases():
         big = () if i % 3 else (int(rng.integers(6000, 17000)),)
         out.append((100 + i, alpha, _sizes(rng, big), 15000 if i % 2 else 100000, 5 + i))
     out.append((200, 1e-4, _sizes(rng, (20000, 40000)), 5000, 1))   # beyond the LDS capacity
+    # WCX_CBS_FUZZ_EXTRA=N: N more cases with fresh seeds (a longer hunt, not part of the default suite)
+    for i in range(int(os.environ.get("WCX_CBS_FUZZ_EXTRA", "0"))):
+        big = (int(rng.integers(5000, 12000)),) if i % 5 == 0 else ()
+        out.append((1000 + i, [1e-4, 1e-3, 1e-2][i % 3], _sizes(rng, big), 15000 if i % 2 else 100000,
+                    50 + i))
     return out
 
 
