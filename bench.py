@@ -316,7 +316,9 @@ class Workload:
                  "attainable_note": "the dense-f16 peak is not attainable on random data: a bare "
                                     "LDS-fed MFMA loop with DMA staging and no epilogue is power-limited "
                                     "to 1.1-1.35 PFLOP/s on this chip, box to box (1.9-2.0 on all-zero "
-                                    "operands; profiles/r02/ubench_mfma.txt)"}
+                                    "operands; profiles/r02/ubench_mfma.txt); the vendor's plain fp16 GEMM "
+                                    "(torch.matmul -> hipBLASLt) sustains 1.24-1.31 PFLOP/s on random data on "
+                                    "the same boxes (profiles/r03/gemm_calibration.json)"}
             if any(stats["phase_cycles"]):          # only with --debug-flags 4
                 r["phase_cycles"] = stats["phase_cycles"]
         else:
