@@ -335,6 +335,7 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // (newref_tools._split_by_chr + the clamps at newref_tools.py:181-184).
   std::vector<TopkBlock> blocks;
   int64_t pairs = 0, searched = 0;
+  int64_t dummy_lo = row_begin, dummy_hi = row_begin;      // pending run of dummy rows
   for (int c = 0; c < n_chr; ++c) {
     const int64_t cs = c ? chr_cum[c - 1] : 0, ce = chr_cum[c];
     WCX_ARG(ce >= cs, "chr_cum must be non-decreasing");
@@ -342,8 +343,13 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     const int64_t hi = ce < row_end ? ce : row_end;
     if (lo >= hi) continue;
     if (n_chr > 22 && c != 22 && c != 23) {  // newref_tools.py:186-191
-      int rc = wcx_fill_dummy_rows(ctx, d_out_idx, d_out_dist, lo - row_begin, hi - row_begin, k);
-      if (rc) return rc;
+      // (the autosomes are adjacent: their dummy rows are filled by ONE launch, not 22)
+      if (dummy_hi == lo) dummy_hi = hi;
+      else {
+        int rc = wcx_fill_dummy_rows(ctx, d_out_idx, d_out_dist, dummy_lo - row_begin, dummy_hi - row_begin, k);
+        if (rc) return rc;
+        dummy_lo = lo; dummy_hi = hi;
+      }
       continue;
     }
     for (int64_t r = lo; r < hi; r += 64) {
@@ -357,6 +363,10 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     }
     searched += hi - lo;
     pairs += (hi - lo) * (B - (ce - cs));
+  }
+  {
+    int rc = wcx_fill_dummy_rows(ctx, d_out_idx, d_out_dist, dummy_lo - row_begin, dummy_hi - row_begin, k);
+    if (rc) return rc;
   }
   ctx->topk_stats[0] = searched;
   ctx->topk_stats[1] = pairs;
