@@ -95,3 +95,50 @@ def test_prepare_and_search_from_device_counts(gender):
     finally:
         dc.close()
         ctx.lib.wcx_pca_end(ctx.h)
+
+
+@pytest.mark.parametrize("nbytes", [1, 4097, (32 << 20) - 1, 32 << 20, (32 << 20) + 1, (96 << 20) + 12345])
+def test_staged_host_copies_round_trip(nbytes):
+    """wcx_memcpy_h2d / _d2h: from 32 MB on, the copy runs through two pinned halves with host threads
+    moving the other half (api.hip: staged_copy) -- every byte must arrive, whatever the size's
+    relation to the 32 MB chunk and to the threads' 4 KB-aligned pieces."""
+    import ctypes as C
+    from wisecondorx_amd import _lib
+    ctx = _lib.default_context(0)
+    rng = np.random.default_rng(nbytes % 1000)
+    src = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    dst = np.zeros(nbytes + 64, dtype=np.uint8)                     # (guard bytes after the end)
+    d = C.c_void_p()
+    _lib.check(ctx.lib.wcx_malloc(ctx.h, nbytes, C.byref(d)))
+    try:
+        _lib.check(ctx.lib.wcx_memcpy_h2d(ctx.h, d, _lib.ptr(src), nbytes))
+        _lib.check(ctx.lib.wcx_memcpy_d2h(ctx.h, _lib.ptr(dst), d, nbytes))
+    finally:
+        ctx.lib.wcx_free(ctx.h, d)
+    assert np.array_equal(dst[:nbytes], src) and not dst[nbytes:].any()
+
+
+def test_counts_entry_points_reject_bad_arguments():
+    from wisecondorx_amd import _lib, prep
+    samples, _ = _cohort(12, ragged=False)
+    ctx = _lib.default_context(0)
+    dc = prep.DeviceCounts(ctx, samples)
+    try:
+        mask = np.ones(dc.n_bins, dtype=bool)
+        sel, sel_p = _lib.i32_array([0, 1, 2])
+        pos, pos_p = _lib.i32_array(np.arange(10))
+        mean, gram = np.empty(10), np.empty((3, 3))
+        lib = ctx.lib
+        # more kept bins than the pass has bins; a pass longer than the matrix; one sample only
+        assert lib.wcx_pca_begin_counts_dev(ctx.h, dc.d, dc.n_bins, sel_p, 3, 5, pos_p, 10, _lib.ptr(mean),
+                                            _lib.ptr(gram)) != 0
+        assert lib.wcx_pca_begin_counts_dev(ctx.h, dc.d, dc.n_bins, sel_p, 3, dc.n_bins + 1, pos_p, 10,
+                                            _lib.ptr(mean), _lib.ptr(gram)) != 0
+        assert lib.wcx_pca_begin_counts_dev(ctx.h, dc.d, dc.n_bins, sel_p, 1, dc.n_bins, pos_p, 10,
+                                            _lib.ptr(mean), _lib.ptr(gram)) != 0
+        assert b"bad sizes" in lib.wcx_last_error()
+        out = np.empty(dc.n_bins, dtype=np.uint8)
+        assert lib.wcx_prep_mask_dev(ctx.h, dc.d, dc.n_bins, sel_p, 0, _lib.ptr(out), None) != 0
+        assert mask.all()
+    finally:
+        dc.close()

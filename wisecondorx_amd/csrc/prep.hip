@@ -171,6 +171,9 @@ int wcx_pca_begin_counts_dev(wcx_ctx *ctx, const int32_t *d_counts, int64_t n_bi
   WCX_ARG(ctx && d_counts && sel && pos && mean_out && gram_out, "NULL argument");
   WCX_ARG(n_bins > 0 && ns > 1 && ns <= 4096 && n_bins_pass > 0 && n_bins_pass <= n_bins && B > 0 && B <= n_bins_pass,
           "bad sizes");
+  for (int64_t i = 0; i < B; ++i)
+    WCX_ARG(pos[i] >= 0 && pos[i] < n_bins_pass, "kept-bin position outside the pass");
+  for (int q = 0; q < ns; ++q) WCX_ARG(sel[q] >= 0, "negative sample index");
   WCX_HIP(hipSetDevice(ctx->device));
   double *dt = nullptr;
   int rc = wcx_pca_alloc(ctx, B, ns, &dt);
