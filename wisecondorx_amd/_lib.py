@@ -167,8 +167,30 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            self.release_buffers()
             self.lib.wcx_ctx_destroy(self.h)
             self.h = None
+
+    def buffers(self, sizes):
+        """Device buffers kept between calls (grow-only; newref's three passes hand their result tables
+        back through the same ones: a fresh hipMalloc of 0.8 GB after a hipFree costs ~60 ms).
+        Returns one raw device pointer (int) per requested size."""
+        keep = self.__dict__.setdefault("_buffers", [])
+        while len(keep) < len(sizes):
+            keep.append([vp(), 0])
+        for slot, n in zip(keep, sizes):
+            if slot[1] < n:
+                if slot[0].value:
+                    check(self.lib.wcx_free(self.h, slot[0]))
+                    slot[0], slot[1] = vp(), 0
+                check(self.lib.wcx_malloc(self.h, max(int(n), 8), C.byref(slot[0])))
+                slot[1] = int(n)
+        return [slot[0].value for slot in keep[:len(sizes)]]
+
+    def release_buffers(self):
+        for slot in self.__dict__.pop("_buffers", []):
+            if slot[0].value and getattr(self, "h", None):
+                self.lib.wcx_free(self.h, slot[0])
 
     def __del__(self):
         try:

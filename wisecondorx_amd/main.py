@@ -197,6 +197,7 @@ def tool_newref(args):
     if dc is not None:
         dc.close()
         contexts[0].lib.wcx_pca_end(contexts[0].h)
+        contexts[0].release_buffers()
     final_ref["is_nipt"] = args.nipt
     final_ref["trained_cutoff"] = trained_cutoff
     n_aut = int(np.sum(final_ref["bins_per_chr"]))

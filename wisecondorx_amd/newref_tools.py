@@ -151,7 +151,6 @@ def get_reference_dev(ctx, n_samples, masked_bins_per_chr_cum, ref_size, sample_
     idx = np.empty((B, k), dtype=np.int32)
     dist = np.empty((B, k), dtype=np.float64)
     nr = np.empty((B, m), dtype=np.float64)
-    bufs = [C.c_void_p() for _ in range(3)]
     # the result tables are 0.8 GB of fresh host pages at 15 kb: worker threads touch them (page
     # faults, the expensive part of a device -> pageable-host copy) while the device searches
     from concurrent.futures import ThreadPoolExecutor
@@ -162,9 +161,7 @@ def get_reference_dev(ctx, n_samples, masked_bins_per_chr_cum, ref_size, sample_
         flat = a.reshape(-1).view(np.uint8)
         touched += [ex.submit(flat[o:o + (32 << 20)].fill, 0) for o in range(0, flat.size, 32 << 20)]
     try:
-        for b, a in zip(bufs, (idx, dist, nr)):
-            _lib.check(lib.wcx_malloc(ctx.h, max(a.nbytes, 8), C.byref(b)))
-        d_idx, d_dist, d_nr = (b.value for b in bufs)
+        d_idx, d_dist, d_nr = ctx.buffers([idx.nbytes, dist.nbytes, nr.nbytes])   # kept between passes
         ct = int(cum[21]) if len(cum) > 22 else 0
         if ct < B:
             _lib.check(lib.wcx_null_rank_prepare_dev(ctx.h, dX, B, S, ids_p, m))
@@ -177,12 +174,9 @@ def get_reference_dev(ctx, n_samples, masked_bins_per_chr_cum, ref_size, sample_
                                                d_nr + ct * m * 8))
         for f in touched:
             f.result()
-        for b, a in zip(bufs, (idx, dist, nr)):
+        for b, a in zip((d_idx, d_dist, d_nr), (idx, dist, nr)):
             if a.nbytes:
                 _lib.check(lib.wcx_memcpy_d2h(ctx.h, _lib.ptr(a), b, a.nbytes))
     finally:
         ex.shutdown(wait=True)
-        for b in bufs:
-            if b.value:
-                lib.wcx_free(ctx.h, b)
     return idx, dist, nr
