@@ -214,6 +214,8 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
   }
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
+  for (auto &sl : ctx->sel_pool)
+    if (sl.p) hipFree(sl.p);
   if (ctx->host_scratch2) hipHostFree(ctx->host_scratch2);
   if (ctx->scratch2) hipFree(ctx->scratch2);
   if (ctx->d_stats) hipFree(ctx->d_stats);

@@ -744,6 +744,8 @@ __global__ __launch_bounds__(256) void k_post_merge(
 
 }  // namespace
 
+void wcx_ref_release_sel(wcx_ctx *ctx, wcx_ref *ref);   // defined next to ensure_sel below
+
 extern "C" {
 
 int wcx_ref_wrap_dev(wcx_ctx *ctx, const int32_t *d_idx, const double *d_dist, int64_t B, int k,
@@ -787,9 +789,10 @@ int wcx_ref_upload(wcx_ctx *ctx, const int32_t *idx, const double *dist, int64_t
 
 int wcx_ref_free(wcx_ctx *ctx, wcx_ref *ref) {
   if (!ref) return WCX_OK;
-  if (ctx) hipStreamSynchronize(ctx->stream);
-  if (ref->d_sel) hipFree(ref->d_sel);
+  if (ctx) wcx_ref_release_sel(ctx, ref);         // back to the context's pool: no free, no sync
+  else if (ref->d_sel) hipFree(ref->d_sel);       // (no context: the pool cannot be told)
   if (ref->owned) {
+    if (ctx) hipStreamSynchronize(ctx->stream);
     hipFree(const_cast<int32_t *>(ref->d_idx));
     hipFree(const_cast<double *>(ref->d_dist));
   }
@@ -951,16 +954,38 @@ int ipl_for(int k) {
   return ipl;
 }
 
-// selection mask of the reference's rows (kept in the handle: it outlives the scratch buffers)
+void sel_release(wcx_ctx *ctx, wcx_ref *ref) {
+  if (!ref->d_sel) return;
+  for (auto &sl : ctx->sel_pool)
+    if (sl.p == ref->d_sel) sl.used = false;
+  ref->d_sel = nullptr;
+  ref->sel_bytes = 0;
+}
+
+// selection mask of the reference's rows (lent to the handle: it outlives the scratch buffers)
 int ensure_sel(wcx_ctx *ctx, wcx_ref *ref, int ipl) {
   const size_t need = (size_t)ref->nrows * ipl * 8;
   if (ref->d_sel && ref->sel_bytes >= need) return WCX_OK;
-  if (ref->d_sel) { WCX_HIP(hipStreamSynchronize(ctx->stream)); WCX_HIP(hipFree(ref->d_sel)); ref->d_sel = nullptr; }
-  if (hipMalloc(reinterpret_cast<void **>(&ref->d_sel), need ? need : 8) != hipSuccess) {
-    wcx_set_error("hipMalloc(%zu) for the selection mask failed", need);
-    return WCX_ERR_NOMEM;
+  sel_release(ctx, ref);
+  // the context's pool: the smallest free buffer that fits, else a new one (all work on a context is
+  // ordered on its stream, so a buffer handed from one handle to the next needs no synchronisation)
+  int best = -1;
+  for (size_t i = 0; i < ctx->sel_pool.size(); ++i) {
+    const auto &sl = ctx->sel_pool[i];
+    if (!sl.used && sl.bytes >= need && (best < 0 || sl.bytes < ctx->sel_pool[best].bytes)) best = (int)i;
   }
-  ref->sel_bytes = need;
+  if (best < 0) {
+    wcx_ctx::SelSlot sl{nullptr, need ? need : 8, false};
+    if (hipMalloc(&sl.p, sl.bytes) != hipSuccess) {
+      wcx_set_error("hipMalloc(%zu) for the selection mask failed", need);
+      return WCX_ERR_NOMEM;
+    }
+    ctx->sel_pool.push_back(sl);
+    best = (int)ctx->sel_pool.size() - 1;
+  }
+  ctx->sel_pool[best].used = true;
+  ref->d_sel = reinterpret_cast<unsigned long long *>(ctx->sel_pool[best].p);
+  ref->sel_bytes = ctx->sel_pool[best].bytes;
   return WCX_OK;
 }
 
@@ -1048,6 +1073,8 @@ int launch_select_mask(wcx_ctx *ctx, wcx_ref *ref, double cutoff, int64_t ct) {
 }
 
 }  // namespace
+
+void wcx_ref_release_sel(wcx_ctx *ctx, wcx_ref *ref) { sel_release(ctx, ref); }
 
 extern "C" {
 

@@ -72,6 +72,10 @@ struct wcx_ctx {
   const double *rank_X = nullptr;
   int64_t rank_B = 0;
   std::vector<int32_t> rank_ids;
+  // selection masks of reference handles (predict): buffers are lent to a handle and taken back by
+  // wcx_ref_free WITHOUT a hipFree -- a free synchronises the device in the middle of every predict
+  struct SelSlot { void *p; size_t bytes; bool used; };
+  std::vector<SelSlot> sel_pool;
   bool rank_pending = false;   // ranking requested, not yet started (wcx_aux_kick)
   // PCA stage (wcx_pca_begin .. wcx_pca_end): t | X | mean | components | dist_to_med
   void *d_pca = nullptr;
