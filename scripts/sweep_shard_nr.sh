@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/shard
 for S in 500 100; do
-for ratio in 0 4; do
+for ratio in 0 2 4 8; do
   WCX_NR_DIRECT_RATIO=$ratio timeout 400 python scripts/bench_shard.py $S > gpurun_out/shard/S${S}_r$ratio.json 2> gpurun_out/shard/S${S}_r$ratio.err
   python - <<PY
 import json

@@ -229,8 +229,8 @@ def test_null_ratios_nan_duplicates_and_ties(nt):
         onr = O.null_ratios(X, idx, 0, B, ids)
     np.testing.assert_allclose(nr, onr, rtol=1e-12, atol=1e-13, equal_nan=True)
     assert np.isnan(nr[0, 3]) and not np.isnan(nr[0, 2])
-    # few target rows (rows x 12 <= bins): the direct kernel selects on the doubles themselves instead
-    # of ranking every bin of every null sample first -- same bits as the rank path
+    # few target rows (rows x 4 <= bins): selection on the high halves of the values' keys, settled on
+    # the full doubles -- no ranking of every bin of every null sample; same bits as the rank path
     few = nt.get_null_ratios(X, idx[:50], 0, 50, ids)
     assert np.array_equal(few, nr[:50], equal_nan=True)
     X[5, :] = -0.0
@@ -244,8 +244,9 @@ def test_null_ratios_nan_duplicates_and_ties(nt):
 
 def test_null_ratios_direct_kernel_equals_rank_path(nt):
     """Both selection paths on a realistic shape (k = 300, 100 null samples): the rows of a small
-    shard (direct kernel: 64-bit keys of the doubles, bucket selection) against the same rows taken
-    from the whole-matrix call (rank path) -- identical bits; and against the oracle."""
+    shard (high-key kernel: bucket selection on hi32 of the values' keys, ties settled on the doubles)
+    against the same rows taken from the whole-matrix call (rank path) -- identical bits; and against
+    the oracle."""
     from wisecondorx_amd.synth import corrected_matrix
     X, mbpc, cum = corrected_matrix([2600, 2400, 2200, 2000, 1800], 120, seed=23)
     X = np.array(X, order="F")

@@ -185,154 +185,105 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
   }
 }
 
-// ---- the same selection on 64-bit keys (order-preserving images of the doubles themselves) --------
-// For a FEW target rows -- the chrX / chrY rows of a gonosomal pass, one rank's shard of a multi-GPU
-// build -- ranking every bin of every null sample first (two radix sorts over n_ids * B elements:
-// 6.7 ms of device work at 15 kb) costs more than it saves: the direct kernel below gathers the
-// doubles, maps them to dkey() and selects the two middle keys of each (row, sample) with the
-// bucket scheme of wave_middle_u32.  Same bits as the rank path (a zero median is +0 on both, as
-// np.median's mean makes it).
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)v, o, 64);
-    const unsigned int hi = (unsigned int)__shfl_xor((int)(unsigned int)(v >> 32), o, 64);
-    const unsigned long long p = ((unsigned long long)hi << 32) | lo;
-    v = p < v ? p : v;
-  }
-  return v;
-}
-
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
   const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
   const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
   return ((unsigned long long)hi << 32) | lo;
 }
 
-template <int IPL>
-__device__ __forceinline__ unsigned long long select_u64_bisect(const unsigned long long (&v)[IPL],
-                                                                unsigned int act, int rank) {
-  unsigned long long prefix = 0;
-  for (int bit = 63; bit >= 0; --bit) {
-    const unsigned long long trial = prefix | (1ull << bit);
-    int c = 0;
-#pragma unroll
-    for (int q = 0; q < IPL; ++q) c += __popcll(__ballot(((act >> q) & 1u) && v[q] < trial));
-    if (c <= rank) prefix = trial;
-  }
-  return prefix;
-}
-
-// hist: int[64], slots: u64[64], wave-private LDS
-template <int IPL>
-__device__ __forceinline__ void wave_middle_u64(const unsigned long long (&v)[IPL], unsigned int act,
-                                                int n, int *hist, unsigned long long *slots,
-                                                unsigned long long &a0, unsigned long long &a1,
-                                                unsigned long long &hi_out) {
-  const int lane = wcx::lane_id();
-  const int r0 = (n - 1) >> 1, r1 = n >> 1;
-  unsigned long long lo = ~0ull, nhi = ~0ull;
-#pragma unroll
-  for (int q = 0; q < IPL; ++q)
-    if ((act >> q) & 1u) { lo = v[q] < lo ? v[q] : lo; nhi = ~v[q] < nhi ? ~v[q] : nhi; }
-  lo = wave_min_u64(lo);
-  const unsigned long long hi = ~wave_min_u64(nhi);
-  hi_out = hi;
-  if (hi == lo) { a0 = lo; a1 = lo; return; }
-  // (float of a u64 difference is monotone; 1.0000002f keeps bucket(hi) <= 63 after rounding)
-  const float scale = 64.0f / ((float)(hi - lo) * 1.0000002f + 1.0f);
-  hist[lane] = 0;
-  __builtin_amdgcn_wave_barrier();
-  int b[IPL];
-#pragma unroll
-  for (int q = 0; q < IPL; ++q) {
-    b[q] = 0;
-    if ((act >> q) & 1u) {
-      int bb = (int)((float)(v[q] - lo) * scale);          // monotone in v
-      bb = bb > 63 ? 63 : bb;
-      b[q] = bb;
-      atomicAdd(&hist[bb], 1);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int h = hist[lane];
-  const int cum = wcx::wave_incl_scan_i(h);
-  const unsigned long long gt = __ballot(cum > r0);
-  const int B0 = __ffsll((long long)gt) - 1;
-  const int before = B0 > 0 ? __builtin_amdgcn_readlane(cum, B0 - 1) : 0;
-  const int need = r0 - before;
-  const int cB = __builtin_amdgcn_readlane(h, B0);
-  if (cB > 64) {
-    a0 = select_u64_bisect<IPL>(v, act, r0);
-    a1 = r1 == r0 ? a0 : select_u64_bisect<IPL>(v, act, r1);
-    return;
-  }
-  int base = 0;
-#pragma unroll
-  for (int q = 0; q < IPL; ++q) {
-    const bool m = ((act >> q) & 1u) && b[q] == B0;
-    const unsigned long long mm = __ballot(m);
-    if (m) slots[base + __popcll(mm & ((1ull << lane) - 1ull))] = v[q];
-    base += __popcll(mm);
-  }
-  __builtin_amdgcn_wave_barrier();
-  const unsigned long long w = lane < cB ? slots[lane] : ~0ull;
-  int rk = 0;
-  for (int L = 0; L < cB; ++L) {
-    const unsigned long long p = readlane_u64(w, L);
-    rk += ((p < w) || (p == w && L < lane)) ? 1 : 0;
-  }
-  const unsigned long long hit = __ballot(lane < cB && rk == need);
-  a0 = readlane_u64(w, __ffsll((long long)hit) - 1);
-  a1 = a0;
-  if (r1 != r0) {
-    if (need + 1 < cB) {
-      const unsigned long long hit1 = __ballot(lane < cB && rk == need + 1);
-      a1 = readlane_u64(w, __ffsll((long long)hit1) - 1);
-    } else {
-      unsigned long long mn = ~0ull;
-#pragma unroll
-      for (int q = 0; q < IPL; ++q)
-        if (((act >> q) & 1u) && b[q] > B0 && v[q] < mn) mn = v[q];
-      a1 = wave_min_u64(mn);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-// order-preserving image that keeps -0 apart from +0 (invertible); NaN sorts last
-__device__ __forceinline__ unsigned long long dkey_raw(double x) {
-  if (x != x) return ~0ull;
-  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-
+// inverse of dkey() (for keys of non-NaN values; -0 comes back as +0)
 __device__ __forceinline__ double dkey_inv(unsigned long long key) {
   const unsigned long long u = (key >> 63) ? (key ^ 0x8000000000000000ull) : ~key;
   return __longlong_as_double((long long)u);
 }
 
-// One wave per (row, group of 4 samples), straight from X.
+// ---- FEW target rows: selection on the HIGH HALVES of the values' keys (no ranking at all) -------
+// Ranking every bin of every null sample (two radix sorts over n_ids * B elements: 6.7 ms of device
+// work at 15 kb) is worth it when ~all rows are targets and the sort hides beside the refine; for
+// the chrX / chrY rows of a gonosomal pass or a rank's shard of an 8-GPU build it is not.
+// hi32(dkey(x)) is monotone in x (not strictly): the bucket selection on it finds the 32-bit keys a0,
+// a1 of the two middle order statistics; which ELEMENT carries them is then settled exactly on the
+// full doubles of the (almost always single) candidates that share that high half.  Needs only the
+// key pieces K[group][bin][8] -- one streaming pass over the null samples' rows.  Same bits as the
+// rank path.  54 ns per (row, 100 samples) against 35 ns + the ranking.
+__global__ __launch_bounds__(NT) void k_nr_hikeys(const double *__restrict__ Xs, int64_t B,
+                                                  const int32_t *__restrict__ sids, int n_ids,
+                                                  unsigned int *__restrict__ Kg) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  const int g = blockIdx.y;
+  if (b >= B) return;
+  unsigned int kk[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int m = g * 8 + j;
+    kk[j] = m < n_ids ? (unsigned int)(dkey(Xs[(int64_t)sids[m] * B + b]) >> 32) : 0u;
+  }
+  uint4 *dst = reinterpret_cast<uint4 *>(Kg + ((int64_t)g * B + b) * 8);
+  dst[0] = make_uint4(kk[0], kk[1], kk[2], kk[3]);
+  dst[1] = make_uint4(kk[4], kk[5], kk[6], kk[7]);
+}
+
+// The j-th smallest (0-based) FULL value among the active elements whose high key equals `key`
+// (bins in cc[], sample row x).  cand: int[64] wave-private LDS.
 template <int IPL>
-__global__ __launch_bounds__(NT) void k_null_ratios_direct(
-    const double *__restrict__ Xs, const int32_t *__restrict__ sids, int64_t B,
-    const int32_t *__restrict__ idx, int64_t row_begin, int64_t n_rows, int k, int n_ids,
-    double *__restrict__ out) {
-  constexpr int SG = 4;
+__device__ __forceinline__ double pick_among_ties(const unsigned int (&v)[IPL], const int (&cc)[IPL],
+                                                  unsigned int act, unsigned int key, int j,
+                                                  const double *__restrict__ x, int *cand) {
+  const int lane = wcx::lane_id();
+  int t = 0;
+  unsigned int tied = 0;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const bool m = ((act >> q) & 1u) && v[q] == key;
+    const unsigned long long mm = __ballot(m);
+    const int pos = t + __popcll(mm & ((1ull << lane) - 1ull));
+    if (m && pos < 64) cand[pos] = cc[q];
+    tied |= m ? (1u << q) : 0u;
+    t += __popcll(mm);
+  }
+  __builtin_amdgcn_wave_barrier();
+  double res;
+  if (t == 1) {
+    res = x[cand[0]];                                   // the usual case: one broadcast load
+  } else if (t <= 64) {
+    const double xv = lane < t ? x[cand[lane]] : 0.0;
+    const unsigned long long w = lane < t ? dkey(xv) : ~0ull;
+    int rk = 0;
+    for (int L = 0; L < t; ++L) {
+      const unsigned long long p = readlane_u64(w, L);
+      rk += ((p < w) || (p == w && L < lane)) ? 1 : 0;
+    }
+    const unsigned long long hit = __ballot(lane < t && rk == j);
+    res = dkey_inv(readlane_u64(w, __ffsll((long long)hit) - 1));
+  } else {
+    // more than 64 elements share the high half (an index row that repeats a bin): select on the
+    // low halves of the tied elements
+    unsigned int lo[IPL];
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) lo[q] = ((tied >> q) & 1u) ? (unsigned int)dkey(x[cc[q]]) : 0u;
+    const unsigned int sel = select_u32_bisect<IPL>(lo, tied, j);
+    res = dkey_inv(((unsigned long long)key << 32) | sel);
+  }
+  __builtin_amdgcn_wave_barrier();
+  return res;
+}
+
+template <int IPL>
+__global__ __launch_bounds__(NT) void k_null_ratios_hi(
+    const unsigned int *__restrict__ Kg, const double *__restrict__ Xs,
+    const int32_t *__restrict__ sids, int64_t B, const int32_t *__restrict__ idx,
+    int64_t row_begin, int64_t n_rows, int k, int n_ids, double *__restrict__ out) {
   const int lane = wcx::lane_id();
   const int wave = threadIdx.x >> 6;
   __shared__ int s_hist[NT / 64][64];
-  __shared__ unsigned long long s_slots[NT / 64][64];
+  __shared__ unsigned int s_slots[NT / 64][64];
+  __shared__ int s_cand[NT / 64][64];
   const int64_t r = (int64_t)blockIdx.x * (NT / 64) + wave;
   if (r >= n_rows) return;
   const int sg = blockIdx.y;
-  const double *xs[SG];
-#pragma unroll
-  for (int s = 0; s < SG; ++s) {
-    const int m = sg * SG + s;
-    xs[s] = Xs + (int64_t)sids[m < n_ids ? m : 0] * B;
-  }
-  unsigned long long v[SG][IPL];
+  const uint4 *slab = reinterpret_cast<const uint4 *>(Kg + (int64_t)sg * B * 8);
+  unsigned int v[8][IPL];
+  int cc[IPL];
   unsigned int act = 0;
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
@@ -340,22 +291,65 @@ __global__ __launch_bounds__(NT) void k_null_ratios_direct(
     const bool valid = t < k;
     int64_t c = valid ? (int64_t)idx[r * (int64_t)k + t] : 0;
     if (c < 0) c += B;  // NumPy negative index
+    cc[q] = (int)c;
     act |= valid ? (1u << q) : 0u;
-#pragma unroll
-    for (int s = 0; s < SG; ++s) v[s][q] = dkey_raw(xs[s][c]);
+    const uint4 a0 = slab[c * 2], a1 = slab[c * 2 + 1];
+    v[0][q] = a0.x; v[1][q] = a0.y; v[2][q] = a0.z; v[3][q] = a0.w;
+    v[4][q] = a1.x; v[5][q] = a1.y; v[6][q] = a1.z; v[7][q] = a1.w;
   }
-  double my_med = 0.0;
+  const int r0 = (k - 1) >> 1, r1 = k >> 1;
+  // Per sample: the high keys a0 <= a1 of the two middle order statistics.  Nearly always each is
+  // carried by ONE element: its bin goes to lane s, and the eight lanes fetch their two doubles
+  // together at the end (no dependent load inside the loop).  Shared high halves take the exact
+  // path at once.
+  int my_c0 = 0, my_c1 = 0;
+  double my_v0 = 0.0, my_v1 = 0.0;
+  bool my_slow = false, my_nan = false;
 #pragma unroll
-  for (int s = 0; s < SG; ++s) {
-    unsigned long long a0, a1, hi;
-    wave_middle_u64<IPL>(v[s], act, k, s_hist[wave], s_slots[wave], a0, a1, hi);
-    double med = (dkey_inv(a0) + dkey_inv(a1)) / 2.0 + 0.0;   // (np.median's mean: a zero median is +0)
-    if (hi == ~0ull) med = __builtin_nan("");              // np.median propagates NaN
-    if (lane == s) my_med = med;
+  for (int s = 0; s < 8; ++s) {
+    const int m = sg * 8 + s;
+    if (m >= n_ids) break;                                   // wave-uniform
+    unsigned int a0, a1, hi;
+    wave_middle_u32<IPL>(v[s], act, k, s_hist[wave], s_slots[wave], a0, a1, hi);
+    int below = 0, t0 = 0, t1 = 0, c0 = 0, c1 = 0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const bool on = (act >> q) & 1u;
+      below += __popcll(__ballot(on && v[s][q] < a0));
+      const unsigned long long e0 = __ballot(on && v[s][q] == a0);
+      if (e0) {
+        t0 += __popcll(e0);
+        c0 = __builtin_amdgcn_readlane(cc[q], __builtin_amdgcn_readfirstlane(__ffsll((long long)e0) - 1));
+      }
+      if (a1 != a0) {
+        const unsigned long long e1 = __ballot(on && v[s][q] == a1);
+        if (e1) {
+          t1 += __popcll(e1);
+          c1 = __builtin_amdgcn_readlane(cc[q], __builtin_amdgcn_readfirstlane(__ffsll((long long)e1) - 1));
+        }
+      }
+    }
+    const bool fast = t0 == 1 && (r1 == r0 || (a1 != a0 && t1 == 1));
+    if (fast) {
+      if (lane == s) { my_c0 = c0; my_c1 = r1 == r0 ? c0 : c1; }
+    } else {
+      const double *x = Xs + (int64_t)sids[m] * B;
+      const double v0 = pick_among_ties<IPL>(v[s], cc, act, a0, r0 - below, x, s_cand[wave]);
+      double v1 = v0;
+      if (r1 != r0)
+        v1 = pick_among_ties<IPL>(v[s], cc, act, a1, a1 == a0 ? r1 - below : 0, x, s_cand[wave]);
+      if (lane == s) { my_v0 = v0; my_v1 = v1; my_slow = true; }
+    }
+    if (lane == s) my_nan = hi == 0xffffffffu;               // only NaN has that high half
   }
-  const int m = sg * SG + lane;
-  if (lane < SG && m < n_ids)
-    out[r * (int64_t)n_ids + m] = log2(Xs[(int64_t)sids[m] * B + row_begin + r] / my_med);
+  const int m = sg * 8 + lane;
+  if (lane < 8 && m < n_ids) {
+    const double *x = Xs + (int64_t)sids[m] * B;
+    if (!my_slow) { my_v0 = x[my_c0]; my_v1 = x[my_c1]; }
+    double med = (my_v0 + my_v1) / 2.0 + 0.0;                // (np.median's mean: a zero median is +0)
+    if (my_nan) med = __builtin_nan("");                     // np.median propagates NaN
+    out[r * (int64_t)n_ids + m] = log2(x[row_begin + r] / med);
+  }
 }
 
 // One wave per (row, group of 8 samples).  blockIdx.x (fastest in dispatch order) walks the rows,
@@ -540,20 +534,21 @@ __global__ __launch_bounds__(256) void k_null_dummy(const double *__restrict__ X
   out[r * n_ids + m] = log2(x[row_begin + r] / x[0]);
 }
 
-// Ranking costs ~0.37 ns per (null sample, bin) whatever the number of target rows -- but mostly
-// hidden beside the refine on the auxiliary stream; the direct selection ~1.0 ns per (null sample,
-// target row) on the main stream.  Measured at 15 kb (scripts/sweep_shard_nr.sh, scripts/
-// sweep_gonosomal.sh): the chrX / chrY rows of a gonosomal pass (B / rows = 16-20): F search + null
-// ratios 6.5 -> 5.7 ms, M 7.5 -> 6.9 ms with the direct kernel; a rank's shard of an 8-GPU build
-// (B / rows = 8): 14.7 vs 14.3 ms (S = 500), 7.6 vs 7.8 ms (S = 100) -- a wash; of a 4-GPU build:
-// 20.4 vs 22.1 ms -- worse.  Hence direct from B / rows >= 12 (WCX_NR_DIRECT_RATIO overrides;
-// 0 = never).
+// Ranking costs ~0.37 ns per (null sample, bin) whatever the number of target rows -- mostly hidden
+// beside the refine on the auxiliary stream when the refine is long; the high-key selection costs
+// 54 ns per (row, 100 samples) against the rank kernel's 35 ns and needs no ranking.  Measured at
+// 15 kb (scripts/sweep_shard_nr.sh, bench.py): the chrX / chrY rows of a gonosomal pass (B / rows =
+// 16-20): null ratios 1.4 / 1.9 ms (a 64-bit-key variant) -> 0.6 / 0.7 ms, and no sort beside the
+// search; a rank's shard of an 8-GPU build (B / rows = 8): shard wall 14.7 -> 12.8 ms (S = 500),
+// 7.8 -> 5.8 ms (S = 100); of a 4-GPU build: 20.4 -> 19.1 ms, 9.9 -> 9.8 ms; from half of the rows
+// on the rank path wins.  Hence: no ranking from B / rows >= 4 (1.5 % slack for uneven shards;
+// WCX_NR_DIRECT_RATIO overrides, 0 = always rank).
 bool wcx_null_ratios_direct_pays(int64_t B, int64_t n_rows) {
   static const int ratio = [] {
     const char *e = getenv("WCX_NR_DIRECT_RATIO");
-    return e && *e ? atoi(e) : 12;
+    return e && *e ? atoi(e) : 4;
   }();
-  return ratio > 0 && n_rows * ratio <= B;
+  return ratio > 0 && n_rows * ratio <= B + B / 64;
 }
 
 // The search knows how many rows it really searches: if they are few, the ranking announced by
@@ -611,31 +606,36 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   rc = wcx_timer_begin(ctx, "null_ratios");
   if (rc) return rc;
   if (!prepared && wcx_null_ratios_direct_pays(B, n_rows)) {
-    // few rows: select on the doubles themselves, no ranking of the n_ids x B matrix
+    // few rows: no ranking of the n_ids x B matrix, selection on the high key halves
     ctx->rank_pending = false;
+    ctx->rank_X = nullptr;
+    const int n_sg = (n_ids + 7) / 8;
     void *scr = nullptr;
-    rc = wcx_scratch(ctx, (size_t)n_ids * 4 + 256, &scr);
+    rc = wcx_scratch(ctx, (size_t)n_sg * B * 32 + (size_t)n_ids * 4 + 512, &scr);
     if (rc) return rc;
-    int32_t *d_sids = reinterpret_cast<int32_t *>(scr);
+    unsigned int *Kg = reinterpret_cast<unsigned int *>(scr);
+    int32_t *d_sids = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(scr) + (size_t)n_sg * B * 32 + 256);
     rc = wcx_upload_small(ctx, d_sids, sample_ids, (size_t)n_ids * 4);
     if (rc) return rc;
-    const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)((n_ids + 3) / 4));
-#define WCX_NRD_LAUNCH(IPL)                                                                       \
-  k_null_ratios_direct<IPL><<<grid, NT, 0, st>>>(dXs, d_sids, B, d_idx, row_begin, n_rows, k, n_ids, d_out)
+    k_nr_hikeys<<<dim3((unsigned)((B + NT - 1) / NT), (unsigned)n_sg), NT, 0, st>>>(dXs, B, d_sids, n_ids, Kg);
+    const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)n_sg);
+#define WCX_NRH_LAUNCH(IPL)                                                                        \
+  k_null_ratios_hi<IPL><<<grid, NT, 0, st>>>(Kg, dXs, d_sids, B, d_idx, row_begin, n_rows, k, n_ids, d_out)
     const int ipl = (k + 63) / 64;
-    if (ipl <= 1) WCX_NRD_LAUNCH(1);
-    else if (ipl <= 2) WCX_NRD_LAUNCH(2);
-    else if (ipl <= 3) WCX_NRD_LAUNCH(3);
-    else if (ipl <= 4) WCX_NRD_LAUNCH(4);
-    else if (ipl <= 5) WCX_NRD_LAUNCH(5);
-    else if (ipl <= 6) WCX_NRD_LAUNCH(6);
-    else if (ipl <= 8) WCX_NRD_LAUNCH(8);
-    else if (ipl <= 16) WCX_NRD_LAUNCH(16);
+    if (ipl <= 1) WCX_NRH_LAUNCH(1);
+    else if (ipl <= 2) WCX_NRH_LAUNCH(2);
+    else if (ipl <= 3) WCX_NRH_LAUNCH(3);
+    else if (ipl <= 4) WCX_NRH_LAUNCH(4);
+    else if (ipl <= 5) WCX_NRH_LAUNCH(5);
+    else if (ipl <= 6) WCX_NRH_LAUNCH(6);
+    else if (ipl <= 8) WCX_NRH_LAUNCH(8);
+    else if (ipl <= 16) WCX_NRH_LAUNCH(16);
+    else if (ipl <= 32) WCX_NRH_LAUNCH(32);
     else {
-      wcx_set_error("refsize %d too large for the direct null-ratio kernel (max 1024)", k);
+      wcx_set_error("refsize %d too large for the null-ratio kernel (max 2048)", k);
       return WCX_ERR_UNSUPPORTED;
     }
-#undef WCX_NRD_LAUNCH
+#undef WCX_NRH_LAUNCH
     WCX_HIP(hipGetLastError());
     return wcx_timer_end(ctx, "null_ratios");
   }
