@@ -169,7 +169,10 @@ int wcx_null_ratios(wcx_ctx *ctx, const double *Xs, int64_t B, int S, const int3
 /* Optional head start for wcx_null_ratios_dev: ranks the null samples (the part of the null-ratio
  * work that depends on X only) on an auxiliary stream of the context, concurrently with whatever
  * follows on the main stream (the search); the next wcx_null_ratios_dev with the same dXs and
- * sample_ids uses it.  Results are identical with or without this call. */
+ * sample_ids uses it.  Results are identical with or without this call.  When the search that
+ * follows covers few rows (a gonosomal pass, a rank's shard of a 4- / 8-GPU build: B / rows >= 4)
+ * the announced ranking is dropped and wcx_null_ratios_dev selects without one (on the high halves
+ * of the values' keys, settled on the doubles) -- same results. */
 int wcx_null_rank_prepare_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                               const int32_t *sample_ids /*host*/, int n_ids);
 /* The same for rows whose reference-bin row is the dummy of a gonosomal pass (all indices 0,
