@@ -405,3 +405,29 @@ def test_many_unresolvable_rows_take_the_tiled_redo(nt):
     for t in rng.choice(B, 60, replace=False):
         oi, od = CO.get_reference_rows(Xs, cum, int(t), int(t) + 1, k)
         assert np.array_equal(idx[t], oi[0]) and np.array_equal(dist[t], od[0]), int(t)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 63, 64, 65, 91, 128, 300, 513])
+def test_null_ratios_few_rows_any_refsize(nt, k):
+    """The no-ranking path (rows x 4 <= bins) for odd and even reference sizes (one or two middle
+    order statistics), sizes around the 64-lane boundaries, with ties, repeats and a NaN -- against
+    the oracle and against the same rows taken from the whole-matrix (rank path) call."""
+    rng = np.random.default_rng(k)
+    B, S = 2400, 13
+    X = np.asfortranarray(1.0 + 0.05 * rng.standard_normal((B, S)))
+    X[100:140, 2] = 1.0625                       # ties in one sample (equal doubles)
+    X[200:260, 4] = 1.0 + np.arange(60) * 2.0 ** -40   # equal HIGH key halves, different doubles
+    X[300, 7] = np.nan
+    idx = rng.integers(0, B, (B, k)).astype(np.int32)
+    idx[3, :] = rng.integers(100, 140, k)        # many ties
+    idx[4, :] = rng.integers(200, 260, k)        # shared high halves: settled on the full doubles
+    idx[5, :] = 205                              # one bin repeated (more than 64 equal elements at k >= 65)
+    idx[6, k // 2] = 300                         # a NaN among the references of sample 7
+    ids = list(range(S))
+    few = nt.get_null_ratios(X, idx[:500], 0, 500, ids)
+    with np.errstate(all="ignore"):
+        want = O.null_ratios(X, idx[:500], 0, 500, ids)
+    np.testing.assert_allclose(few, want, rtol=1e-12, atol=1e-13, equal_nan=True)
+    assert np.isnan(few[6, 7])
+    full = nt.get_null_ratios(X, idx, 0, B, ids)
+    assert np.array_equal(few, full[:500], equal_nan=True)
