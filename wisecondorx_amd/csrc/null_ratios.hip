@@ -109,7 +109,9 @@ __device__ __forceinline__ unsigned int select_u32_bisect(const unsigned int (&v
   return prefix;
 }
 
-// The two middle order statistics (ranks r0 = (n-1)/2 and r1 = n/2) of the active values.
+// The two middle order statistics (ranks r0 = (n-1)/2 and r1 = n/2) of the active values: entry
+// q * 64 + lane is active iff it is < n (one compare against a scalar; `act` is that as a per-lane
+// bit mask, for the general path).
 // hist: int[64], slots: unsigned[64], wave-private LDS.  hi_out = the maximum (NaN detection).
 template <int IPL>
 __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], unsigned int act,
@@ -121,7 +123,7 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
   unsigned int lo = 0xffffffffu, nhi = 0xffffffffu;
 #pragma unroll
   for (int q = 0; q < IPL; ++q)
-    if ((act >> q) & 1u) { lo = v[q] < lo ? v[q] : lo; nhi = ~v[q] < nhi ? ~v[q] : nhi; }
+    if (q * 64 + lane < n) { lo = v[q] < lo ? v[q] : lo; nhi = ~v[q] < nhi ? ~v[q] : nhi; }
   lo = wave_min_u32(lo);
   const unsigned int hi = ~wave_min_u32(nhi);
   hi_out = hi;
@@ -133,7 +135,7 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
     b[q] = 0;
-    if ((act >> q) & 1u) {
+    if (q * 64 + lane < n) {
       int bb = (int)((float)(v[q] - lo) * scale);          // monotone in v
       bb = bb > 63 ? 63 : bb;
       b[q] = bb;
@@ -156,7 +158,7 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
   int base = 0;
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
-    const bool m = ((act >> q) & 1u) && b[q] == B0;
+    const bool m = q * 64 + lane < n && b[q] == B0;
     const unsigned long long mm = __ballot(m);
     if (m) slots[base + __popcll(mm & ((1ull << lane) - 1ull))] = v[q];
     base += __popcll(mm);
@@ -179,7 +181,7 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
       unsigned int mn = 0xffffffffu;
 #pragma unroll
       for (int q = 0; q < IPL; ++q)
-        if (((act >> q) & 1u) && b[q] > B0 && v[q] < mn) mn = v[q];
+        if (q * 64 + lane < n && b[q] > B0 && v[q] < mn) mn = v[q];
       a1 = wave_min_u32(mn);
     }
   }
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(NT) void k_null_ratios_hi(
     int below = 0, t0 = 0, t1 = 0, c0 = 0, c1 = 0;
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
-      const bool on = (act >> q) & 1u;
+      const bool on = q * 64 + lane < k;
       below += __popcll(__ballot(on && v[s][q] < a0));
       const unsigned long long e0 = __ballot(on && v[s][q] == a0);
       if (e0) {
