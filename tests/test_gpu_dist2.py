@@ -93,7 +93,7 @@ def test_ranks_on_one_device_real_kernels(world):
         np.testing.assert_allclose([mlr, mz], [emlr, emz], rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("mode", ["strong", "replicas"])
+@pytest.mark.parametrize("mode", ["strong", "replicas", "strong8"])
 def test_bench_two_ranks_smoke(mode):
     """bench.py's N > 1 code path end to end (launcher contract, sharding of the A pass and of the
     gonosomal passes, collectives, replica predict, JSON line) with two gloo ranks on one device and
@@ -104,16 +104,17 @@ def test_bench_two_ranks_smoke(mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    n = "8" if mode == "strong8" else "2"          # (8 ranks: the driver's largest launch, uneven shards)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", n,
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--binsize", "100000", "--samples", "40",
+           "--gpus", n, "--steps", "2", "--warmup", "1", "--binsize", "100000", "--samples", "40",
            "--refsize", "100"] + (["--replicas"] if mode == "replicas" else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                       # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["n_gpus"] == int(n) and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
     assert d["roofline"]["frac"] > 0
     assert d["scaling"] == ("weak" if mode == "replicas" else "strong")
     assert d["verified"]["mismatches"] == 0 and d["verified"]["rows"] > 100
