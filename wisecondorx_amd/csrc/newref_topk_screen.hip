@@ -737,8 +737,13 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // candidate chunk per launch: a few MB of fragments (3 MB fits the 4 MB XCD L2)
   const int64_t group_bytes = (int64_t)GRr * NK * 32;
   // (every launch costs ~30 us of prologue per round of workgroups -- target fragments, visit
-  // list --, so large K, whose groups are big, takes bigger chunks: L2 misses go to the MALL)
-  int64_t chunk_groups = ((int64_t)env_int("WCX_SCREEN_CHUNK_KB", NK > 16 ? 8192 : 3072) << 10) / group_bytes;
+  // list --, so large K, whose groups are big, takes bigger chunks: L2 misses go to the MALL.
+  // Every launch also re-reads the 128 KB of target fragments of each of its workgroups, which is
+  // most of what reaches the fabric; fetched bytes per sweep at K = 512 against the chunk size
+  // (rocprofv3 FETCH_SIZE x 2, scripts/sweep_chunk_traffic.sh): 2 / 3 / 4 / 8 / 16 / 32 / 64 / 128 MB
+  // -> 59 / 44 / 36 / 24.5 / 19.8 / 25 / 45 / 63 GB, sweep 32.7 / 31.8 / 31.5 / 31.3 / 31.2 / 32.5 /
+  // 33.7 / 42.7 ms: beyond 16 MB the workgroups of a launch drift apart and stop sharing lines)
+  int64_t chunk_groups = ((int64_t)env_int("WCX_SCREEN_CHUNK_KB", NK > 16 ? 16384 : 3072) << 10) / group_bytes;
   // (small shards swept in candidate segments -- the gonosomal passes: ~300 workgroups, less than one
   // round -- have no tail to hide and no L2 to share in step; their launches only cost: 3 / 6 / 12 /
   // 24 MB chunks: F pass screen 4.56 / 3.73 / 3.43 / 3.22 ms, M pass 5.33 / 4.87 / 4.34 / 4.16 ms)
