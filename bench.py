@@ -223,7 +223,7 @@ class Workload:
         self.pargs = argparse.Namespace(minrefbins=150, alpha=1e-4, seed=1, maskrepeats=5)
         self.rem = {"args": self.pargs, "mask": passes["F"]["mask"], "bins_per_chr": passes["F"]["bins_per_chr"],
                     "binsize": args.binsize, "ref_gender": "F"}
-        self.names = ("topk", "topk_screen", "topk_prep", "topk_refine", "null_ratios")
+        self.names = ("topk", "topk_screen", "topk_pre", "topk_prep", "topk_refine", "null_ratios")
         self.ms = {"{}:{}".format(t, n_): [] for t in ("A", "F", "M") for n_ in self.names}
         for n_ in ("normalize", "cbs", "segment_z", "predict_full", "gather_ref"):
             self.ms[n_] = []
@@ -249,6 +249,7 @@ class Workload:
                     if record:
                         self.ms["A:topk"].append(ctx.kernel_ms("A:topk"))
                         self.ms["A:topk_screen"].append(ctx.kernel_ms("A:topk_screen"))
+                        self.ms["A:topk_pre"].append(ctx.kernel_ms("A:topk_pre"))
                     return
                 t0 = time.perf_counter()
                 idx, dist_, nr = wd.gather_reference3(idx_l, dist_l, nr_l, P["B"], self.world, self.backend)
@@ -308,7 +309,8 @@ class Workload:
                  "topk_total_ms": k_ms, "pairs_per_launch": pairs_A,
                  "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": self.fb_rows,
                  "compactions": stats["compactions"], "appends": stats["appends"],
-                 "refined_pairs": stats["refined"],
+                 "refined_pairs": stats["refined"], "sym_gates": stats.get("sym_gates", 0),
+                 "sym_row_appends": stats.get("sym_row_appends", 0), "pre_ms": self.mean_ms("A:topk_pre"),
                  "kernel_ms_note": "wall time of one whole sweep of the A pass (HIP events on the launch "
                                    "stream, second stream joined by an event); the target blocks sweep in "
                                    "two halves on two concurrent streams, so rocprofv3's average launch "

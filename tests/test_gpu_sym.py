@@ -1,0 +1,133 @@
+"""GPU parity tests of the SYMMETRIC sweep of the reference-bin search (csrc/screen_sym.h; replaces
+newref_tools.py:255-278 for the all-rows search): every tile pair is computed once and serves both
+directions.  Indices and distances must be bit-identical to the C oracle; the tests also check that
+the symmetric path really ran (gate counter) and that its failure paths (a refuted threshold
+estimate, list overflow) end in the exact kernel with unchanged results."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nt():
+    from wisecondorx_amd import newref_tools
+    return newref_tools
+
+
+def _oracle(X, cum, k):
+    Xs = np.ascontiguousarray(np.asarray(X).T)
+    return CO.get_reference_rows_threaded(Xs, cum, 0, cum[-1], k)
+
+
+def _run(nt, X, cum, k):
+    from wisecondorx_amd import _lib
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, cum[-1], mode=2)
+    return idx, dist, _lib.default_context().topk_stats()
+
+
+# (chromosome sizes, samples -> K steps, refsize, sample rate)
+SHAPES = [
+    ([1900, 1700, 1500, 1300, 1100, 900, 700], 100, 100, 8),      # K = 112 (NK 7, two tiles per step)
+    ([2600, 2300, 2100, 1800, 1500, 1200, 900], 500, 300, 8),     # K = 512 (NK 32)
+    ([1500, 1400, 1300, 1000, 800, 400], 30, 128, 8),             # K = 48
+    ([1600, 1500, 1400, 1200, 1100, 900, 500], 260, 150, 8),      # K = 320 (NK 20)
+    ([1700, 1500, 1300, 1200, 1000, 0, 700, 650], 150, 100, 8),   # K = 160 (NK 10), an empty chromosome
+]
+
+
+@pytest.mark.parametrize("mb,S,k,sf", SHAPES)
+def test_symmetric_sweep_vs_c_oracle(nt, mb, S, k, sf, monkeypatch):
+    from wisecondorx_amd.synth import corrected_matrix
+    monkeypatch.setenv("WCX_SCREEN_SAMPLE", str(sf))
+    X, mbpc, cum = corrected_matrix(mb, S, seed=S + k)
+    oi, od = _oracle(X, cum, k)
+    idx, dist, st = _run(nt, X, cum, k)
+    assert st["sym_gates"] > 0, "the symmetric sweep did not run"
+    assert np.array_equal(idx, oi), "indices differ"
+    assert np.array_equal(dist, od), "distances differ"
+    assert st["fallback_rows"] <= 2
+    # the one-directional sweep on the same input: same bits
+    monkeypatch.setenv("WCX_SCREEN_SYM", "0")
+    idx1, dist1, st1 = _run(nt, X, cum, k)
+    assert st1["sym_gates"] == 0
+    assert np.array_equal(idx1, oi) and np.array_equal(dist1, od)
+
+
+def test_symmetric_sweep_small_chunks_and_splits(nt, monkeypatch):
+    """Many launches (tiny chunks of streamed tiles), several work items per target quad, one
+    stream: the tile-pair bookkeeping (who owns which pair, per-item candidate ranges) must cover
+    every pair exactly once."""
+    from wisecondorx_amd.synth import corrected_matrix
+    monkeypatch.setenv("WCX_SCREEN_SAMPLE", "8")
+    X, mbpc, cum = corrected_matrix([1900, 1700, 1500, 1300, 1100, 900, 700], 100, seed=77)
+    k = 100
+    oi, od = _oracle(X, cum, k)
+    for chunk_kb, split, streams in ((256, 3, 1), (512, 0, 2), (64, 2, 2)):
+        monkeypatch.setenv("WCX_SYM_CHUNK_KB", str(chunk_kb))
+        monkeypatch.setenv("WCX_SYM_SPLIT", str(split))
+        monkeypatch.setenv("WCX_SCREEN_STREAMS", str(streams))
+        idx, dist, st = _run(nt, X, cum, k)
+        assert st["sym_gates"] > 0
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), (chunk_kb, split, streams)
+
+
+def test_symmetric_sweep_refuted_estimates_are_redone(nt, monkeypatch):
+    """An absurd sample rank makes most threshold estimates too tight: the final cut must refute
+    them and the exact kernel redo the rows -- same bits."""
+    from wisecondorx_amd.synth import corrected_matrix
+    monkeypatch.setenv("WCX_SCREEN_SAMPLE", "4")
+    monkeypatch.setenv("WCX_SCREEN_CUT_R", "3")
+    X, mbpc, cum = corrected_matrix([1500, 1300, 1100, 900, 700, 500], 36, seed=23)
+    k = 80
+    oi, od = _oracle(X, cum, k)
+    idx, dist, st = _run(nt, X, cum, k)
+    assert st["sym_gates"] > 0 and st["fallback_rows"] > 100
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def test_symmetric_sweep_ties_nan_inf_duplicates_outliers(nt, monkeypatch):
+    monkeypatch.setenv("WCX_SCREEN_SAMPLE", "8")
+    rng = np.random.default_rng(12)
+    mb = [1700, 1650, 1600, 1500, 1450, 1200]
+    cum = np.cumsum(mb).tolist()
+    B, S, k = cum[-1], 24, 60
+    X = np.asfortranarray(rng.integers(0, 4, (B, S)).astype(np.float64))   # heavy exact ties
+    X[5, 3] = np.nan
+    X[900, 0] = np.inf
+    X[1500, 2] = -np.inf
+    X[2000, 1] = 3e5                 # d ~ 9e10 -> never admitted
+    X[2100] = X[10]                  # duplicate rows -> zero distances
+    X[2101] = X[10]
+    X[800] = np.nan                  # NaN target row
+    oi, od = _oracle(X, cum, k)
+    idx, dist, st = _run(nt, X, cum, k)
+    assert st["sym_gates"] > 0
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    # real-valued data with a few rows 100x larger (inflated error budget) and zero-norm rows
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([1900, 1800, 1700, 1600, 1200], 64, seed=21)
+    X = np.array(X, order="F")
+    X[[3, 1000, 2500]] *= 100.0
+    X[[7, 1200]] = 1.0
+    oi, od = _oracle(X, cum, 100)
+    idx, dist, st = _run(nt, X, cum, 100)
+    assert st["sym_gates"] > 0
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def test_symmetric_sweep_wide_norm_spread(nt, monkeypatch):
+    """Heavy-tailed row norms: many norm classes, loose estimates, rows the screen cannot resolve
+    (list overflow -> exact kernel)."""
+    monkeypatch.setenv("WCX_SCREEN_SAMPLE", "8")
+    rng = np.random.default_rng(340)
+    mb = rng.integers(1500, 3000, 6)
+    cum = np.cumsum(mb).tolist()
+    B, S, k = cum[-1], 140, 150
+    X = np.asfortranarray(1.0 + 0.1 * rng.gamma(2.0, 0.5, B)[:, None] * rng.standard_normal((B, S)))
+    oi, od = _oracle(X, cum, k)
+    idx, dist, st = _run(nt, X, cum, k)
+    assert st["sym_gates"] > 0
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)

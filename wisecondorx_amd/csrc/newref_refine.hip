@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
                                                int32_t *__restrict__ out_idx,
                                                double *__restrict__ out_dist,
                                                ScreenGlobals *__restrict__ glob,
-                                               unsigned long long *__restrict__ stats) {
+                                               unsigned long long *__restrict__ stats, int sls) {
   extern __shared__ __align__(16) unsigned char rsm[];
   const int wave = threadIdx.x >> 6;
   const size_t per_wave = (size_t)(64 * RPITCH + Sp) * 8 + 64 * 4;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
     const int64_t row = row_begin + r;
     int64_t cs = 0, ce = chr.cum[0];
     for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
-    refine_row<8>(Xr, S, Sp, row, cs, ce - cs, sl + r * (int64_t)CAP, perm, n, k,
+    refine_row<8>(Xr, S, Sp, row, cs, ce - cs, sl + r * (int64_t)sls, perm, n, k,
                   out_idx + r * (int64_t)k, out_dist + r * (int64_t)k, tile, xt_s, g_s);
   }
 }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr
                                                    const unsigned int *__restrict__ flags,
                                                    const int *__restrict__ perm, int k,
                                                    int32_t *__restrict__ out_idx,
-                                                   double *__restrict__ out_dist) {
+                                                   double *__restrict__ out_dist, int sls) {
   __shared__ double sd[CAP];
   __shared__ int si[CAP];
   for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr
     for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
     const int64_t own = ce - cs;
     const double *xt = Xr + row * (int64_t)Sp;
-    const uint2 *sl_row = sl + r * (int64_t)CAP;
+    const uint2 *sl_row = sl + r * (int64_t)sls;
     __syncthreads();
     for (int e = threadIdx.x; e < CAP; e += NT) {
       double acc = HUGE_VAL;
@@ -247,16 +247,16 @@ int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTa
                       int64_t row_begin, int64_t n_rows, const unsigned char *searched,
                       const uint2 *sl, const int *cnt_out, const unsigned int *flags,
                       const int *perm, int k, int32_t *d_out_idx, double *d_out_dist,
-                      ScreenGlobals *glob) {
+                      ScreenGlobals *glob, int sl_stride) {
   const unsigned gref = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
   const size_t rlds = (NT / 64) * ((size_t)(64 * RPITCH + Sp) * 8 + 64 * 4);
   WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_refine),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
   k_refine<<<gref, NT, rlds, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out,
-                                         flags, perm, k, d_out_idx, d_out_dist, glob, ctx->d_stats);
+                                         flags, perm, k, d_out_idx, d_out_dist, glob, ctx->d_stats, sl_stride);
   const unsigned gbig = (unsigned)(n_rows < 2048 ? n_rows : 2048);
   k_refine_big<<<gbig, NT, 0, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl,
-                                             cnt_out, flags, perm, k, d_out_idx, d_out_dist);
+                                             cnt_out, flags, perm, k, d_out_idx, d_out_dist, sl_stride);
   WCX_HIP(hipGetLastError());
   return WCX_OK;
 }

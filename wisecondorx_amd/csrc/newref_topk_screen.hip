@@ -473,6 +473,186 @@ __global__ __launch_bounds__(NT) void k_redo_fill(int64_t row_begin, int64_t n_r
   rowlist[atomicAdd(&ctr[34 + c], 1u)] = (int32_t)row;
 }
 
+// ------------------------------------------------------------------------------------------
+// Symmetric sweep (screen_sym.h): sweep order, thresholds, final cut.
+constexpr int SYM_NCLS = 32;               // coarse norm classes: float bits of |a|^2 >> 22 (two per octave)
+constexpr int SYM_NCELL = SYM_NCLS * 32;   // (class, chromosome) cells, each padded to whole 32-row tiles
+constexpr float SYM_DMAX = 4.0e9f;         // thresholds at or above this: the row goes to the exact kernel
+
+__global__ __launch_bounds__(NT) void k_sym_hist(const unsigned int *__restrict__ rbits,
+                                                 const int *__restrict__ rchr, int64_t B,
+                                                 const ScreenGlobals *__restrict__ glob,
+                                                 int *__restrict__ rkey, int *__restrict__ cellcnt) {
+  __shared__ int lh[SYM_NCELL];
+  for (int i = threadIdx.x; i < SYM_NCELL; i += NT) lh[i] = 0;
+  __syncthreads();
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (b < B) {
+    const unsigned int umin = 0xffffffffu - glob->uinv;
+    const unsigned int u = rbits[b];
+    unsigned int cls = SYM_NCLS - 1;                    // non-finite rows go last
+    if (u != 0xffffffffu && u >= umin) { cls = (u - umin) >> 2; if (cls > SYM_NCLS - 2) cls = SYM_NCLS - 2; }
+    const int key = (int)cls * 32 + rchr[b];
+    rkey[b] = key;
+    atomicAdd(&lh[key], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SYM_NCELL; i += NT)
+    if (lh[i]) atomicAdd(&cellcnt[i], lh[i]);
+}
+
+// First sweep position of every cell (cells padded to whole tiles), the chromosome of every tile,
+// the number of tiles in use (rounded up to whole quads).  tchr was preset to 255.
+__global__ __launch_bounds__(SYM_NCELL) void k_sym_scan(const int *__restrict__ cellcnt,
+                                                        int *__restrict__ cursor,
+                                                        unsigned char *__restrict__ tchr,
+                                                        ScreenGlobals *__restrict__ glob) {
+  __shared__ int part[SYM_NCELL];
+  const int t = threadIdx.x;
+  const int padded = (cellcnt[t] + 31) & ~31;
+  part[t] = padded;
+  __syncthreads();
+  for (int off = 1; off < SYM_NCELL; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  const int start = part[t] - padded;
+  cursor[t] = start;
+  for (int i = start >> 5; i < (start + padded) >> 5; ++i) tchr[i] = (unsigned char)(t & 31);
+  if (t == SYM_NCELL - 1) glob->n_tiles = (unsigned int)((((start + padded) >> 5) + 3) & ~3);
+}
+
+// After the sampled pre-pass: the estimated threshold of every row, in screen-distance space
+// (D = G + nb': the pre-pass admits t = nb'_c - 2 g~ <= G), as theta = -D/2 per sweep position;
+// per-tile minimum; list counters reset (the pre-pass's entries are dropped: the symmetric sweep
+// meets every pair again).  Rows without a usable estimate go to the exact kernel.
+__global__ __launch_bounds__(NT) void k_sym_setup(const int *__restrict__ perm,
+                                                  const RowInfo *__restrict__ info,
+                                                  const ScreenGlobals *__restrict__ glob,
+                                                  const float *__restrict__ g_state,
+                                                  int *__restrict__ cnt, unsigned int *__restrict__ flags,
+                                                  float *__restrict__ Dest,
+                                                  unsigned int *__restrict__ tinfo,
+                                                  float *__restrict__ tmin) {
+  const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
+  const int64_t tile = p >> 5;
+  if (tile >= (int64_t)glob->n_tiles) return;
+  const int l = (int)(p & 31);
+  const int row = perm[p];
+  float theta = HUGE_VALF;
+  if (row >= 0) {
+    const float G = g_state[row];
+    const float D = G + info[p].nb;
+    if (flags[row] || !(G < GMAX) || !(D < SYM_DMAX)) flags[row] = 1u;
+    else theta = -0.5f * D;
+    Dest[row] = D;
+    cnt[row] = 0;
+  }
+  tinfo[tile * 64 + l] = __float_as_uint(theta);
+  tinfo[tile * 64 + 32 + l] = (unsigned int)row;
+  float m = theta;
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(m, off, 64);
+    m = o < m ? o : m;
+  }
+  if (l == 0) tmin[tile] = m;
+}
+
+// Records of the symmetric sweep (row, partner position, d~ bits) -> the rows' lists.
+__global__ __launch_bounds__(NT) void k_sym_regroup(const uint4 *__restrict__ pool,
+                                                    const unsigned int *__restrict__ pool_head,
+                                                    const unsigned int *__restrict__ pool_ovf,
+                                                    unsigned int pool_cap, int64_t n_rows,
+                                                    uint2 *__restrict__ sl, int *__restrict__ cnt,
+                                                    unsigned int *__restrict__ flags) {
+  if (*pool_ovf) {                           // records were lost: every row goes to the exact kernel
+    for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * NT)
+      flags[r] = 1u;
+    return;
+  }
+  unsigned int n = *pool_head;
+  if (n > pool_cap) n = pool_cap;
+  for (unsigned int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    const uint4 rec = pool[i];
+    const int slot = atomicAdd(&cnt[rec.x], 1);
+    if (slot < CAP2) sl[(int64_t)rec.x * CAP2 + slot] = make_uint2(rec.z, rec.y);
+    else flags[rec.x] = 1u;
+  }
+}
+
+// Final cut of the symmetric sweep, one wave per row: the k-th smallest screen distance of the
+// list bounds the true k-th distance; its filter bound F must not exceed the estimate the list was
+// collected under (everything with d~ <= D is in the list) -- then the entries with d~ <= F are
+// exactly the ones the refine needs; else the row is flagged for the exact kernel.
+__global__ __launch_bounds__(NT) void k_sym_final(const RowInfo *__restrict__ info,
+                                                  const ScreenGlobals *__restrict__ glob,
+                                                  const int *__restrict__ rowpos, int64_t n_rows,
+                                                  uint2 *__restrict__ sl, int *__restrict__ cnt,
+                                                  unsigned int *__restrict__ flags,
+                                                  const float *__restrict__ Dest, int k, float gamma) {
+  const int lane = wcx::lane_id();
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  const float e_max = __uint_as_float(glob->e_max), N_max = __uint_as_float(glob->N_max);
+  constexpr int IPL = CAP2 / 64;
+  for (int64_t r = w0; r < n_rows; r += nw) {
+    const int c = cnt[r];
+    if (flags[r] || c > CAP2 || c < k) {
+      if (lane == 0) { flags[r] = 1u; cnt[r] = 0; }
+      continue;
+    }
+    uint2 *row = sl + r * (int64_t)CAP2;
+    unsigned int key[IPL], idx[IPL];
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const uint2 v = row[q * 64 + lane];
+      key[q] = (q * 64 + lane < c) ? f32_key(__uint_as_float(v.x)) : 0xffffffffu;
+      idx[q] = v.y;
+    }
+    const unsigned int kref = (unsigned int)__builtin_amdgcn_readfirstlane((int)key[0]);
+    unsigned int x = 0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) x |= (q * 64 + lane < c) ? (key[q] ^ kref) : 0u;
+    x = wcx::wave_or_u32(x);
+    const int hb = 31 - __builtin_clz(x | 1u);
+    unsigned int prefix = kref & ~((2u << hb) - 1u);
+    for (int bit = hb; bit >= 0; --bit) {
+      const unsigned int trial = prefix | (1u << bit);
+      int n_lt = 0;
+#pragma unroll
+      for (int q = 0; q < IPL; ++q) n_lt += __popcll(__ballot(key[q] < trial));
+      if (n_lt < k) prefix = trial;
+    }
+    const float tk = key_f32(prefix);
+    float na, E, Q;
+    row_budget(info[rowpos[r]], e_max, N_max, gamma, na, E, Q);
+    const float dk = tk > 0.f ? tk : 0.f;
+    const float rt = sqrtf(up(dk + Q)) * 1.0000005f + 2.f * E;
+    const float Fb = up(up(rt * rt) + Q);
+    if (!(Fb <= Dest[r])) {                 // estimate unproven (or NaN): exact kernel
+      if (lane == 0) { flags[r] = 1u; cnt[r] = 0; }
+      continue;
+    }
+    const unsigned int gkey = f32_key(Fb);
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const bool keep = key[q] <= gkey && (q * 64 + lane < c);
+      const unsigned long long m = __ballot(keep);
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (keep) row[pos] = make_uint2(__float_as_uint(key_f32(key[q])), idx[q]);
+      base += __popcll(m);
+    }
+    if (lane == 0) {
+      if (base > CAP) { flags[r] = 1u; cnt[r] = 0; }
+      else cnt[r] = base;
+    }
+  }
+}
+
 }  // namespace
 
 // Host side --------------------------------------------------------------------------------
@@ -503,6 +683,320 @@ static int screen_dispatch(const ScreenCfg &c, const ScreenArgs &a, unsigned gri
   if (rc < 0) rc = wcx_screen_launch_k5(c, a, grid, lds, st);
   if (rc < 0) rc = wcx_screen_launch_k6(c, a, grid, lds, st);
   return rc;
+}
+
+static int sym_dispatch(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds,
+                        hipStream_t st) {
+  int rc = wcx_sym_launch_k1(nk, ctg, lb, ring, a, grid, lds, st);
+  if (rc < 0) rc = wcx_sym_launch_k2(nk, ctg, lb, ring, a, grid, lds, st);
+  if (rc < 0) rc = wcx_sym_launch_k3(nk, ctg, lb, ring, a, grid, lds, st);
+  return rc;
+}
+
+// The search of ALL rows against all rows with the symmetric sweep (screen_sym.h):
+//   order A   the sample rows (b = 0 mod SF) best-first, own small fragment array F_s
+//   order B   all rows by (norm class, chromosome), cells padded to tiles: fragment array F
+//   pre-pass  one-directional kernel, targets = all rows (fragments from F), candidates = F_s:
+//             streaming top-r -> an estimated threshold per row (its list entries are dropped)
+//   sweep     k_screen_sym over all tile pairs {a < b}, fixed thresholds, atomic appends
+//   final cut proves the estimate per row or flags it; refine; exact redo of flagged rows
+static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const int64_t *chr_cum,
+                           int n_chr, const std::vector<ScreenBlock> &blocks, const ScreenCfg &cfg,
+                           int SF, int cut_r, int slots, int k, int32_t *d_out_idx,
+                           double *d_out_dist) {
+  const int NK = cfg.nk, CTG = cfg.ctg, GRr = CTG * 32;
+  const int Sp = (S + 3) & ~3;
+  const int64_t n_rows = B;
+  const int64_t n_s = (B + SF - 1) / SF;
+  const int64_t P_s = (n_s + CT - 1) / CT * CT;
+  const int64_t Bpad2 = P_s + ((B - n_s) + CT - 1) / CT * CT;       // positions of the two-region order
+  const int64_t NTb = (((B + 31) / 32 + (int64_t)SYM_NCLS * n_chr + 4) + 7) / 8 * 8;   // tile bound
+  const int64_t PB = NTb * 32;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_glob = carve(sizeof(ScreenGlobals));
+  const size_t o_mean = carve((size_t)S * 8 * 5);
+  const size_t o_xr = carve((size_t)B * Sp * 8 + 256);
+  const size_t o_F = carve((size_t)PB * NK * 32);
+  const size_t o_Fs = carve((size_t)P_s * NK * 32);
+  const size_t o_info = carve((size_t)PB * sizeof(RowInfo));
+  const size_t o_infs = carve((size_t)P_s * sizeof(RowInfo));
+  const size_t o_perm = carve((size_t)PB * 4);
+  const size_t o_perm2 = carve((size_t)Bpad2 * 4);
+  const size_t o_rpos = carve((size_t)B * 4);
+  const size_t o_rpos2 = carve((size_t)B * 4);
+  const size_t o_rbit = carve((size_t)B * 4);
+  const size_t o_rchr = carve((size_t)B * 4);
+  const size_t o_rkey = carve((size_t)B * 4);
+  const size_t o_cell = carve((size_t)2 * NCELL * 4);
+  const size_t o_curs = carve((size_t)2 * NCELL * 4);
+  const size_t o_gmsk = carve((size_t)(P_s / CT) * 4);
+  const size_t o_tinf = carve((size_t)NTb * 64 * 4);
+  const size_t o_tmin = carve((size_t)NTb * 4);
+  const size_t o_tchr = carve((size_t)NTb);
+  const size_t o_dest = carve((size_t)n_rows * 4);
+  // records: row-direction hits (a few per cent of all) + everything from launches that split a
+  // target quad over several work items (the high, hub-free tiles)
+  const unsigned int pool_cap = (unsigned int)(n_rows * 1024 < 200000000ll ? n_rows * 1024 : 200000000ll);
+  const size_t o_pool = carve((size_t)pool_cap * 16);
+  const size_t o_phead = carve(256);
+  const size_t o_sl = carve((size_t)n_rows * CAP2 * 8);
+  const size_t o_cnt = carve((size_t)n_rows * 4);
+  const size_t o_gst = carve((size_t)n_rows * 4);
+  const size_t o_flag = carve((size_t)n_rows * 4);
+  const size_t o_srch = carve((size_t)n_rows);
+  const size_t o_blk = carve(blocks.size() * sizeof(ScreenBlock));
+  const size_t o_redo = carve((size_t)n_rows * sizeof(TopkBlock));
+  const size_t o_nredo = carve(512);
+  const size_t o_rtile = carve(((size_t)n_rows / 64 + 64) * sizeof(TopkBlock));
+  const size_t o_rlist = carve((size_t)n_rows * 4);
+  const size_t o_rscr = carve(wcx_topk_redo_scratch_bytes(k, B));
+  void *scr = nullptr;
+  int rc = wcx_scratch(ctx, off, &scr);
+  if (rc) return rc;
+  char *base = reinterpret_cast<char *>(scr);
+  ScreenGlobals *glob = reinterpret_cast<ScreenGlobals *>(base + o_glob);
+  double *cmean = reinterpret_cast<double *>(base + o_mean);
+  double *Xr = reinterpret_cast<double *>(base + o_xr);
+  half8 *F = reinterpret_cast<half8 *>(base + o_F);
+  half8 *Fs = reinterpret_cast<half8 *>(base + o_Fs);
+  RowInfo *info = reinterpret_cast<RowInfo *>(base + o_info);
+  RowInfo *infs = reinterpret_cast<RowInfo *>(base + o_infs);
+  int *perm = reinterpret_cast<int *>(base + o_perm);
+  int *perm2 = reinterpret_cast<int *>(base + o_perm2);
+  int *rowpos = reinterpret_cast<int *>(base + o_rpos);
+  int *rowpos2 = reinterpret_cast<int *>(base + o_rpos2);
+  unsigned int *rbits = reinterpret_cast<unsigned int *>(base + o_rbit);
+  int *rchr = reinterpret_cast<int *>(base + o_rchr);
+  int *rkey = reinterpret_cast<int *>(base + o_rkey);
+  int *cellcnt = reinterpret_cast<int *>(base + o_cell);
+  int *cursor = reinterpret_cast<int *>(base + o_curs);
+  unsigned int *gmask = reinterpret_cast<unsigned int *>(base + o_gmsk);
+  unsigned int *tinfo = reinterpret_cast<unsigned int *>(base + o_tinf);
+  float *tmin = reinterpret_cast<float *>(base + o_tmin);
+  unsigned char *tchr = reinterpret_cast<unsigned char *>(base + o_tchr);
+  float *Dest = reinterpret_cast<float *>(base + o_dest);
+  uint4 *pool = reinterpret_cast<uint4 *>(base + o_pool);
+  unsigned int *pool_head = reinterpret_cast<unsigned int *>(base + o_phead);
+  uint2 *sl = reinterpret_cast<uint2 *>(base + o_sl);
+  int *cnt_out = reinterpret_cast<int *>(base + o_cnt);
+  float *g_state = reinterpret_cast<float *>(base + o_gst);
+  unsigned int *flags = reinterpret_cast<unsigned int *>(base + o_flag);
+  unsigned char *searched = reinterpret_cast<unsigned char *>(base + o_srch);
+  ScreenBlock *d_blocks = reinterpret_cast<ScreenBlock *>(base + o_blk);
+  TopkBlock *d_redo = reinterpret_cast<TopkBlock *>(base + o_redo);
+  unsigned int *d_nredo = reinterpret_cast<unsigned int *>(base + o_nredo);
+  TopkBlock *d_rtile = reinterpret_cast<TopkBlock *>(base + o_rtile);
+  int32_t *d_rlist = reinterpret_cast<int32_t *>(base + o_rlist);
+
+  hipStream_t st = ctx->stream;
+  WCX_HIP(hipMemsetAsync(glob, 0, sizeof(ScreenGlobals), st));
+  WCX_HIP(hipMemsetAsync(cnt_out, 0, (size_t)n_rows * 4, st));
+  WCX_HIP(hipMemsetAsync(flags, 0, (size_t)n_rows * 4, st));
+  WCX_HIP(hipMemsetAsync(searched, 1, (size_t)n_rows, st));          // every row is a target
+  WCX_HIP(hipMemsetAsync(pool_head, 0, 256, st));
+  WCX_HIP(hipMemsetAsync(d_nredo, 0, 512, st));
+  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, st));
+  rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
+  if (rc) return rc;
+
+  rc = wcx_timer_begin(ctx, "topk");
+  if (rc) return rc;
+  rc = wcx_timer_begin(ctx, "topk_prep");
+  if (rc) return rc;
+  unsigned long long *cmin = reinterpret_cast<unsigned long long *>(cmean + 3 * S);
+  unsigned long long *cmax = cmin + S;
+  WCX_HIP(hipMemsetAsync(cmean + S, 0, (size_t)S * 16, st));
+  WCX_HIP(hipMemsetAsync(cmin, 0xff, (size_t)S * 8, st));
+  WCX_HIP(hipMemsetAsync(cmax, 0, (size_t)S * 8, st));
+  k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, cmean + S, cmean + 2 * S, cmin, cmax);
+  k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, cmean + S, cmean + 2 * S, cmin, cmax, cmean,
+                                                         glob);
+  k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
+  ChrTab tab;
+  tab.n_chr = n_chr;
+  for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
+  const unsigned gb = (unsigned)((B + NT - 1) / NT);
+  k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
+  // order A: the two-region best-first order; only its sample region [0, P_s) is used
+  WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
+  WCX_HIP(hipMemsetAsync(perm2, 0xff, (size_t)Bpad2 * 4, st));
+  k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, SF, 0, glob, rkey, cellcnt);
+  k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, (int)(P_s - n_s));
+  k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm2, rowpos2);
+  k_group_mask<<<(unsigned)((P_s / CT + NT - 1) / NT), NT, 0, st>>>(perm2, rchr, P_s / CT, gmask);
+  // order B: (norm class, chromosome) cells padded to tiles
+  WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
+  WCX_HIP(hipMemsetAsync(cursor, 0, (size_t)2 * NCELL * 4, st));
+  WCX_HIP(hipMemsetAsync(perm, 0xff, (size_t)PB * 4, st));
+  WCX_HIP(hipMemsetAsync(tchr, 0xff, (size_t)NTb, st));
+  k_sym_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt);
+  k_sym_scan<<<1, SYM_NCELL, 0, st>>>(cellcnt, cursor, tchr, glob);
+  k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
+  const unsigned gprep = (unsigned)((PB + NT - 1) / NT), gprep_s = (unsigned)((P_s + NT - 1) / NT);
+  switch (NK) {
+#define WCX_PREP_CASE(N) case N: \
+    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, PB, S, Sp, cmean, perm, glob, F, info); \
+    k_screen_prep<N><<<gprep_s, NT, 0, st>>>(Xr, P_s, S, Sp, cmean, perm2, glob, Fs, infs); break;
+    WCX_PREP_CASE(1) WCX_PREP_CASE(2) WCX_PREP_CASE(3) WCX_PREP_CASE(4) WCX_PREP_CASE(5)
+    WCX_PREP_CASE(6) WCX_PREP_CASE(7) WCX_PREP_CASE(8) WCX_PREP_CASE(10) WCX_PREP_CASE(12)
+    WCX_PREP_CASE(14) WCX_PREP_CASE(16) WCX_PREP_CASE(20) WCX_PREP_CASE(24) WCX_PREP_CASE(28)
+    default:
+      k_screen_prep<32><<<gprep, NT, 0, st>>>(Xr, PB, S, Sp, cmean, perm, glob, F, info);
+      k_screen_prep<32><<<gprep_s, NT, 0, st>>>(Xr, P_s, S, Sp, cmean, perm2, glob, Fs, infs);
+      break;
+#undef WCX_PREP_CASE
+  }
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "topk_prep");
+  if (rc) return rc;
+  const int kick_at = env_int("WCX_RANK_KICK", S >= 256 ? 1 : 0);
+  if (kick_at == 0) {
+    rc = wcx_aux_kick(ctx);
+    if (rc) return rc;
+  }
+  rc = wcx_timer_begin(ctx, "topk_screen");
+  if (rc) return rc;
+  rc = wcx_timer_begin(ctx, "topk_pre");
+  if (rc) return rc;
+
+  // ---- sampled pre-pass (one-directional kernel; candidates = the sample's fragments)
+  {
+    const int64_t group_bytes = (int64_t)GRr * NK * 32;
+    int64_t chunk_groups = ((int64_t)env_int("WCX_SCREEN_CHUNK_KB", NK > 16 ? 16384 : 3072) << 10) / group_bytes;
+    if (chunk_groups < 16) chunk_groups = 16;
+    if (chunk_groups > 4096) chunk_groups = 4096;
+    const size_t lds = (size_t)(cfg.ring >= 2 ? cfg.ring : 2) * (size_t)(CTG * NK * 64) * 16 +
+                       (size_t)(chunk_groups + 64) * 4;
+    ScreenArgs a;
+    a.F = Fs; a.Ft = F; a.info = info; a.glob = glob; a.perm = perm2; a.rowpos = rowpos; a.gmask = gmask;
+    a.blocks = d_blocks; a.sl = sl; a.cnt = cnt_out; a.flags = flags; a.g_state = g_state;
+    a.stats = ctx->d_stats; a.row_begin = 0; a.n_rows_all = n_rows;
+    a.k = k; a.dbg = ctx->debug_flags & ~3; a.n_seg = 1; a.n_blocks = (int)blocks.size();
+    int trig_a = 4 * cut_r + 64;
+    if (trig_a > LIM) trig_a = LIM;
+    const int64_t g_end = P_s / GRr;
+    bool first = true;
+    for (int64_t g0 = 0; g0 < g_end; g0 += chunk_groups) {
+      const int64_t g1 = g0 + chunk_groups < g_end ? g0 + chunk_groups : g_end;
+      a.g_start = g0; a.g_count = (int)(g1 - g0);
+      a.cut_k = cut_r; a.cut_mode = 1; a.trig = trig_a; a.end_cut = g1 == g_end ? 1 : 0;
+      a.first = first ? 1 : 0;
+      first = false;
+      const int e = screen_dispatch(cfg, a, (unsigned)blocks.size(), lds, st);
+      if (e < 0) {
+        wcx_set_error("screen kernel configuration nk=%d ctg=%d is not instantiated", cfg.nk, cfg.ctg);
+        return (int)WCX_ERR_UNSUPPORTED;
+      }
+      if (e != 0) {
+        wcx_set_error("screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        return (int)WCX_ERR_HIP;
+      }
+    }
+  }
+  k_sym_setup<<<gprep, NT, 0, st>>>(perm, info, glob, g_state, cnt_out, flags, Dest, tinfo, tmin);
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "topk_pre");
+  if (rc) return rc;
+
+  // ---- symmetric sweep: one launch per chunk of streamed tiles and stream.  The target quads are
+  // dealt to two streams by parity: the tails of one stream's launches are filled by the other's
+  // workgroups, and as long as a launch has ONE work item per quad, a row's counter has a single
+  // writer at any time (launches of a stream run in order) -- column-direction hits then go straight
+  // to the lists with register counters.  Launches high in the order have few target quads left
+  // above their chunk: there a quad is split over several work items, which write records instead.
+  {
+    int64_t Cz = ((int64_t)env_int("WCX_SYM_CHUNK_KB", NK > 16 ? 8192 : 3072) << 10) / ((int64_t)NK * 1024);
+    Cz = Cz / 8 * 8;
+    if (Cz < 32) Cz = 32;
+    if (Cz > 8192) Cz = 8192;
+    if (!ctx->sweep_stream) {
+      WCX_HIP(hipStreamCreateWithFlags(&ctx->sweep_stream, hipStreamNonBlocking));
+      WCX_HIP(hipEventCreateWithFlags(&ctx->ev_sweep0, hipEventDisableTiming));
+      WCX_HIP(hipEventCreateWithFlags(&ctx->ev_sweep1, hipEventDisableTiming));
+    }
+    const int n_streams = env_int("WCX_SCREEN_STREAMS", 2) == 2 ? 2 : 1;
+    hipStream_t st2 = n_streams == 2 ? ctx->sweep_stream : st;
+    if (n_streams == 2) {
+      WCX_HIP(hipEventRecord(ctx->ev_sweep0, st));
+      WCX_HIP(hipStreamWaitEvent(st2, ctx->ev_sweep0, 0));
+    }
+    const int glist_cap = (int)((Cz / CTG + 64 + 3) / 4 * 4);
+    const size_t lds = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)cfg.ring * CTG * 256 +
+                       (size_t)glist_cap * 4 + (size_t)4 * 64 * 16 +
+                       (size_t)4 * (NK <= 8 ? 1 : 2) * 64 * 16;   // visit list, staged records, accumulator rounds
+    SymArgs a;
+    a.F = F; a.tinfo = tinfo; a.tmin = tmin; a.tchr = tchr; a.glob = glob; a.sl = sl; a.cnt = cnt_out;
+    a.flags = flags; a.stats = ctx->d_stats; a.dbg = ctx->debug_flags;
+    a.pool = pool; a.pool_head = pool_head; a.pool_ovf = pool_head + 1; a.pool_cap = pool_cap;
+    a.glist_cap = glist_cap;
+    const int NQb = (int)(NTb / 4);
+    const int split_env = env_int("WCX_SYM_SPLIT", 0);
+    const int fill = env_int("WCX_SYM_FILL", 1) * slots;        // work items a chunk should offer
+    for (int64_t c0 = 0; c0 < NTb; c0 += Cz) {
+      const int64_t c1 = c0 + Cz < NTb ? c0 + Cz : NTb;
+      a.c0 = (int)c0; a.c1 = (int)c1;
+      const int q_first = (int)(c0 / 4);
+      const int n_active = NQb - q_first;
+      int n_split = n_active >= fill ? 1 : (fill + n_active - 1) / n_active;
+      const int max_split = (int)((c1 - c0) / CTG / 8) > 1 ? (int)((c1 - c0) / CTG / 8) : 1;
+      if (n_split > max_split) n_split = max_split;
+      if (split_env > 0) n_split = split_env < max_split ? split_env : max_split;
+      if (n_split < 1) n_split = 1;
+      a.n_split = n_split;
+      a.excl = n_split == 1 ? 1 : 0;
+      a.qstride = n_streams;
+      for (int h = 0; h < n_streams; ++h) {
+        a.q0 = q_first + h;
+        const int n_q = (n_active - h + n_streams - 1) / n_streams;
+        if (n_q <= 0) continue;
+        const int e = sym_dispatch(NK, CTG, cfg.lb, cfg.ring, a, (unsigned)(n_q * n_split), lds, h ? st2 : st);
+        if (e < 0) {
+          wcx_set_error("symmetric screen kernel nk=%d ctg=%d lb=%d ring=%d is not instantiated", NK, CTG,
+                        cfg.lb, cfg.ring);
+          return (int)WCX_ERR_UNSUPPORTED;
+        }
+        if (e != 0) {
+          wcx_set_error("symmetric screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+          return (int)WCX_ERR_HIP;
+        }
+      }
+    }
+    if (n_streams == 2) {
+      WCX_HIP(hipEventRecord(ctx->ev_sweep1, st2));
+      WCX_HIP(hipStreamWaitEvent(st, ctx->ev_sweep1, 0));
+    }
+    k_sym_regroup<<<2048, NT, 0, st>>>(pool, pool_head, pool_head + 1, pool_cap, n_rows, sl, cnt_out, flags);
+  }
+  {
+    const float gamma = (float)(16 * NK + 12) * 1.1920929e-7f;
+    const unsigned gf = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
+    k_sym_final<<<gf, NT, 0, st>>>(info, glob, rowpos, n_rows, sl, cnt_out, flags, Dest, k, gamma);
+  }
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "topk_screen");
+  if (rc) return rc;
+  if (kick_at == 1) {
+    rc = wcx_aux_kick(ctx);
+    if (rc) return rc;
+  }
+  rc = wcx_timer_begin(ctx, "topk_refine");
+  if (rc) return rc;
+  rc = wcx_refine_launch(ctx, Xr, S, Sp, tab, 0, n_rows, searched, sl, cnt_out, flags, perm, k, d_out_idx,
+                         d_out_dist, glob, CAP2);
+  if (rc) return rc;
+  rc = wcx_timer_end(ctx, "topk_refine");
+  if (rc) return rc;
+  k_collect_redo<<<(unsigned)((n_rows + NT - 1) / NT), NT, 0, st>>>(0, n_rows, searched, flags, tab, d_redo,
+                                                                   d_nredo, ctx->d_stats);
+  k_redo_plan<<<1, 64, 0, st>>>(tab, d_nredo, d_rtile);
+  k_redo_fill<<<(unsigned)((n_rows + NT - 1) / NT), NT, 0, st>>>(0, n_rows, searched, flags, tab, d_nredo,
+                                                                d_rlist);
+  WCX_HIP(hipGetLastError());
+  rc = wcx_topk_exact_redo_launch(ctx, dXs, B, S, d_redo, d_nredo, d_rtile, d_nredo + 1, d_rlist,
+                                  base + o_rscr, 0, k, d_out_idx, d_out_dist);
+  if (rc) return rc;
+  return wcx_timer_end(ctx, "topk");
 }
 
 int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
@@ -594,11 +1088,11 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // overwhelming probability (mean k/SF of the k nearest fall into the sample; + 10 % for the
   // uneven share of the own chromosome, Poisson tail 1e-6 per row): the estimate admits ~r SF
   // candidates; a row whose estimate fails costs ~0.1 ms in the device-wide redo.
-  int cut_r = 0;
-  if (SF) {
+  auto sample_rank = [&](int nseg) {
+    if (!SF) return 0;
     // smallest r with P(Poisson(lambda) >= r) <= 1e-6 / n_seg,  lambda = 1.1 k / (SF n_seg)
-    const double lambda = 1.1 * (double)k / ((double)SF * n_seg);
-    const double target = 1e-6 / n_seg;
+    const double lambda = 1.1 * (double)k / ((double)SF * nseg);
+    const double target = 1e-6 / nseg;
     double term = exp(-lambda), cdf = 0.0;   // term = P(X = i)
     int i = 0;
     for (; i < 4 * k; ++i) {
@@ -606,13 +1100,26 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       cdf += term;
       term *= lambda / (double)(i + 1);
     }
-    cut_r = i + 1;
-    // the sample must hold several times cut_r candidates and cut_r must be well below k
-    if (cut_r * 2 > k || P_s / n_seg < 16 * (int64_t)cut_r) cut_r = 0;
+    int r = i + 1;
+    // the sample must hold several times r candidates and r must be well below k
+    if (r * 2 > k || P_s / nseg < 16 * (int64_t)r) r = 0;
     // testing: a deliberately unsafe rank makes estimates fail, which the final cut must detect
     // (rows go to the exact kernel; results stay identical)
     const int forced = env_int("WCX_SCREEN_CUT_R", 0);
-    if (forced > 0 && forced < k) cut_r = forced;
+    if (forced > 0 && forced < k) r = forced;
+    return r;
+  };
+  const int cut_r = sample_rank(n_seg);
+  // All rows searched against all rows with a sampled pre-pass available: the symmetric sweep
+  // (half the matrix work; screen_sym.h).  WCX_SCREEN_SYM=0 keeps the one-directional sweep.
+  {
+    int64_t covered = 0;
+    for (const ScreenBlock &sb : blocks) covered += sb.nrows;
+    const int cut_r1 = sample_rank(1);     // (the symmetric sweep has no candidate segments)
+    if (cut_r1 && row_begin == 0 && n_rows == B && covered == B && cfg.tt == 1 && cfg.wpb == 4 &&
+        cfg.ring >= 2 && env_int("WCX_SCREEN_SYM", 1))
+      return screen_sym_path(ctx, dXs, B, S, chr_cum, n_chr, blocks, cfg, SF, cut_r1, slots, k, d_out_idx,
+                             d_out_dist);
   }
   // scratch layout
   size_t off = 0;
@@ -753,7 +1260,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t lds = (size_t)(cfg.ring >= 2 ? cfg.ring : 2) * (size_t)(CTG * NK * 64) * 16 +
                      (size_t)(chunk_groups + 64) * 4;   // + the chunk's visit list
   ScreenArgs a;
-  a.F = F; a.info = info; a.glob = glob; a.perm = perm; a.rowpos = rowpos; a.gmask = gmask;
+  a.F = F; a.Ft = F; a.info = info; a.glob = glob; a.perm = perm; a.rowpos = rowpos; a.gmask = gmask;
   a.blocks = d_blocks; a.sl = sl; a.cnt = cnt_out; a.flags = flags; a.g_state = g_state;
   a.stats = ctx->d_stats; a.row_begin = row_begin; a.n_rows_all = n_rows;
   a.k = k; a.dbg = ctx->debug_flags; a.n_seg = n_seg; a.n_blocks = (int)blocks.size();

@@ -11,6 +11,7 @@ constexpr int NT = 256;      // threads of the helper kernels (prep, merge, refi
 constexpr int CT = 64;       // sweep positions are padded to a multiple of this (gmask granule)
 constexpr int CAP = 1024;    // shortlist capacity per target
 constexpr int LIM = CAP - CT;
+constexpr int CAP2 = 2048;   // list capacity per row in the symmetric sweep (fixed thresholds, no cuts)
 
 struct RowInfo {
   float nb;  // |a~|^2
@@ -24,6 +25,7 @@ struct ScreenGlobals {
   unsigned int e_max, L_max, N_max;  // float bits, finite rows only
   unsigned int n_overflow;
   unsigned int uinv;             // 0xffffffff - min(norm float bits >> 20) over finite rows
+  unsigned int n_tiles;          // symmetric sweep: tiles in use (multiple of 4)
 };
 
 
@@ -42,6 +44,8 @@ struct ScreenArgs {
   const int *perm, *rowpos;
   const unsigned int *gmask;
   const ScreenBlock *blocks;
+  const half8 *Ft;          // fragments the TARGET rows are read from (rowpos positions); = F unless the
+                            // candidates are a separate sample array (symmetric path, pre-pass)
   uint2 *sl;
   int *cnt;
   unsigned int *flags;
@@ -57,6 +61,32 @@ struct ScreenArgs {
                             // sampled pre-pass (estimate from rank cut_k), 2 = final (exact k-th)
   int first, dbg, n_seg, n_blocks;
 };
+
+// Arguments of the symmetric sweep (screen_sym.h).
+struct SymArgs {
+  const half8 *F;             // fragments, tile-major: half8[tile][NK][64]
+  const unsigned int *tinfo;  // [tile][64]: 0..31 float bits of theta = -D/2 (+inf: nothing passes),
+                              //             32..63 row id (-1 = padding)
+  const float *tmin;          // [tile] min theta over the tile's rows
+  const unsigned char *tchr;  // [tile] chromosome of the (pure) tile; 255 = no rows
+  const ScreenGlobals *glob;  // n_tiles
+  uint2 *sl;                  // [row][CAP2]
+  int *cnt;                   // [row] entries appended (device-scope atomic)
+  unsigned int *flags;        // [row] 1 = redo exactly
+  unsigned long long *stats;
+  uint4 *pool;                // records (row, partner position, d~ bits, -) for k_sym_regroup
+  unsigned int *pool_head, *pool_ovf;
+  unsigned int pool_cap;
+  int q0, qstride, n_split;   // target quads q0, q0 + qstride, ...; work items per quad
+  int c0, c1;                 // streamed tiles [c0, c1) of the launch
+  int excl;                   // 1 = no other work item of this launch or a concurrent one owns the same
+                              // target rows: column-direction hits go straight to the lists
+  int glist_cap;              // ints reserved for the visit list in LDS
+  int dbg;
+};
+int wcx_sym_launch_k1(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_sym_launch_k2(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_sym_launch_k3(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
 
 // Screen kernel configuration: K = 16 nk, ctg candidate sub-tiles per iteration, tt target tiles
 // per wave, wpb waves per workgroup (targets per workgroup = 32 tt wpb), lb = waves per SIMD the
@@ -82,4 +112,4 @@ int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTa
                       int64_t row_begin, int64_t n_rows, const unsigned char *searched,
                       const uint2 *sl, const int *cnt_out, const unsigned int *flags,
                       const int *perm, int k, int32_t *d_out_idx, double *d_out_dist,
-                      ScreenGlobals *glob);
+                      ScreenGlobals *glob, int sl_stride = CAP);

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * WPB, LBW) void k_screen(
     const int64_t ttile = tpos[tt] >> 5;
     const int trl = tpos[tt] & 31;
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) th[tt][ks] = A.F[(ttile * NK + ks) * 64 + trl + 32 * hf];
+    for (int ks = 0; ks < NK; ++ks) th[tt][ks] = A.Ft[(ttile * NK + ks) * 64 + trl + 32 * hf];
     const int c0 = (A.first || !tvalid[tt]) ? 0 : A.cnt[wg_srow + tl[tt]];
     cntr[tt] = c0 & CNT_MASK;     // identical in the target's two lanes
     est[tt] = (c0 >> 30) & 1;
