@@ -243,7 +243,7 @@ class Workload:
                 # ratios of this rank's target rows, then every rank gets the whole tables
                 idx_l, dist_l, nr_l, _ = wd.newref_sharded(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
                                                            self.backend, self.rank, self.world, out=P["bufs"])
-                if self.args.debug_flags & 3:            # (ablations leave garbage neighbour tables)
+                if self.args.debug_flags & 27:           # (ablations leave garbage neighbour tables)
                     ctx.timer_tag("")
                     ctx.sync()
                     if record:
@@ -300,21 +300,25 @@ class Workload:
             nk = next(v for v in nk_list if 16 * v >= S + 4)   # same rule as wcx_topk_screen_launch
             flops = 2.0 * S * pairs_A
             achieved = flops / (screen_ms * 1e-3) / 1e12
-            r = {"kernel": "k_screen of the autosomal pass (v_mfma_f32_32x32x16_f16, fp16 hi plane, fp32 "
-                           "acc) + fused top-k filter", "bound": "mfma", "achieved": achieved,
+            sym = stats.get("sym_gates", 0) > 0
+            r = {"kernel": ("k_screen_sym (symmetric sweep: every tile pair once, both directions) + sampled "
+                            "pre-pass k_screen + final cut" if sym else "k_screen") +
+                           " of the autosomal pass (v_mfma_f32_32x32x16_f16, fp16 hi plane, fp32 acc) + fused "
+                           "top-k filter", "bound": "mfma", "achieved": achieved,
                  "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": screen_ms,
-                 "executed_tflops": 2.0 * nk * 16 * pairs_A / (screen_ms * 1e-3) / 1e12,
+                 "executed_tflops": (0.5 + 1.0 / 16 if sym else 1.0) * 2.0 * nk * 16 * pairs_A / (screen_ms * 1e-3) / 1e12,
                  "prep_ms": self.mean_ms("A:topk_prep"), "refine_ms": self.mean_ms("A:topk_refine"),
                  "topk_total_ms": k_ms, "pairs_per_launch": pairs_A,
                  "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": self.fb_rows,
                  "compactions": stats["compactions"], "appends": stats["appends"],
                  "refined_pairs": stats["refined"], "sym_gates": stats.get("sym_gates", 0),
-                 "sym_row_appends": stats.get("sym_row_appends", 0), "pre_ms": self.mean_ms("A:topk_pre"),
+                 "sym_row_appends": stats.get("sym_row_appends", 0), "sym_counts": stats["phase_cycles"][:4], "pre_ms": self.mean_ms("A:topk_pre"),
                  "kernel_ms_note": "wall time of one whole sweep of the A pass (HIP events on the launch "
-                                   "stream, second stream joined by an event); the target blocks sweep in "
-                                   "two halves on two concurrent streams, so rocprofv3's average launch "
-                                   "duration x launches per sweep / 2 is the figure to compare with",
+                                   "stream): symmetric path = pre-pass k_screen + k_sym_setup + ONE persistent "
+                                   "k_screen_sym launch + k_sym_regroup + k_sym_final (rocprofv3: the sum of "
+                                   "those dispatches); one-directional path = chunk launches on two "
+                                   "concurrent streams (average launch duration x launches per sweep / 2)",
                  "attainable_note": "the dense-f16 peak is not attainable on random data: a bare "
                                     "LDS-fed MFMA loop with DMA staging and no epilogue is power-limited "
                                     "to 1.1-1.35 PFLOP/s on this chip, box to box (1.9-2.0 on all-zero "

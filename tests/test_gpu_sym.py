@@ -22,6 +22,11 @@ def _oracle(X, cum, k):
     return CO.get_reference_rows_threaded(Xs, cum, 0, cum[-1], k)
 
 
+@pytest.fixture(autouse=True)
+def _force_sym(monkeypatch):
+    monkeypatch.setenv("WCX_SCREEN_SYM", "2")      # also where the default policy prefers the other sweep
+
+
 def _run(nt, X, cum, k):
     from wisecondorx_amd import _lib
     idx, dist = nt.get_ref_for_rows(X, cum, k, 0, cum[-1], mode=2)
@@ -57,21 +62,21 @@ def test_symmetric_sweep_vs_c_oracle(nt, mb, S, k, sf, monkeypatch):
 
 
 def test_symmetric_sweep_small_chunks_and_splits(nt, monkeypatch):
-    """Many launches (tiny chunks of streamed tiles), several work items per target quad, one
-    stream: the tile-pair bookkeeping (who owns which pair, per-item candidate ranges) must cover
-    every pair exactly once."""
+    """Many chunks of streamed tiles, several work items per target quad (records instead of direct
+    appends), more workgroups than work: the tile-pair bookkeeping (who owns which pair, per-item
+    candidate ranges, the per-quad ordering of exclusive items) must cover every pair exactly once."""
     from wisecondorx_amd.synth import corrected_matrix
     monkeypatch.setenv("WCX_SCREEN_SAMPLE", "8")
     X, mbpc, cum = corrected_matrix([1900, 1700, 1500, 1300, 1100, 900, 700], 100, seed=77)
     k = 100
     oi, od = _oracle(X, cum, k)
-    for chunk_kb, split, streams in ((256, 3, 1), (512, 0, 2), (64, 2, 2)):
+    for chunk_kb, split, fill in ((256, 3, 1), (512, 0, 1), (64, 2, 1), (224, 0, 0), (160, 0, 0)):
         monkeypatch.setenv("WCX_SYM_CHUNK_KB", str(chunk_kb))
         monkeypatch.setenv("WCX_SYM_SPLIT", str(split))
-        monkeypatch.setenv("WCX_SCREEN_STREAMS", str(streams))
+        monkeypatch.setenv("WCX_SYM_FILL", str(fill))     # 0: never split -> every item exclusive
         idx, dist, st = _run(nt, X, cum, k)
         assert st["sym_gates"] > 0
-        assert np.array_equal(idx, oi) and np.array_equal(dist, od), (chunk_kb, split, streams)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), (chunk_kb, split, fill)
 
 
 def test_symmetric_sweep_refuted_estimates_are_redone(nt, monkeypatch):

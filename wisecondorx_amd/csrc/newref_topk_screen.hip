@@ -739,7 +739,9 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   // target quad over several work items (the high, hub-free tiles)
   const unsigned int pool_cap = (unsigned int)(n_rows * 1024 < 200000000ll ? n_rows * 1024 : 200000000ll);
   const size_t o_pool = carve((size_t)pool_cap * 16);
-  const size_t o_phead = carve(256);
+  const size_t o_phead = carve(256);      // pool head | pool overflow | queue head
+  const size_t o_desc = carve(256 * sizeof(SymDesc));
+  const size_t o_seq = carve((size_t)(NTb / 4 + 1) * 4);
   const size_t o_sl = carve((size_t)n_rows * CAP2 * 8);
   const size_t o_cnt = carve((size_t)n_rows * 4);
   const size_t o_gst = carve((size_t)n_rows * 4);
@@ -778,6 +780,8 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   float *Dest = reinterpret_cast<float *>(base + o_dest);
   uint4 *pool = reinterpret_cast<uint4 *>(base + o_pool);
   unsigned int *pool_head = reinterpret_cast<unsigned int *>(base + o_phead);
+  SymDesc *d_desc = reinterpret_cast<SymDesc *>(base + o_desc);
+  int *d_seq = reinterpret_cast<int *>(base + o_seq);
   uint2 *sl = reinterpret_cast<uint2 *>(base + o_sl);
   int *cnt_out = reinterpret_cast<int *>(base + o_cnt);
   float *g_state = reinterpret_cast<float *>(base + o_gst);
@@ -899,72 +903,64 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   rc = wcx_timer_end(ctx, "topk_pre");
   if (rc) return rc;
 
-  // ---- symmetric sweep: one launch per chunk of streamed tiles and stream.  The target quads are
-  // dealt to two streams by parity: the tails of one stream's launches are filled by the other's
-  // workgroups, and as long as a launch has ONE work item per quad, a row's counter has a single
-  // writer at any time (launches of a stream run in order) -- column-direction hits then go straight
-  // to the lists with register counters.  Launches high in the order have few target quads left
-  // above their chunk: there a quad is split over several work items, which write records instead.
+  // ---- symmetric sweep: ONE persistent launch; the workgroups pull (chunk, quad) work items from a
+  // device-side queue in chunk-major order (k_screen_sym).  As long as a chunk has at least `fill`
+  // quads above it, a quad is one work item per chunk and its column-direction hits go straight to
+  // the lists (exclusive items, ordered per quad); the chunks high in the order, which few quads
+  // still stream, split a quad over several items that write records instead.
   {
     int64_t Cz = ((int64_t)env_int("WCX_SYM_CHUNK_KB", NK > 16 ? 8192 : 3072) << 10) / ((int64_t)NK * 1024);
     Cz = Cz / 8 * 8;
     if (Cz < 32) Cz = 32;
     if (Cz > 8192) Cz = 8192;
-    if (!ctx->sweep_stream) {
-      WCX_HIP(hipStreamCreateWithFlags(&ctx->sweep_stream, hipStreamNonBlocking));
-      WCX_HIP(hipEventCreateWithFlags(&ctx->ev_sweep0, hipEventDisableTiming));
-      WCX_HIP(hipEventCreateWithFlags(&ctx->ev_sweep1, hipEventDisableTiming));
-    }
-    const int n_streams = env_int("WCX_SCREEN_STREAMS", 2) == 2 ? 2 : 1;
-    hipStream_t st2 = n_streams == 2 ? ctx->sweep_stream : st;
-    if (n_streams == 2) {
-      WCX_HIP(hipEventRecord(ctx->ev_sweep0, st));
-      WCX_HIP(hipStreamWaitEvent(st2, ctx->ev_sweep0, 0));
-    }
+    while ((NTb + Cz - 1) / Cz > 256) Cz *= 2;                   // descriptor table: <= 256 chunks
     const int glist_cap = (int)((Cz / CTG + 64 + 3) / 4 * 4);
     const size_t lds = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)cfg.ring * CTG * 256 +
-                       (size_t)glist_cap * 4 + (size_t)4 * 64 * 16 +
-                       (size_t)4 * (NK <= 8 ? 1 : 2) * 64 * 16;   // visit list, staged records, accumulator rounds
+                       (size_t)glist_cap * 4 + (size_t)4 * 64 * 16;   // visit list, staged records
+    const int NQb = (int)(NTb / 4);
+    const int split_env = env_int("WCX_SYM_SPLIT", 0);
+    const int fill = env_int("WCX_SYM_FILL", 1) * slots;        // work items a chunk should offer
+    std::vector<SymDesc> descs;
+    int total = 0;
+    for (int64_t c0 = 0; c0 < NTb; c0 += Cz) {
+      SymDesc d;
+      d.c0 = (int)c0;
+      d.c1 = (int)(c0 + Cz < NTb ? c0 + Cz : NTb);
+      d.q_first = (int)(c0 / 4);
+      d.n_q = NQb - d.q_first;
+      int n_split = d.n_q >= fill ? 1 : (fill + d.n_q - 1) / d.n_q;
+      const int max_split = (d.c1 - d.c0) / CTG / 8 > 1 ? (d.c1 - d.c0) / CTG / 8 : 1;
+      if (n_split > max_split) n_split = max_split;
+      if (split_env > 0) n_split = split_env < max_split ? split_env : max_split;
+      if (n_split < 1) n_split = 1;
+      if (!descs.empty() && n_split < descs.back().n_split) n_split = descs.back().n_split;   // (monotone:
+      d.n_split = n_split;                          //  a quad's exclusive items are its chunks 0 .. L - 1)
+      d.item_base = total;
+      d.index = (int)descs.size();
+      d.pad = 0;
+      total += d.n_q * d.n_split;
+      descs.push_back(d);
+    }
+    rc = wcx_upload_small(ctx, d_desc, descs.data(), descs.size() * sizeof(SymDesc));
+    if (rc) return rc;
+    WCX_HIP(hipMemsetAsync(d_seq, 0, (size_t)(NQb + 1) * 4, st));
     SymArgs a;
     a.F = F; a.tinfo = tinfo; a.tmin = tmin; a.tchr = tchr; a.glob = glob; a.sl = sl; a.cnt = cnt_out;
     a.flags = flags; a.stats = ctx->d_stats; a.dbg = ctx->debug_flags;
     a.pool = pool; a.pool_head = pool_head; a.pool_ovf = pool_head + 1; a.pool_cap = pool_cap;
+    a.queue_head = pool_head + 2;
+    a.desc = d_desc; a.n_desc = (int)descs.size(); a.total_items = total; a.seq = d_seq;
     a.glist_cap = glist_cap;
-    const int NQb = (int)(NTb / 4);
-    const int split_env = env_int("WCX_SYM_SPLIT", 0);
-    const int fill = env_int("WCX_SYM_FILL", 1) * slots;        // work items a chunk should offer
-    for (int64_t c0 = 0; c0 < NTb; c0 += Cz) {
-      const int64_t c1 = c0 + Cz < NTb ? c0 + Cz : NTb;
-      a.c0 = (int)c0; a.c1 = (int)c1;
-      const int q_first = (int)(c0 / 4);
-      const int n_active = NQb - q_first;
-      int n_split = n_active >= fill ? 1 : (fill + n_active - 1) / n_active;
-      const int max_split = (int)((c1 - c0) / CTG / 8) > 1 ? (int)((c1 - c0) / CTG / 8) : 1;
-      if (n_split > max_split) n_split = max_split;
-      if (split_env > 0) n_split = split_env < max_split ? split_env : max_split;
-      if (n_split < 1) n_split = 1;
-      a.n_split = n_split;
-      a.excl = n_split == 1 ? 1 : 0;
-      a.qstride = n_streams;
-      for (int h = 0; h < n_streams; ++h) {
-        a.q0 = q_first + h;
-        const int n_q = (n_active - h + n_streams - 1) / n_streams;
-        if (n_q <= 0) continue;
-        const int e = sym_dispatch(NK, CTG, cfg.lb, cfg.ring, a, (unsigned)(n_q * n_split), lds, h ? st2 : st);
-        if (e < 0) {
-          wcx_set_error("symmetric screen kernel nk=%d ctg=%d lb=%d ring=%d is not instantiated", NK, CTG,
-                        cfg.lb, cfg.ring);
-          return (int)WCX_ERR_UNSUPPORTED;
-        }
-        if (e != 0) {
-          wcx_set_error("symmetric screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-          return (int)WCX_ERR_HIP;
-        }
-      }
+    const int grid = total < slots ? total : slots;
+    const int e = sym_dispatch(NK, CTG, cfg.lb, cfg.ring, a, (unsigned)grid, lds, st);
+    if (e < 0) {
+      wcx_set_error("symmetric screen kernel nk=%d ctg=%d lb=%d ring=%d is not instantiated", NK, CTG, cfg.lb,
+                    cfg.ring);
+      return (int)WCX_ERR_UNSUPPORTED;
     }
-    if (n_streams == 2) {
-      WCX_HIP(hipEventRecord(ctx->ev_sweep1, st2));
-      WCX_HIP(hipStreamWaitEvent(st, ctx->ev_sweep1, 0));
+    if (e != 0) {
+      wcx_set_error("symmetric screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+      return (int)WCX_ERR_HIP;
     }
     k_sym_regroup<<<2048, NT, 0, st>>>(pool, pool_head, pool_head + 1, pool_cap, n_rows, sl, cnt_out, flags);
   }
@@ -1116,8 +1112,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     int64_t covered = 0;
     for (const ScreenBlock &sb : blocks) covered += sb.nrows;
     const int cut_r1 = sample_rank(1);     // (the symmetric sweep has no candidate segments)
+    // WCX_SCREEN_SYM: 0 = never, 1 = where it pays (default), 2 = whenever possible (tests).  Small K
+    // is bound by the appends, not by the matrix pipe, and the symmetric sweep's hit path is the dearer
+    // one (15 kb x 100 samples, K = 112: 19.2 ms against 11.5 ms; x 500 samples, K = 512: 25.2 against 31.5)
+    const int sym_mode = env_int("WCX_SCREEN_SYM", 1);
     if (cut_r1 && row_begin == 0 && n_rows == B && covered == B && cfg.tt == 1 && cfg.wpb == 4 &&
-        cfg.ring >= 2 && env_int("WCX_SCREEN_SYM", 1))
+        cfg.ring >= 2 && (sym_mode == 2 || (sym_mode == 1 && NK >= 20)))
       return screen_sym_path(ctx, dXs, B, S, chr_cum, n_chr, blocks, cfg, SF, cut_r1, slots, k, d_out_idx,
                              d_out_dist);
   }

@@ -62,6 +62,13 @@ struct ScreenArgs {
   int first, dbg, n_seg, n_blocks;
 };
 
+// One chunk of streamed tiles of the symmetric sweep: work items = (quads q_first .. q_first + n_q - 1)
+// x n_split shares of the chunk; n_split == 1: exclusive items (see k_screen_sym), `index` = the
+// chunk's number = the position of the item among the exclusive items of its quad.
+struct SymDesc {
+  int c0, c1, q_first, n_q, n_split, item_base, index, pad;
+};
+
 // Arguments of the symmetric sweep (screen_sym.h).
 struct SymArgs {
   const half8 *F;             // fragments, tile-major: half8[tile][NK][64]
@@ -77,10 +84,10 @@ struct SymArgs {
   uint4 *pool;                // records (row, partner position, d~ bits, -) for k_sym_regroup
   unsigned int *pool_head, *pool_ovf;
   unsigned int pool_cap;
-  int q0, qstride, n_split;   // target quads q0, q0 + qstride, ...; work items per quad
-  int c0, c1;                 // streamed tiles [c0, c1) of the launch
-  int excl;                   // 1 = no other work item of this launch or a concurrent one owns the same
-                              // target rows: column-direction hits go straight to the lists
+  const SymDesc *desc;        // chunk descriptors, in queue order
+  int n_desc, total_items;
+  unsigned int *queue_head;   // next work item
+  int *seq;                   // [quad] exclusive items of the quad that have finished
   int glist_cap;              // ints reserved for the visit list in LDS
   int dbg;
 };

@@ -29,37 +29,38 @@
 
 namespace {
 
-// NK = k-steps of 16, CTG = streamed tiles per iteration, LBW = waves per SIMD budgeted,
-// RING = LDS-DMA ring slots.  A workgroup = 4 waves = 4 consecutive target tiles (a "quad").
-template <int NK, int CTG, int LBW, int RING>
-__global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
+struct SymCounters { unsigned int n_app, n_row, n_slow, n_cg, n_rg, n_ce, n_re; };
+
+// ONE work item: target quad `quad` (4 tiles, one per wave) against the streamed tiles of chunk
+// [c0, c1) that lie below its tiles -- share `split` of `n_split`.  excl: this item is the only
+// writer of its rows' counters while it runs (see k_screen_sym).
+// NK = k-steps of 16, CTG = streamed tiles per iteration, RING = LDS-DMA ring slots.
+template <int NK, int CTG, int RING>
+__device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, int *s_nlist_p, int quad,
+                                         int split, int n_split, int c0, int c1, int excl,
+                                         SymCounters &C) {
   constexpr int WPB = 4;
   constexpr int TILE_H8 = CTG * NK * 64;             // half8 elements per streamed group
   constexpr int NPIECE = CTG * NK + CTG;             // DMA pieces per group: fragments + tile info
   constexpr int NPW = (NPIECE + WPB - 1) / WPB;      // pieces per wave and group
   constexpr int STG = 64;                            // staged records per wave
-  constexpr int DQ = NK <= 8 ? 1 : 2;                // accumulator quarters per LDS round (hit path)
   static_assert(RING >= 2 && (RING - 2) * NPW <= 63, "vmcnt range");
-  extern __shared__ __align__(16) unsigned char smem[];
   half8 *sbuf = reinterpret_cast<half8 *>(smem);                                   // [RING][TILE_H8]
   unsigned int *tinf = reinterpret_cast<unsigned int *>(smem + RING * TILE_H8 * 16);   // [RING][CTG][64]
   int *glist = reinterpret_cast<int *>(tinf + RING * CTG * 64);
-  __shared__ int s_nlist;
+  int &s_nlist = *s_nlist_p;
 
   const int n_tiles = (int)A.glob->n_tiles;
-  const int item = (int)blockIdx.x;
-  const int quad = A.q0 + (item / A.n_split) * A.qstride, split = item % A.n_split;
   const int t0 = quad * 4;
-  if (t0 >= n_tiles) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, hf = lane >> 5;
   const int t = t0 + wave;                            // this wave's target tile
-  // this work item's share of the launch's candidate groups, below the quad's highest tile
-  const int ng = (A.c1 - A.c0) / CTG;
-  const int per = (ng + A.n_split - 1) / A.n_split;
-  const int g_lo = A.c0 / CTG + split * per;
-  int g_hi = g_lo + per < A.c1 / CTG ? g_lo + per : A.c1 / CTG;
+  // this work item's share of the chunk's candidate groups, below the quad's highest tile
+  const int ng = (c1 - c0) / CTG;
+  const int per = (ng + n_split - 1) / n_split;
+  const int g_lo = c0 / CTG + split * per;
+  int g_hi = g_lo + per < c1 / CTG ? g_lo + per : c1 / CTG;
   {
     const int top = t0 + 3 < n_tiles ? t0 + 3 : n_tiles;     // groups whose first tile is < top
     const int lim = (top + CTG - 1) / CTG;
@@ -112,11 +113,11 @@ __global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
   const int rowj = (int)A.tinfo[(int64_t)t * 64 + 32 + l32];
   const int mychr = (int)A.tchr[t] & 31;
   const unsigned int posj = (unsigned int)(t * 32 + l32);
-  unsigned int n_app = 0, n_row = 0, n_slow = 0;
-
+  
   // column-direction list of my row (exclusive launches: register counter, see below)
   uint2 *mine = A.sl + (int64_t)(rowj >= 0 ? rowj : 0) * CAP2;
-  int cntr = (A.excl && rowj >= 0) ? A.cnt[rowj] : 0;
+  // (device-scope accesses: the previous item of this quad may have run on another XCD)
+  int cntr = (excl && rowj >= 0) ? __hip_atomic_load(&A.cnt[rowj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
   // Records (row, partner position, d~ bits): hits that may not touch a row's counter directly
   // are staged per wave in LDS and flushed to a global pool with ONE returning atomic per STG
   // records; k_sym_regroup distributes them after the sweep.
@@ -259,18 +260,20 @@ __global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
       m = fmaxf(m, acc[s][15]);
       const bool col_gate = __any(m >= thj), row_gate = __any(m >= thc[s]);
       if (!(col_gate || row_gate) || (A.dbg & 1)) continue;
-      ++n_slow;
+      ++C.n_slow;
+      C.n_cg += col_gate ? 1u : 0u;
+      C.n_rg += row_gate ? 1u : 0u;
       const unsigned int *ti = tinf + (slot * CTG + s) * 64;
       // per-lane pass bits, bit (15 - r) = output r: column direction (my row is the target, the
       // streamed rows are candidates) and row direction (a streamed row is the target)
       unsigned int pm = 0, rm = 0;
-      if (col_gate) {
+      if (col_gate && !(A.dbg & 16)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           pm = __builtin_amdgcn_alignbit(pm, ~__float_as_uint(acc[s][r] - thj), 31);
         pm &= 0xffffu;
       }
-      if (row_gate) {
+      if (row_gate && !(A.dbg & 8)) {
 #pragma unroll
         for (int a4 = 0; a4 < 4; ++a4) {
           const uint4 tv = *reinterpret_cast<const uint4 *>(ti + 8 * a4 + 4 * hf);
@@ -284,14 +287,16 @@ __global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
       const unsigned int both = wcx::wave_or_u32(pm | (rm << 16));
       if (both == 0) continue;
       const unsigned int anym = both & 0xffffu, rany = both >> 16;
+      C.n_ce += anym ? 1u : 0u;
+      C.n_re += rany ? 1u : 0u;
       const unsigned int pc = (unsigned int)__popc(pm), rc = (unsigned int)__popc(rm);
-      n_app += pc + rc;
-      n_row += rc;
+      C.n_app += pc + rc;
+      C.n_row += rc;
       // destinations.  Exclusive launches: column hits go straight to my row's list under a register
       // counter (the target's two lanes l, l + 32 swap their pass counts); everything else becomes
       // records -- one reservation per event, column records first.
       int ofs = 0, coff = 0, roff = 0, rtotal = 0;
-      if (A.excl) {
+      if (excl) {
         if (anym) {
           const auto pcs = __builtin_amdgcn_permlane32_swap(pc, pc, false, false);
           ofs = cntr + (hf ? (int)pcs[0] : 0);
@@ -312,59 +317,104 @@ __global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
         roff = b0 + tc + (incl >> 16) - (int)rc;
       }
       const unsigned int cposb = (unsigned int)((g * CTG + s) * 32 + 4 * hf);
-      // The accumulators go through LDS, DQ quarters (4 outputs) at a time, so that every lane can
-      // walk ITS OWN hits (a register file cannot be indexed per lane): iterations = the largest
-      // number of hits of one lane in the round, not the number of outputs with a hit somewhere.
-      float4 *dump = reinterpret_cast<float4 *>(stg_all + WPB * STG) + wave * (DQ * 64);
-      const float *dumpf = reinterpret_cast<const float *>(dump);
+      // One scalar-skipped, fully unrolled pass over the 16 outputs (static register indices; a
+      // per-lane walk of the hits through LDS was measured slower: its dependent LDS reads are
+      // exposed, 2 000 SIMD cycles per event at K = 512).
+      if (anym) {
 #pragma unroll
-      for (int h0 = 0; h0 < 4; h0 += DQ) {
-        const unsigned int hmask = ((0xffffu >> (4 * h0)) & ~(0xffffu >> (4 * (h0 + DQ)))) & 0xffffu;
-        if (((anym | rany) & hmask) == 0) continue;         // wave-uniform
-#pragma unroll
-        for (int q4 = 0; q4 < DQ; ++q4)
-          dump[q4 * 64 + lane] = make_float4(acc[s][4 * (h0 + q4) + 0], acc[s][4 * (h0 + q4) + 1],
-                                             acc[s][4 * (h0 + q4) + 2], acc[s][4 * (h0 + q4) + 3]);
-        unsigned int mc = pm & hmask, mr = rm & hmask;
-        while (__any((mc | mr) != 0)) {
-          if (mc) {
-            const int b = 31 - __builtin_clz(mc);
-            mc ^= 1u << b;
-            const int rl = 15 - b - 4 * h0;                  // output within the round
-            const float v = dumpf[((rl >> 2) * 64 + lane) * 4 + (rl & 3)];
-            const unsigned int cp = cposb + (unsigned int)(8 * ((15 - b) >> 2) + ((15 - b) & 3));
-            if (A.excl) {
-              if (ofs < CAP2) mine[ofs] = make_uint2(__float_as_uint(-2.f * v), cp);
-              ++ofs;
-            } else {
-              put(coff, make_uint4((unsigned int)rowj, cp, __float_as_uint(-2.f * v), 0u), rtotal);
-              ++coff;
+        for (int r = 0; r < 16; ++r) {
+          if (anym & (0x8000u >> r)) {
+            asm volatile("" ::: "memory");                 // (keeps the two tests separate)
+            if (pm & (0x8000u >> r)) {
+              const unsigned int cp = cposb + (unsigned int)(8 * (r >> 2) + (r & 3));
+              if (excl) {
+                if (ofs < CAP2) mine[ofs] = make_uint2(__float_as_uint(-2.f * acc[s][r]), cp);
+                ++ofs;
+              } else {
+                put(coff, make_uint4((unsigned int)rowj, cp, __float_as_uint(-2.f * acc[s][r]), 0u), rtotal);
+                ++coff;
+              }
             }
           }
-          if (mr) {
-            const int b = 31 - __builtin_clz(mr);
-            mr ^= 1u << b;
-            const int r = 15 - b, rl = r - 4 * h0;
-            const float v = dumpf[((rl >> 2) * 64 + lane) * 4 + (rl & 3)];
-            const unsigned int rowi = ti[32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
-            put(roff, make_uint4(rowi, posj, __float_as_uint(-2.f * v), 0u), rtotal);
-            ++roff;
+        }
+      }
+      if (rany) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (rany & (0x8000u >> r)) {
+            asm volatile("" ::: "memory");
+            if (rm & (0x8000u >> r)) {
+              const unsigned int rowi = ti[32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
+              put(roff, make_uint4(rowi, posj, __float_as_uint(-2.f * acc[s][r]), 0u), rtotal);
+              ++roff;
+            }
           }
         }
       }
     }
   }
   flush();
-  if (A.excl && hf == 0 && rowj >= 0) {
-    A.cnt[rowj] = cntr;
+  if (excl && hf == 0 && rowj >= 0) {
+    __hip_atomic_store(&A.cnt[rowj], cntr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cntr > CAP2) A.flags[rowj] = 1u;
   }
+}
+
+// Persistent kernel: the workgroups pull work items (chunk-major: all quads above chunk 0, then
+// chunk 1, ...) from a device-side queue, so the sweep has no launch boundaries -- no partly filled
+// last rounds -- while the workgroups running at any time still stream the same one or two chunks
+// (L2 sharing).  Exclusive items of one quad (its chunks 0, 1, 2, ...) are ordered by a per-quad
+// sequence counter: item (quad, l) starts after (quad, l - 1) has published its rows' counters
+// (write-through stores, vmcnt(0), then the counter: device-scope on both sides).  A waiting item
+// only ever waits for an item that was dequeued before it, so the scheme cannot deadlock.
+// LBW = waves per SIMD budgeted.
+template <int NK, int CTG, int LBW, int RING>
+__global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int s_nlist, s_item, s_desc;
+  const int tid = threadIdx.x;
+  const int n_tiles = (int)A.glob->n_tiles;
+  SymCounters C = {0, 0, 0, 0, 0, 0, 0};
+  for (;;) {
+    __syncthreads();                                   // everybody is done with the previous item
+    if (tid == 0) s_item = (int)atomicAdd(A.queue_head, 1u);
+    __syncthreads();
+    const int item_g = s_item;
+    if (item_g >= A.total_items) break;
+    if (tid < A.n_desc && item_g >= A.desc[tid].item_base &&
+        item_g < A.desc[tid].item_base + A.desc[tid].n_q * A.desc[tid].n_split)
+      s_desc = tid;
+    __syncthreads();
+    const SymDesc d = A.desc[s_desc];
+    const int item = item_g - d.item_base;
+    const int quad = d.q_first + item / d.n_split, split = item % d.n_split;
+    if (quad * 4 >= n_tiles) continue;                 // (the tables are sized for a tile bound)
+    const int excl = d.n_split == 1 ? 1 : 0;
+    if (excl) {
+      if (tid == 0) {
+        while (__hip_atomic_load(&A.seq[quad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != d.index)
+          __builtin_amdgcn_s_sleep(16);
+      }
+      __syncthreads();
+    }
+    sym_item<NK, CTG, RING>(A, smem, &s_nlist, quad, split, d.n_split, d.c0, d.c1, excl, C);
+    if (excl) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's counter stores have left
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&A.seq[quad], d.index + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   if (A.stats) {
-    const int tot_a = wcx::wave_sum_i((int)n_app), tot_r = wcx::wave_sum_i((int)n_row);
+    const int lane = tid & 63;
+    const int tot_a = wcx::wave_sum_i((int)C.n_app), tot_r = wcx::wave_sum_i((int)C.n_row);
     if (lane == 0) {
       atomicAdd(&A.stats[4], (unsigned long long)tot_a);
       atomicAdd(&A.stats[7], (unsigned long long)tot_r);
-      atomicAdd(&A.stats[6], (unsigned long long)n_slow);
+      atomicAdd(&A.stats[6], (unsigned long long)C.n_slow);
+      atomicAdd(&A.stats[8], (unsigned long long)C.n_cg);
+      atomicAdd(&A.stats[9], (unsigned long long)C.n_rg);
+      atomicAdd(&A.stats[10], (unsigned long long)C.n_ce);
+      atomicAdd(&A.stats[11], (unsigned long long)C.n_re);
     }
   }
 }
