@@ -251,6 +251,8 @@ class Workload:
                         self.ms["A:topk_screen"].append(ctx.kernel_ms("A:topk_screen"))
                         self.ms["A:topk_pre"].append(ctx.kernel_ms("A:topk_pre"))
                     return
+                if record and self.world > 1:
+                    torch.cuda.synchronize()             # (the gather's own time, not the drain of the search)
                 t0 = time.perf_counter()
                 idx, dist_, nr = wd.gather_reference3(idx_l, dist_l, nr_l, P["B"], self.world, self.backend)
                 if record and self.world > 1:

@@ -330,6 +330,77 @@ def golden_prep_filter():
     save("prep_filter.npz", **out)
 
 
+def golden_mask_skew():
+    """The prep_filter cohort (the F / M passes' PCA-distance filter drops an AUTOSOMAL bin after the
+    A pass saved its mask) through the reference's WHOLE newref, then its predict merge on one
+    sample: what does upstream do with the skewed reference it has just built?  Recorded: the three
+    masks, and the outcome of main.py:232-275 -- results_r/z/w post-process (every bin after the
+    dropped one shifted), results_nr RAISES IndexError in get_post_processed_result
+    (predict_control.py:50: the merged null-ratio table has sum(mask.F) rows, ref_sizes one entry per
+    merged result).  Upstream cannot predict on such a reference."""
+    binsize = 4000000
+    co = Cohort(binsize, struct_seed=21, female_y=0.1)
+    samples, genders = co.cohort(28, seed0=700, reads=4e6)
+    rng = np.random.default_rng(9)
+    sd = 1.6
+    spec = [(2, 10, "FM"), (5, 7, "F"), (6, 7, "F"), (7, 9, "F"), (8, 3, "F"), (9, 3, "M"),
+            (10, 3, "M"), (11, 5, "M"), (12, 5, "M"), (3, 5, "F"), (4, 5, "F"), (13, 5, "F"),
+            (24, 4, "M"), (23, 11, "F")]
+    for c, b, who in spec:          # (same perturbation as golden_prep_filter)
+        for i, s in enumerate(samples):
+            if genders[i] in who:
+                s[str(c)][b] = int(s[str(c)][b] * np.exp(rng.normal(0, sd)))
+    tmp = tempfile.mkdtemp(prefix="wcx_golden_skew_")
+    infiles = []
+    for i, s in enumerate(samples):
+        p = os.path.join(tmp, "s{}.npz".format(i))
+        write_sample(p, s, binsize)
+        infiles.append(p)
+    args = argparse.Namespace(infiles=infiles, outfile=os.path.join(tmp, "ref.npz"), nipt=False,
+                              yfrac=0.004, plotyfrac=None, refsize=40, binsize=binsize, cpus=1)
+    np.random.seed(5)
+    random.seed(5)
+    try:
+        ref_main.tool_newref(args)
+    except NameError as e:          # main.py:135 qc_reference never imported
+        print("expected reference bug:", e)
+    ref = np.load(args.outfile, encoding="latin1", allow_pickle=True)
+    n_aut = int(np.sum(ref["bins_per_chr"]))
+    out = {"cohort_counts": np.stack([np.concatenate([s[str(c)] for c in range(1, 25)])
+                                      for s in samples]),
+           "cohort_genders": np.array(genders), "cohort_bpc": np.array(co.bpc),
+           "mask": ref["mask"], "mask_F": ref["mask.F"], "mask_M": ref["mask.M"]}
+    assert int(ref["mask"][:n_aut].sum()) > int(ref["mask.F"][:n_aut].sum())
+    pargs = argparse.Namespace(maskrepeats=5, minrefbins=10)
+    sample0 = co.sample(9002, "F", reads=4e6, cnv=[(7, 5, 15, 0.5)])
+    out["test_counts"] = np.concatenate([sample0[str(c)] for c in range(1, 25)])
+    gender = ref_pt.predict_gender(sample0, ref["trained_cutoff"])
+    sample = ref_ot.gender_correct({k: v.copy() for k, v in sample0.items()}, gender)
+    rA = ref_pc.normalize(pargs, sample, ref, "A")
+    rG = ref_pc.normalize(pargs, sample, ref, gender)
+    nr_aut = ref["null_ratios"]
+    nr_gon = ref["null_ratios.{}".format(gender)][len(nr_aut):]
+    rem_input = {"args": pargs, "binsize": int(ref["binsize"]), "ref_gender": gender,
+                 "mask": ref["mask.{}".format(gender)],
+                 "bins_per_chr": ref["bins_per_chr.{}".format(gender)]}
+    ref_sizes = np.append(rA[3], rG[3])
+    null_ratios = np.array([x.tolist() for x in nr_aut] + [x.tolist() for x in nr_gon], dtype=object)
+    outcome = {}
+    for nm, v in (("results_r", np.append(rA[0], rG[0])), ("results_nr", null_ratios)):
+        try:
+            ref_pc.get_post_processed_result(pargs, v, ref_sizes, rem_input)
+            outcome[nm] = "ok"
+        except Exception as e:      # noqa: BLE001
+            outcome[nm] = type(e).__name__
+    print("upstream predict on its own skewed reference:", outcome)
+    assert outcome == {"results_r": "ok", "results_nr": "IndexError"}
+    out["predict_gender"] = np.array(gender)
+    out["predict_results_r"] = np.array(outcome["results_r"])
+    out["predict_results_nr"] = np.array(outcome["results_nr"])
+    out["len_merged"] = np.array([len(ref_sizes), len(null_ratios), int(np.sum(rem_input["mask"]))])
+    save("mask_skew.npz", **out)
+
+
 # --------------------------------------------------------------------------- f3 output tables
 def golden_tables():
     """Byte pins of the `predict --bed --regions` tables: the reference's own tool_test run end to
@@ -567,3 +638,5 @@ if __name__ == "__main__":
         golden_pipeline()
     if "prep_filter" in which:
         golden_prep_filter()
+    if "mask_skew" in which:
+        golden_mask_skew()

@@ -226,3 +226,100 @@ def test_predict_one_dev_equals_the_host_path():
         assert a[:3] == b[:3]
         np.testing.assert_allclose([float(a[3]), a[4]], [float(b[3]), b[4]], rtol=1e-9, atol=1e-9)
     assert any(abs(s[4] - np.log2(1.5)) < 0.1 for s in rows)          # the planted gain is called
+
+
+def test_mask_skew_default_is_upstream_and_aligned_masks_is_opt_in(tmp_path):
+    """The cohort of tests/golden/mask_skew.npz makes the F / M passes' PCA-distance filter drop an
+    autosomal bin the finished A reference still holds (newref_control.py:48-54).  DEFAULT newref
+    reproduces upstream's three masks bit for bit; upstream's own predict raises IndexError on that
+    reference (recorded in the fixture: predict_control.py:50 on results_nr) and ours refuses it too;
+    --aligned-masks keeps the autosomal masks equal and predict works."""
+    from wisecondorx_amd import main, npz_io
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_skew.npz"))
+    assert str(g["predict_results_nr"]) == "IndexError" and str(g["predict_results_r"]) == "ok"
+    bpc = g["cohort_bpc"]
+    infiles = []
+    for i, counts in enumerate(g["cohort_counts"]):
+        p = str(tmp_path / "s{}.npz".format(i))
+        npz_io.save_sample(p, sample_from_counts(counts, bpc), 4000000)
+        infiles.append(p)
+    sp = str(tmp_path / "test.npz")
+    npz_io.save_sample(sp, sample_from_counts(g["test_counts"], bpc), 4000000)
+    n_aut = int(np.sum(bpc[:22]))
+    common = ["--binsize", "4000000", "--refsize", "40", "--yfrac", "0.004"]
+    # default: upstream's masks, skew included
+    out = str(tmp_path / "ref.npz")
+    random.seed(5)
+    main.main(["newref"] + infiles + [out] + common)
+    mine = np.load(out, allow_pickle=True)
+    assert np.array_equal(mine["mask"], g["mask"])
+    assert np.array_equal(mine["mask.F"], g["mask_F"])
+    assert np.array_equal(mine["mask.M"], g["mask_M"])
+    assert mine["mask"][:n_aut].sum() > mine["mask.F"][:n_aut].sum()
+    with pytest.raises(SystemExit) as ei:
+        main.main(["predict", sp, out, str(tmp_path / "ID"), "--bed", "--minrefbins", "10", "--seed", "3"])
+    assert ei.value.code == 1
+    # --aligned-masks: the gonosomal passes keep the autosomal mask of the A pass; predict runs
+    out2 = str(tmp_path / "ref_aligned.npz")
+    random.seed(5)
+    main.main(["newref"] + infiles + [out2, "--aligned-masks"] + common)
+    fixed = np.load(out2, allow_pickle=True)
+    assert np.array_equal(fixed["mask"], g["mask"])
+    assert np.array_equal(fixed["mask.F"][:n_aut], fixed["mask"][:n_aut])
+    assert np.array_equal(fixed["mask.M"][:n_aut], fixed["mask"][:n_aut])
+    main.main(["predict", sp, out2, str(tmp_path / "ID2"), "--bed", "--minrefbins", "10", "--seed", "3"])
+    assert os.path.exists(str(tmp_path / "ID2_bins.bed"))
+
+
+def test_predict_full_dev_applies_the_blacklist_like_the_host_path(tmp_path):
+    """dist.predict_full_dev with --blacklist: the blacklisted bins of r / z / w are zeroed on the device
+    between the log2 transform and CBS (main.py:263-265, predict_tools.py:202-214) -- same per-bin
+    vectors and same segments as the host mirror with apply_blacklist."""
+    import torch
+    import bench
+    from wisecondorx_amd import _lib, dist as wd, predict_tools as pt
+    co, p, test = bench.make_workload(100000, 40)
+    X = p["X"]
+    cum = np.asarray(p["masked_bins_per_chr_cum"], dtype=np.int64)
+    B, S, k = int(cum[-1]), X.shape[1], 100
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx)
+    Xrow = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+    ids = np.arange(S, dtype=np.int32)
+    idx, dist, nr, _ = wd.newref_sharded(Xrow, B, cum, k, ids, be, 0, 1)
+    x = pt.project_pc(pt.coverage_normalize_and_mask(test, p, ""), p, "")
+    d_x = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    bl = str(tmp_path / "bl.bed")
+    with open(bl, "w") as fh:
+        fh.write("chr3\t1000000\t2600000\n7\t0\t450000\nchrX\t0\t100\n")
+    args = argparse.Namespace(minrefbins=30, alpha=1e-4, seed=3, maskrepeats=5, blacklist=bl)
+    rem = {"args": args, "mask": p["mask"], "bins_per_chr": p["bins_per_chr"], "binsize": 100000,
+           "ref_gender": "F"}
+    A = {"idx": idx, "dist": dist, "nr": nr, "cum": cum}
+    rows, host = wd.predict_full_dev(be, A, None, d_x, None, rem, pt, want_host=True)
+
+    ref = dict(p)
+    ref.update({"indexes": idx.cpu().numpy(), "distances": dist.cpu().numpy(),
+                "null_ratios": nr.cpu().numpy()})
+    cache = {}
+    cutoff = pt.get_optimal_cutoff(ref, 5, cache)
+    w = pt.get_weights(ref, "", cache)
+    z, r, n, mlr, mz = pt.normalize_repeat(x, ref, cutoff, 0, 0, "", cache)
+    res = {"results_r": r, "results_z": z - mz, "results_w": w / np.nanmean(w)}
+    for key in res:
+        res[key] = pt.get_post_processed_result(args, res[key], n, rem)
+    pt.log_trans(res, mlr)
+    pt.apply_blacklist(rem, res)
+    off = np.concatenate(([0], np.cumsum(p["bins_per_chr"]))).astype(int)
+    for row, key in enumerate(("results_r", "results_z", "results_w")):
+        want_vec = np.concatenate(res[key])
+        np.testing.assert_allclose(host[row], want_vec, rtol=1e-9, atol=1e-12)
+        assert np.all(host[row][off[2] + 10:off[2] + 27] == 0) and np.all(host[row][off[6]:off[6] + 5] == 0)
+    nr_full = pt.inflate_results(ref["null_ratios"], rem)
+    res["results_nr"] = [nr_full[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+    want = pt.exec_cbs(rem, res, _lib.default_context(0))
+    assert len(rows) == len(want)
+    for a, b in zip(rows, want):
+        assert a[:3] == b[:3]
+        np.testing.assert_allclose([float(a[3]), a[4]], [float(b[3]), b[4]], rtol=1e-9, atol=1e-9)

@@ -488,3 +488,18 @@ def test_gender_model_cutoff_matches_reference():
     # --yfrac given: no mixture, the value is used as is (newref_tools.py:55-56)
     g2, c2 = main.train_gender_model(argparse.Namespace(plotyfrac=None, yfrac=0.002), samples)
     assert c2 == 0.002 and g2 == genders
+
+
+def test_newref_mask_skew_default_follows_upstream():
+    """newref's default lets a gonosomal pass drop autosomal bins like upstream (frozen = 0); the fix is
+    opt-in.  The fixture records what upstream's own predict does with such a reference: IndexError."""
+    import os
+    from wisecondorx_amd import main
+    a = main.build_parser().parse_args(["newref", "a.npz", "out.npz"])
+    assert a.aligned_masks is False
+    assert main.build_parser().parse_args(["newref", "a.npz", "out.npz", "--aligned-masks"]).aligned_masks
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_skew.npz"))
+    n_aut = int(np.sum(g["cohort_bpc"][:22]))
+    assert g["mask"][:n_aut].sum() == g["mask_F"][:n_aut].sum() + 1
+    assert str(g["predict_results_nr"]) == "IndexError"
+    assert g["len_merged"].tolist()[0] == g["len_merged"].tolist()[1] + 1

@@ -358,7 +358,7 @@ def predict_batch_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False)
         BG = BG_all - ct
         d_xG = d_xG.view(-1, d_xG.shape[-1])
     cache = getattr(backend, "_predict_full_bufs", None)
-    key = (ns, BA, BG, n_bins, hash(mask.tobytes()))
+    key = (ns, BA, BG, BG_all, n_bins, hash(mask.tobytes()))
     if cache is None or cache["key"] != key:
         pos = np.flatnonzero(mask).astype(np.int32)
         if len(pos) != BA + BG:
@@ -373,6 +373,7 @@ def predict_batch_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False)
         backend._predict_full_bufs = cache
     a, g, med, out = cache["a"], cache["g"], cache["med"], cache["out"]
     hA, hG = _lib.vp(), _lib.vp()
+    w_fallback = _lib.C.c_int(0)
     _lib.check(lib.wcx_ref_wrap_dev(ctx.h, A["idx"].data_ptr(), A["dist"].data_ptr(), BA, k, cumA_p,
                                     len(cumA), _lib.C.byref(hA)))
     try:
@@ -380,10 +381,12 @@ def predict_batch_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False)
         _lib.check(lib.wcx_cutoff(ctx.h, hA, int(args.maskrepeats), _lib.C.byref(cutoff)))
         _lib.check(lib.wcx_weights_dev(ctx.h, hA, cache["wa"].data_ptr()))
         ctx.timer_tag("aut:")
-        _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hA, d_xA.data_ptr(), ns, cutoff.value, 0, 0,
-                                                 a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
-                                                 med[0].data_ptr(), med[1].data_ptr()))
-        ctx.timer_tag("")
+        try:
+            _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hA, d_xA.data_ptr(), ns, cutoff.value, 0, 0,
+                                                     a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                                     med[0].data_ptr(), med[1].data_ptr()))
+        finally:
+            ctx.timer_tag("")
         if G is not None:
             _lib.check(lib.wcx_ref_wrap_dev(ctx.h, G["idx"].data_ptr(), G["dist"].data_ptr(), BG_all, k,
                                             cumG_p, len(cumG), _lib.C.byref(hG)))
@@ -396,11 +399,24 @@ def predict_batch_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False)
             g[0].data_ptr() if BG else None, g[1].data_ptr() if BG else None,
             g[2].data_ptr() if BG else None, cache["wg"].data_ptr() + 8 * ct if BG else None, BG, ns,
             med[0].data_ptr(), med[1].data_ptr(), float(args.minrefbins), cache["pos"].data_ptr(),
-            n_bins, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None))
+            n_bins, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _lib.C.byref(w_fallback)))
     finally:
         lib.wcx_ref_free(ctx.h, hA)
         if hG:
             lib.wcx_ref_free(ctx.h, hG)
+    if w_fallback.value:        # main.py:252-256
+        import logging
+        logging.warning("Non-numeric values found in weights -- reference too small. "
+                        "Circular binary segmentation and z-scoring will be unweighted")
+    if getattr(args, "blacklist", None):
+        # main.py:263-265 / predict_tools.py:202-214: ratio, z and weight of the blacklisted bins
+        # become 0 between the log2 transform and CBS (the merge call above has synchronised)
+        bl = cache.get("blacklist")
+        if bl is None or bl[0] != args.blacklist:
+            bl = (args.blacklist, torch.from_numpy(pt.blacklist_bin_indices(rem_input)).to(dev))
+            cache["blacklist"] = bl
+        if bl[1].numel():       # (the context runs on torch's current stream: ordered with the kernels)
+            out.index_fill_(2, bl[1], 0.0)
     # null ratios: autosomal rows + the gonosomal rows of the gonosomal reference (main.py:216-219)
     if G is None:
         nr = A["nr"]

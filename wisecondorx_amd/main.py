@@ -91,12 +91,14 @@ def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, context
     indexes -- normalisation, masking and the PCA then run from HBM, and on one GPU the corrected
     matrix never leaves it."""
     from . import newref_tools
-    # PCA on the device.  In the gonosomal passes the autosomal part of the mask is frozen: the
-    # reference lets their PCA-distance filter drop autosomal bins the A reference still holds and
-    # then misaligns the merged result at predict time (see prep.prepare); --reference-mask-skew
-    # restores that behaviour.
+    # PCA on the device.  DEFAULT = upstream (newref_control.py:48-54): the PCA-distance filter of a
+    # gonosomal pass may drop autosomal bins the finished A reference still holds (the shared mask
+    # is mutated in place after the A pass saved its copy).  Upstream's predict then raises
+    # IndexError on such a reference (predict_control.py:50 on results_nr; pinned by
+    # tests/golden/mask_skew.npz) and so does ours (tool_test).  --aligned-masks freezes the
+    # autosomal part of the mask in the gonosomal passes instead (see prep.prepare).
     frozen = 0
-    if gender != "A" and not getattr(args, "reference_mask_skew", False):
+    if gender != "A" and getattr(args, "aligned_masks", False):
         frozen = int(np.sum(bins_per_chr[:22]))
     n_parts = len(contexts)
     if dc is not None:
@@ -158,8 +160,8 @@ def tool_newref(args):
     dc = None
     try:
         dc = prep.DeviceCounts(contexts[0], samples)
-    except TypeError as e:
-        logging.info("Host-side masks / normalisation: {}".format(e))
+    except (TypeError, ValueError, RuntimeError) as e:      # non-integer counts, a count beyond int32,
+        logging.info("Host-side masks / normalisation: {}".format(e))   # no room in HBM: the host path works
     sel_of = {"A": np.arange(len(genders)), "F": np.flatnonzero(g == "F"), "M": np.flatnonzero(g == "M")}
     get_mask = (lambda k: dc.get_mask(sel_of[k])) if dc is not None else \
         (lambda k: prep.get_mask(samples[sel_of[k]]))
@@ -170,34 +172,38 @@ def tool_newref(args):
         total_mask = total_mask & get_mask("M")[0]
 
     final_ref = {"has_female": False, "has_male": False}
-    if len(genders) > 9:
-        logging.info("Starting autosomal reference creation ...")
-        sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts, dc, sel_of["A"])
-        final_ref.update({k: v for k, v in sub.items() if k != "gender"})
-    else:
-        logging.critical("Provide at least 10 samples to enable the generation of a reference.")
-        sys.exit()
-    if genders.count("F") > 4:
-        logging.info("Starting female gonosomal reference creation ...")
-        sub = build_sub_reference(args, samples[g == "F"], "F", total_mask, bins_per_chr, contexts, dc,
-                                  sel_of["F"])
-        final_ref["has_female"] = True
-        final_ref.update({k + ".F": v for k, v in sub.items() if k != "gender"})
-    else:
-        logging.warning("Provide at least 5 female samples to enable normalization of female gonosomes.")
-    if not args.nipt:
-        if genders.count("M") > 4:
-            logging.info("Starting male gonosomal reference creation ...")
-            sub = build_sub_reference(args, samples[g == "M"], "M", total_mask, bins_per_chr, contexts, dc,
-                                      sel_of["M"])
-            final_ref["has_male"] = True
-            final_ref.update({k + ".M": v for k, v in sub.items() if k != "gender"})
+    try:
+        if len(genders) > 9:
+            logging.info("Starting autosomal reference creation ...")
+            sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts, dc, sel_of["A"])
+            final_ref.update({k: v for k, v in sub.items() if k != "gender"})
         else:
-            logging.warning("Provide at least 5 male samples to enable normalization of male gonosomes.")
-    if dc is not None:
-        dc.close()
-        contexts[0].lib.wcx_pca_end(contexts[0].h)
-        contexts[0].release_buffers()
+            logging.critical("Provide at least 10 samples to enable the generation of a reference.")
+            sys.exit()
+        if genders.count("F") > 4:
+            logging.info("Starting female gonosomal reference creation ...")
+            sub = build_sub_reference(args, samples[g == "F"], "F", total_mask, bins_per_chr, contexts, dc,
+                                      sel_of["F"])
+            final_ref["has_female"] = True
+            final_ref.update({k + ".F": v for k, v in sub.items() if k != "gender"})
+        else:
+            logging.warning("Provide at least 5 female samples to enable normalization of female gonosomes.")
+        if not args.nipt:
+            if genders.count("M") > 4:
+                logging.info("Starting male gonosomal reference creation ...")
+                sub = build_sub_reference(args, samples[g == "M"], "M", total_mask, bins_per_chr, contexts, dc,
+                                          sel_of["M"])
+                final_ref["has_male"] = True
+                final_ref.update({k + ".M": v for k, v in sub.items() if k != "gender"})
+            else:
+                logging.warning("Provide at least 5 male samples to enable normalization of male gonosomes.")
+    finally:
+        # (also on an error in any pass: the device counts, the PCA stage and the buffers must not
+        # outlive the call while the context does)
+        if dc is not None:
+            dc.close()
+            contexts[0].lib.wcx_pca_end(contexts[0].h)
+            contexts[0].release_buffers()
     final_ref["is_nipt"] = args.nipt
     final_ref["trained_cutoff"] = trained_cutoff
     n_aut = int(np.sum(final_ref["bins_per_chr"]))
@@ -207,8 +213,8 @@ def tool_newref(args):
             # the reference has the same latent skew (newref_control.py:51-54 mutates the shared
             # mask after the A pass kept its copy) and misaligns silently at predict time
             logging.warning("The PCA-distance filter of the {} pass dropped {} autosomal bin(s) "
-                            "the autosomal reference still holds: predict cannot align the two "
-                            "(rebuild without the offending samples/bins)".format(
+                            "the autosomal reference still holds (upstream behaviour): predict cannot "
+                            "align the two -- rebuild with --aligned-masks".format(
                                 ap[1:], int(np.sum(final_ref["mask"]) -
                                             np.sum(final_ref["mask" + ap][:n_aut]))))
     npz_io.save_npz(args.outfile, final_ref)
@@ -294,13 +300,14 @@ def tool_test(args):
     n_aut = int(np.sum(ref_file["bins_per_chr"]))
     mask_aut, mask_gon_aut = np.asarray(ref_file["mask"])[:n_aut], np.asarray(ref_file["mask" + ap])[:n_aut]
     if int(np.sum(mask_gon_aut)) != n_aut_masked:
-        # upstream walks the merged vector through mask{ap} bin by bin (predict_tools.py:163-170):
-        # with fewer autosomal bins there it shifts every later bin silently, with more it raises
-        # IndexError -- neither is a result worth reproducing
+        # Upstream fails on the same input: the merged null-ratio table has sum(mask{ap}) rows but
+        # ref_sizes one entry per merged result, so get_post_processed_result raises "IndexError:
+        # boolean index did not match" (predict_control.py:50; run of the reference itself recorded in
+        # tests/golden/mask_skew.npz).  Same outcome here, with the reason spelled out.
         logging.critical("Reference mask{} holds {} autosomal bins but the autosomal reference {}: "
                          "the reference was built with a PCA-distance filter skew "
-                         "(newref_control.py:51-54) and cannot be aligned; rebuild it with this "
-                         "newref (or upstream's after removing the skewed samples)".format(
+                         "(newref_control.py:48-54) and cannot be aligned (upstream raises IndexError "
+                         "at predict_control.py:50 for it); rebuild it with newref --aligned-masks".format(
                              ap, int(np.sum(mask_gon_aut)), n_aut_masked))
         sys.exit(1)
     if not np.array_equal(mask_gon_aut, mask_aut):
@@ -371,9 +378,10 @@ def build_parser():
                    help="Scale samples to this binsize, multiples of existing binsize only")
     p.add_argument("--cpus", type=int, default=1, help="Accepted for compatibility (ignored)")
     p.add_argument("--gpus", type=int, default=1, help="Number of MI355X devices to split the rows over")
-    p.add_argument("--reference-mask-skew", action="store_true",
-                   help="Let the PCA-distance filter of the gonosomal passes drop autosomal bins, like "
-                        "upstream WisecondorX (such references cannot be aligned at predict time)")
+    p.add_argument("--aligned-masks", action="store_true",
+                   help="Keep the autosomal part of the mask fixed in the gonosomal passes. Default "
+                        "(like upstream WisecondorX): their PCA-distance filter may drop autosomal bins "
+                        "the autosomal reference still holds -- predict cannot use such a reference")
     p.set_defaults(func=tool_newref)
 
     p = sub.add_parser("gender", description="Returns the gender of a .npz resulting from convert",

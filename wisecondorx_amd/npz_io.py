@@ -18,11 +18,15 @@ CLI's wall-clock once the search runs on the GPU, so both go around `zipfile` fo
 import io
 import os
 import struct
+import tempfile
 import zipfile
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
+
+_UMASK = os.umask(0)
+os.umask(_UMASK)
 
 _BIG = 8 << 20            # stored by the direct writer / read by the direct reader
 _DEFLATE_MAX = 1 << 20    # anything larger is mostly incompressible doubles: stored as is
@@ -109,8 +113,11 @@ def save_npz(path, arrays, compress_small=True):
     cd_off = off
     # written next to the target and renamed once EVERY write has succeeded: a failed write (disk
     # full) must not leave a plausible-looking archive behind
-    final_path, path = path, str(path) + ".tmp"
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    # (a unique name: two writers of one target, or somebody's stale .tmp, must not trample each other)
+    final_path = str(path)
+    fd, path = tempfile.mkstemp(dir=os.path.dirname(os.path.abspath(final_path)) or ".",
+                                prefix=os.path.basename(final_path) + ".", suffix=".tmp")
+    os.fchmod(fd, 0o644 & ~_UMASK)
     ok = False
     try:
         with ThreadPoolExecutor(max_workers=_THREADS) as ex:
@@ -171,6 +178,7 @@ def save_npz(path, arrays, compress_small=True):
                                 0xFFFFFFFF if len(cd) >= _Z64 else len(cd),
                                 0xFFFFFFFF if cd_off >= _Z64 else cd_off, 0)
             _pwrite_all(fd, memoryview(cd + tail), cd_off)
+        os.fsync(fd)            # the bytes are on disk before the name points at them
         ok = True
     finally:
         os.close(fd)

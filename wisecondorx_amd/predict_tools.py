@@ -283,6 +283,22 @@ def apply_blacklist(rem_input, results):
             results[key][c][lo:hi] = 0
 
 
+def blacklist_bin_indices(rem_input):
+    """The flat (unmasked, concatenated per chromosome) bin indexes apply_blacklist zeroes -- for the
+    device-resident predict (dist.predict_batch_dev), which holds r / z / w as [samples][n_bins]."""
+    bpc = [int(v) for v in rem_input["bins_per_chr"]]
+    off = np.concatenate(([0], np.cumsum(bpc))).astype(np.int64)
+    n_chr = len(bpc)
+    idx = []
+    for c, first, last in _blacklist_spans(rem_input["args"].blacklist, rem_input["binsize"]):
+        if c >= n_chr or (n_chr < 24 and c == 23):
+            continue
+        lo, hi = max(first, 0), min(last, bpc[c])
+        if lo < hi:
+            idx.append(np.arange(off[c] + lo, off[c] + hi, dtype=np.int64))
+    return np.unique(np.concatenate(idx)) if idx else np.zeros(0, dtype=np.int64)
+
+
 def _flatten(results, key, n_chr=None):
     """Per-chromosome arrays -> one contiguous float64 vector.  When the pieces already are
     consecutive views of one contiguous array (post_process_fused builds them that way) that array
