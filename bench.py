@@ -86,6 +86,7 @@ def make_full_workload(binsize, n_samples, seed=0, device=0):
     passes["F"] = prep.prepare(samples[g == "F"], "F", total_mask, bpc, ctx=ctx, frozen=n_aut)
     passes["M"] = prep.prepare(samples[g == "M"], "M", total_mask, bpc, ctx=ctx, frozen=n_aut)
     test = gender_correct(co.sample(777 + seed, "F", cnv=[(3, 100, 100 + max(4, int(4e7 // binsize)), 1.5)]), "F")
+    co.cohort_corrected = (samples, genders)       # (for the CLI end-to-end block of bench.py)
     return co, passes, test
 
 
@@ -180,6 +181,7 @@ class Workload:
         self.torch, self.wd, self.pt = torch, wd, predict_tools
         self.rank, self.world, self.args = rank, world, args
         co, passes, test = make_full_workload(args.binsize, n_samples, device=dev_index)
+        self.co = co
         self.k = args.refsize
         stream = torch.cuda.current_stream().cuda_stream
         self.ctx = _lib.Context(dev_index, stream)
@@ -225,7 +227,7 @@ class Workload:
                     "binsize": args.binsize, "ref_gender": "F"}
         self.names = ("topk", "topk_screen", "topk_pre", "topk_prep", "topk_refine", "null_ratios")
         self.ms = {"{}:{}".format(t, n_): [] for t in ("A", "F", "M") for n_ in self.names}
-        for n_ in ("normalize", "cbs", "segment_z", "predict_full", "gather_ref"):
+        for n_ in ("normalize", "cbs", "segment_z", "predict_full", "gather_ref", "cutoff", "weights"):
             self.ms[n_] = []
         self.fb_rows = []
         self.n_segments = 0
@@ -268,6 +270,7 @@ class Workload:
                                                              self.backend, self.rank, self.world, P["bufs"])
             ref[tag] = {"idx": idx, "dist": dist_, "nr": nr, "cum": P["cum"]}
         ctx.timer_tag("")
+        self.last_ref = ref
         # predict ONE sample, complete (replica on every rank): autosomes vs A, gonosomes vs F
         t0 = time.perf_counter()
         res = wd.predict_full_dev(self.backend, ref["A"], ref["F"], self.d_xA, self.d_xG, self.rem, self.pt)
@@ -275,7 +278,7 @@ class Workload:
         if record:
             self.ms["predict_full"].append(1e3 * (time.perf_counter() - t0))
             self.ms["normalize"].append(ctx.kernel_ms("aut:normalize") + max(0.0, ctx.kernel_ms("normalize")))
-            for name in ("cbs", "segment_z"):
+            for name in ("cbs", "segment_z", "cutoff", "weights"):
                 self.ms[name].append(ctx.kernel_ms(name))
             for tag in ("A", "F", "M"):
                 for n_ in self.names:
@@ -353,6 +356,152 @@ class Workload:
         return r, screen_ms
 
 
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def hbm_kernels(w, rf):
+    """the gather / scan kernels are HBM bound in principle -- achieved GB/s on their
+    ALGORITHMIC bytes and the fraction of 8 TB/s (what they really move goes through L2: DESIGN.md 4)."""
+    B, S, k = int(w.B), int(w.S), int(w.k)
+    m = int(len(w.P["A"]["ids"]))
+    BG = int(w.P["F"]["B"] - int(w.P["F"]["cum"][21]))
+    rows = {
+        "k_null_ratios (A pass)": (rf.get("null_ratios_ms", -1), B * k * 4 + m * B * 8,
+                                   "B k 4 (indexes) + m B 8 (ratios out)"),
+        "k_refine (A pass)": (rf.get("refine_ms", -1), B * S * 8 + int(rf.get("refined_pairs", 0)) * 8 + B * k * 12,
+                              "X once + shortlists + idx / dist out (it gathers refined_pairs x S x 8 = "
+                              "{:.0f} GB through L2)".format(int(rf.get("refined_pairs", 0)) * S * 8 / 1e9)),
+        "k_cut_partial (cut-off, 5 repeats x 2 sweeps)": (w.mean_ms("cutoff"), 10 * B * k * 8,
+                                                          "10 sweeps of the autosomal distances"),
+        "k_weights": (w.mean_ms("weights"), (B + int(w.P["F"]["B"])) * k * 8, "one sweep of distances (A + gonosomal reference)"),
+        "k_normalize_pass x3 (1 sample, A + gonosomes)": (w.mean_ms("normalize"), 3 * (B + BG) * (k * 4 + k // 8 + 32),
+                                                          "per pass and bin: k indexes + selection bits + in / out values"),
+    }
+    out = {}
+    for name, (ms, nbytes, what) in rows.items():
+        if ms is None or ms <= 0:
+            continue
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"ms": ms, "algorithmic_bytes": int(nbytes), "achieved_GBs": gbs,
+                     "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "bytes": what}
+    return out
+
+
+def config5_block(w, batch=96, runs=3):
+    """BASELINE configs[4]: predict a batch of 96 samples at 15 kb, device-resident end to end
+    (dist.predict_batch_dev) against the reference of the last timed step, on this one device (8 GPUs
+    stripe the samples, no collective)."""
+    import torch
+    from wisecondorx_amd.overall_tools import gender_correct
+    pt, wd = w.pt, w.wd
+    A, G = w.last_ref["A"], w.last_ref["F"]
+    ref = dict(w.p)
+    ref.update({k_ + ".F": v for k_, v in w.P["F"]["p"].items()})
+    tests = [gender_correct(w.co.sample(5000 + i, "F", cnv=[(1 + i % 22, 200, 2200, 1.5)]), "F")
+             for i in range(batch)]
+    dev = A["idx"].device
+    cache = {}
+    t_all, t_prep = [], []
+    rows = None
+    for _ in range(runs):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dA = torch.from_numpy(pt.sample_counts_matrix(tests, ref, "")).to(dev)
+        dG = torch.from_numpy(pt.sample_counts_matrix(tests, ref, ".F")).to(dev)
+        xA = pt.prepare_batch_dev(dA, ref, "", w.ctx, cache)
+        xG = pt.prepare_batch_dev(dG, ref, ".F", w.ctx, cache)
+        torch.cuda.synchronize()
+        t_prep.append(time.perf_counter() - t0)
+        rows = wd.predict_batch_dev(w.backend, A, G, xA, xG, w.rem, pt)
+        torch.cuda.synchronize()
+        t_all.append(time.perf_counter() - t0)
+    ms = {k_: w.ctx.kernel_ms(k_) for k_ in ("aut:normalize", "normalize", "cbs", "segment_z")}
+    B, BG, k = int(w.B), int(w.P["F"]["B"] - int(w.P["F"]["cum"][21])), int(w.k)
+    nbytes = 3 * (B + BG) * (k * 4 + k // 8) + 3 * batch * (B + BG) * 32
+    norm_ms = max(ms["aut:normalize"], 0.0) + max(ms["normalize"], 0.0)
+    return {"workload": "BASELINE configs[4]: predict {} samples at {} kb (autosomes + gonosomes, merge, "
+                        "CBS, segment z), one device".format(batch, w.args.binsize // 1000),
+            "batch_s": min(t_all), "runs_s": t_all, "prep_s": min(t_prep), "samples_per_s": batch / min(t_all),
+            "kernel_ms": ms, "segments": int(sum(len(r_) for r_ in rows)),
+            "normalize_roofline": {"ms": norm_ms, "algorithmic_bytes": int(nbytes),
+                                   "achieved_GBs": nbytes / (norm_ms * 1e-3) / 1e9 if norm_ms > 0 else None,
+                                   "frac_of_hbm_peak": nbytes / (norm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if norm_ms > 0 else None,
+                                   "bytes": "3 passes x (A + gonosomal rows) x (k indexes + selection bits), read once "
+                                            "per batch + 32 B per (sample, bin, pass)"}}
+
+
+def e2e_cli_block(w, workdir="/tmp/wcx_bench_e2e"):
+    """BASELINE.json's literal metric: wall-clock of the CLI -- `newref` on the cohort's sample files
+    (load, gender model, masks, PCA, A / F / M searches + null ratios, reference .npz written, QC) and
+    `predict --bed` of one sample.  Sample files are written before the clock starts."""
+    import random
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    from wisecondorx_amd import main as cli, npz_io
+    shutil.rmtree(workdir, ignore_errors=True)
+    os.makedirs(workdir)
+    samples, genders = w.co.cohort_corrected
+    def raw(s_, g_):                     # undo gender_correct (males' gonosomal counts were doubled)
+        return s_ if g_ != "M" else dict(s_, **{"23": s_["23"] // 2, "24": s_["24"] // 2})
+    files = [os.path.join(workdir, "s{:03d}.npz".format(i)) for i in range(len(samples))]
+    with ThreadPoolExecutor(16) as ex:
+        list(ex.map(lambda a_: npz_io.save_sample(a_[0], raw(a_[1], a_[2]), w.args.binsize),
+                    zip(files, samples, genders)))
+    test_file = os.path.join(workdir, "test.npz")
+    npz_io.save_sample(test_file, w.co.sample(9001, "F", cnv=[(3, 500, 500 + int(3e7 / w.args.binsize), 1.5)]),
+                       w.args.binsize)
+    ref_file = os.path.join(workdir, "ref.npz")
+    random.seed(1)
+    out = {"workload": "CLI newref ({} sample files, {} bp bins, refsize {}, --aligned-masks) + predict "
+                       "--bed of 1 sample, one device".format(len(files), w.args.binsize, w.k)}
+    try:
+        t0 = time.perf_counter()
+        cli.main(["--loglevel", "error", "newref"] + files + [
+            ref_file, "--binsize", str(w.args.binsize), "--refsize", str(w.k), "--yfrac", "0.004",
+            "--aligned-masks"])
+        out["newref_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cli.main(["--loglevel", "error", "predict", test_file, ref_file, os.path.join(workdir, "out"),
+                  "--bed", "--seed", "1"])
+        out["predict_s"] = time.perf_counter() - t0
+        out["newref_plus_predict_s"] = out["newref_s"] + out["predict_s"]
+        out["reference_npz_bytes"] = os.path.getsize(ref_file)
+        out["segments"] = sum(1 for _ in open(os.path.join(workdir, "out_segments.bed"))) - 1
+    except SystemExit as e:
+        out["error"] = "CLI exited ({})".format(e.code)
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    return out
+
+
+def cpu_baseline_predict(w, budget_bins=2048):
+    """CPU leg for the predict path: the pinned NumPy oracle's normalize_once (predict_tools.py:111-142)
+    for a block of target bins (each against its full reference row), the three passes of
+    normalize_repeat, 1 core; extrapolated linearly in bins (the cost per bin is constant)."""
+    from oracle import wcx_oracle as O
+    A = w.last_ref["A"]
+    idx = A["idx"].cpu().numpy()
+    dist = A["dist"].cpu().numpy()
+    x = w.d_xA.cpu().numpy()
+    mb = [int(v) for v in w.p["masked_bins_per_chr"]]
+    cum = [int(v) for v in w.cum]
+    cutoff = float(O.get_optimal_cutoff(dist[::16], 5))
+    lo = cum[2]                                     # a block inside chromosome 4
+    t0 = time.perf_counter()
+    copy = np.copy(x)
+    for _ in range(3):
+        z, r, n = O.normalize_once(x, copy, mb, cum, idx, dist, cutoff, 0, 0, row_range=(lo, lo + budget_bins))
+        with np.errstate(all="ignore"):
+            copy[np.abs(z) >= 3] = -1
+    dt = time.perf_counter() - t0
+    per_bin = dt / budget_bins
+    return {"value": 1.0 / per_bin, "unit": "bins/s (3 normalisation passes, k refs each)", "cores": 1,
+            "kind": "port", "sample": "{} of {} autosomal bins, one sample".format(budget_bins, len(x)),
+            "seconds": dt, "extrapolated_s_per_sample": per_bin * len(x),
+            "gpu_ms_per_sample_A_plus_gonosomes": w.mean_ms("normalize")}
+
+
 def run_steps(w, steps, warmup, spinup, barrier):
     # Untimed spin-up (setup, not one of the contract's warm-up steps; reported in config): the
     # first process on an idle box otherwise measures the clock ramp.  A FIXED number of steps:
@@ -380,6 +529,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the S=100 block")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run oracle check")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip config 5, the 100 kb config and the CLI end-to-end block")
     ap.add_argument("--replicas", action="store_true",
                     help="throughput mode: every rank builds its OWN whole reference + predict (N cohorts "
                          "side by side, no collective on the data path; 'scaling': 'weak') instead of "
@@ -485,10 +636,26 @@ def main():
                             "roofline": {k_: r2[k_] for k_ in r2
                                          if k_ not in ("kernel", "attainable_note",
                                                        "fallback_rows_per_step")}}
+    if rank == 0 and world == 1 and not args.debug_flags:
+        out["hbm_kernels"] = hbm_kernels(w, roofline)
     if rank == 0 and not args.debug_flags and not args.no_verify:
         out["verified"] = verify_rows(w)
+    if rank == 0 and world == 1 and not args.debug_flags and not args.no_extras:
+        # the other BASELINE configs and the literal wall-clock metric, outside the timed region
+        out["config5"] = config5_block(w)
+        a2 = argparse.Namespace(**dict(vars(args), binsize=100000))
+        w3 = Workload(a2, 100, torch, dev, dev_index, rank, world)
+        dt3 = run_steps(w3, args.steps, args.warmup, SPINUP_STEPS, barrier)
+        r3, _ = w3.roofline()
+        out["config2_100kb"] = {"workload": "BASELINE configs[1]: 100 kb x 100 samples, same step",
+                                "ms_per_step": dt3 / args.steps * 1e3, "value": w3.pairs_total / (dt3 / args.steps),
+                                "bins": int(w3.B), "screen_ms": r3.get("kernel_ms"), "refine_ms": r3.get("refine_ms"),
+                                "roofline_frac": r3.get("frac"), "null_ratios_ms": r3.get("null_ratios_ms")}
+        del w3
+        out["e2e_cli"] = e2e_cli_block(w)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w.Xs_host, w.cum, w.k)
+        out["cpu_baseline"]["predict"] = cpu_baseline_predict(w)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -288,6 +288,78 @@ __global__ __launch_bounds__(NT) void k_normalize_pass_tile(
   }
 }
 
+// Passes 0 and 1 of a BATCH (predict_tools.py:99-104): they feed nothing but the z-mask of the next
+// pass, so only count, mean and standard deviation are needed -- no median.  LANE = SAMPLE: a wave owns
+// one bin and 64 samples; the bin's selected reference rows are walked once, every step one coalesced
+// 512-byte load of copyT[row][64 samples], and each lane keeps its own sample's running sums in
+// registers -- no cross-lane reduction at all (the tiled kernel below spends its time in three
+// 64-lane reductions per sample and bin).  Sums are taken about c = the sample's own value of the
+// bin: mean = c + S1 / n, var = (S2 - S1^2 / n) / n (c is close to the mean: no cancellation); a set
+// of identical values gives sd = 0 exactly, as np.std does.  (Measured, 96 samples at 15 kb: the three
+// passes 42.8 -> 34.8 ms; a variant with two bins x 32 samples per wave -- no idle lanes for 96
+// samples -- was slower, 36.4 ms: the kernel is bound by its per-element instructions, not by bytes.)
+__global__ __launch_bounds__(NT) void k_normalize_mask_lanes(
+    const double *__restrict__ xT, const double *__restrict__ copy_in, double *__restrict__ copy_out,
+    const int32_t *__restrict__ idx, const unsigned long long *__restrict__ sel, int64_t B, int k,
+    int ipl, int NS, int64_t lo, int64_t hi, ChrTable chr) {
+  const int lane = wcx::lane_id();
+  const int s = blockIdx.y * 64 + lane;             // my sample (NS is a multiple of 64)
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  for (int64_t i = lo + w0; i < hi; i += nw) {
+    int64_t cs = 0, ce = chr.cum[0];
+    for (int c = 1; c < chr.n_chr && i >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+    const int64_t own = ce - cs;
+    const int64_t len_cd = B - own;  // len(chr_data), predict_tools.py:125-130
+    const double c0 = xT[i * NS + s];
+    double S1a = 0.0, S2a = 0.0, S1b = 0.0, S2b = 0.0, vmin = HUGE_VAL, vmax = -HUGE_VAL;
+    int n = 0;
+    for (int q = 0; q < ipl; ++q) {
+      const int t = q * 64 + lane;
+      int gv = 0;
+      if (t < k) {
+        int64_t c = idx[i * (int64_t)k + t];
+        if (c < 0) c += len_cd;                       // NumPy negative index
+        gv = (int)(c < cs ? c : c + own);             // chr_data index -> row
+      }
+      unsigned long long w = sel[i * ipl + q];
+      if (q == ipl - 1 && (k & 63)) w &= (1ull << (k & 63)) - 1ull;
+      // the selected rows of this word, four at a time (their loads in flight together)
+      while (w) {
+        int g[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          on[u] = w != 0;
+          const int b = on[u] ? __builtin_ctzll(w) : 0;
+          w &= w - 1ull;                              // (0 & -1 = 0: stays empty)
+          g[u] = __builtin_amdgcn_readlane(gv, b);
+        }
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = copy_in[(int64_t)g[u] * NS + s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool keep = on[u] && v[u] >= 0.0;     // predict_tools.py:134
+          const double d = keep ? v[u] - c0 : 0.0;
+          const double dd = d * d;
+          if (u & 1) { S1b = S1b + d; S2b = S2b + dd; } else { S1a = S1a + d; S2a = S2a + dd; }
+          n += keep ? 1 : 0;
+          vmin = keep && v[u] < vmin ? v[u] : vmin;
+          vmax = keep && v[u] > vmax ? v[u] : vmax;
+        }
+      }
+    }
+    const double S1 = S1a + S1b, S2 = S2a + S2b, dn = (double)n;
+    double mean = c0 + S1 / dn;
+    double var = (S2 - S1 * (S1 / dn)) / dn;
+    if (vmin == vmax) { mean = vmin; var = 0.0; }     // identical values: sd = 0 exactly (np.std)
+    const double sd = sqrt(var > 0.0 ? var : 0.0);
+    const double z = (c0 - mean) / sd;                // predict_tools.py:136
+    copy_out[i * NS + s] = (fabs(z) >= Z_MASK) ? -1.0 : copy_in[i * NS + s];   // :104
+  }
+}
+
 // x [n_samples][B] -> sample-minor copies a[B][NS], b[B][NS] (padding samples = 0)
 __global__ __launch_bounds__(256) void k_to_sample_minor(const double *__restrict__ x, int64_t B,
                                                          int n_samples, int NS, double *__restrict__ a,
@@ -1038,7 +1110,7 @@ int launch_pass_tile(wcx_ctx *ctx, const wcx_ref *ref, const double *d_x, const 
   tab.n_chr = (int)ref->chr_cum.size();
   for (int c = 0; c < 32; ++c) tab.cum[c] = c < tab.n_chr ? ref->chr_cum[c] : B;
   const int64_t nl = hi - lo;
-  dim3 grid((unsigned)((nl + 3) / 4 < 16384 ? (nl + 3) / 4 : 16384), (unsigned)(NS / T));
+  dim3 grid((unsigned)((nl + 3) / 4 < 16384 ? (nl + 3) / 4 : 16384), (unsigned)((n_samples + T - 1) / T));
 #define WCX_NORMT_LAUNCH(IPL)                                                                     \
   k_normalize_pass_tile<IPL, T><<<grid, NT, 0, ctx->stream>>>(d_x, cin, cout, ref->d_idx, ref->d_sel, \
                                                                B, k, NS, n_samples, ct, lo, hi, tab, \
@@ -1102,20 +1174,28 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
   // copies are SAMPLE-MINOR [B][NS] (NS = n_samples rounded up to the tile) for the tiled kernel.
   constexpr int TILE = 8;
   const bool tiled = n_samples >= 2 && ipl_for(ref->k) <= 8;
-  const int NS = tiled ? (n_samples + TILE - 1) / TILE * TILE : n_samples;
+  // batches of 16 or more: passes 0 and 1 (z-mask only) run lane-per-sample (k_normalize_mask_lanes;
+  // 64-sample tiles: NS is rounded up to 64, and an untouched sample-minor copy of x is kept)
+  static const int lanes_min = [] { const char *e = getenv("WCX_NORM_LANES_MIN"); return e && *e ? atoi(e) : 16; }();
+  const bool lanes = tiled && n_samples >= lanes_min;
+  const int NS = lanes ? (n_samples + 63) / 64 * 64 : tiled ? (n_samples + TILE - 1) / TILE * TILE : n_samples;
   const size_t cp_b = (size_t)NS * B * 8;
   const size_t lr_b = (size_t)n_samples * Bp * 8;
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, 2 * cp_b + lr_b, &scr);
+  int rc = wcx_scratch(ctx, (lanes ? 3 : 2) * cp_b + lr_b, &scr);
   if (rc) return rc;
   double *cA = reinterpret_cast<double *>(scr);
   double *cB = cA + (size_t)NS * B;
   double *lr = cB + (size_t)NS * B;
+  double *xT = lanes ? lr + (size_t)n_samples * Bp : nullptr;
   rc = wcx_timer_begin(ctx, "normalize");
   if (rc) return rc;
   if (tiled) {
     k_to_sample_minor<<<dim3((unsigned)((B + 31) / 32), (unsigned)((NS + 31) / 32)), 256, 0,
                         ctx->stream>>>(d_x, B, n_samples, NS, cA, cB);
+    if (lanes)
+      k_to_sample_minor<<<dim3((unsigned)((B + 31) / 32), (unsigned)((NS + 31) / 32)), 256, 0,
+                          ctx->stream>>>(d_x, B, n_samples, NS, xT, xT);
   } else {
     const int64_t ntot = (int64_t)n_samples * B;
     k_copy2<<<(unsigned)((ntot + 255) / 256), 256, 0, ctx->stream>>>(d_x, cA, cB, ntot);
@@ -1125,7 +1205,15 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
   for (int pass = 0; pass < 3; ++pass) {  // predict_tools.py:99
     const double *cin = (pass & 1) ? cB : cA;
     double *cout = (pass & 1) ? cA : cB;
-    if (tiled)
+    if (lanes && pass < 2) {
+      ChrTable tab;
+      tab.n_chr = (int)ref->chr_cum.size();
+      for (int c = 0; c < 32; ++c) tab.cum[c] = c < tab.n_chr ? ref->chr_cum[c] : B;
+      const dim3 grid((unsigned)((Bp + 3) / 4 < 16384 ? (Bp + 3) / 4 : 16384), (unsigned)(NS / 64));
+      k_normalize_mask_lanes<<<grid, NT, 0, ctx->stream>>>(xT, cin, cout, ref->d_idx, ref->d_sel, B, ref->k,
+                                                           ipl_for(ref->k), NS, ct, B, tab);
+      WCX_HIP(hipGetLastError());
+    } else if (tiled)
       rc = launch_pass_tile<TILE>(ctx, ref, d_x, cin, cout, n_samples, NS, ct, pass == 2, d_out_z,
                                   d_out_r, d_out_n, lr);
     else
