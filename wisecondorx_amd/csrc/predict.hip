@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_normalize_pass_tile(
 // registers -- no cross-lane reduction at all (the tiled kernel below spends its time in three
 // 64-lane reductions per sample and bin).  Sums are taken about c = the sample's own value of the
 // bin: mean = c + S1 / n, var = (S2 - S1^2 / n) / n (c is close to the mean: no cancellation); a set
-// of identical values gives sd = 0 exactly, as np.std does.  (Measured, 96 samples at 15 kb: the three
+// of identical values ends like np.std's (see below).  (Measured, 96 samples at 15 kb: the three
 // passes 42.8 -> 34.8 ms; a variant with two bins x 32 samples per wave -- no idle lanes for 96
 // samples -- was slower, 36.4 ms: the kernel is bound by its per-element instructions, not by bytes.)
 __global__ __launch_bounds__(NT) void k_normalize_mask_lanes(
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NT) void k_normalize_mask_lanes(
     const int64_t own = ce - cs;
     const int64_t len_cd = B - own;  // len(chr_data), predict_tools.py:125-130
     const double c0 = xT[i * NS + s];
-    double S1a = 0.0, S2a = 0.0, S1b = 0.0, S2b = 0.0, vmin = HUGE_VAL, vmax = -HUGE_VAL;
+    double S1a = 0.0, S2a = 0.0, S1b = 0.0, S2b = 0.0;
     int n = 0;
     for (int q = 0; q < ipl; ++q) {
       const int t = q * 64 + lane;
@@ -345,15 +345,15 @@ __global__ __launch_bounds__(NT) void k_normalize_mask_lanes(
           const double dd = d * d;
           if (u & 1) { S1b = S1b + d; S2b = S2b + dd; } else { S1a = S1a + d; S2a = S2a + dd; }
           n += keep ? 1 : 0;
-          vmin = keep && v[u] < vmin ? v[u] : vmin;
-          vmax = keep && v[u] > vmax ? v[u] : vmax;
         }
       }
     }
+    // (a set of identical values v: np.std gives 0 or rounding dust, z = nan / 0 if the bin's own value
+    //  equals v -- kept --, else inf or huge -- masked; the sums about c0 end the same way: S1 = 0 = S2
+    //  for c0 = v, and var = dust or <= 0 otherwise)
     const double S1 = S1a + S1b, S2 = S2a + S2b, dn = (double)n;
-    double mean = c0 + S1 / dn;
-    double var = (S2 - S1 * (S1 / dn)) / dn;
-    if (vmin == vmax) { mean = vmin; var = 0.0; }     // identical values: sd = 0 exactly (np.std)
+    const double mean = c0 + S1 / dn;
+    const double var = (S2 - S1 * (S1 / dn)) / dn;
     const double sd = sqrt(var > 0.0 ? var : 0.0);
     const double z = (c0 - mean) / sd;                // predict_tools.py:136
     copy_out[i * NS + s] = (fabs(z) >= Z_MASK) ? -1.0 : copy_in[i * NS + s];   // :104
