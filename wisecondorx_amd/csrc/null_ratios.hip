@@ -8,18 +8,16 @@
 //
 // 1.8e7 medians of 300 gathered doubles each (15 kb, 100 null samples).  Selecting on doubles costs
 // three instructions per compare and 80 VGPRs per wave; instead every null sample is ranked ONCE
-// (stable two-pass radix sort of all samples together: low 32 key bits, then sample | high 32
-// bits), and the medians are selected on the 32-bit RANKS -- exact, because rank order is value
-// order and equal values give equal medians whichever of them is picked:
-//   k_nr_keys / hipcub radix sort x2 / k_nr_key64 / k_nr_scatter   ranks R and sorted values V
+// (own sample sort, one segment per null sample: k_rank_*), and the medians are selected on the
+// 32-bit RANKS -- exact, because rank order is value order and equal values give equal medians
+// whichever of them is picked:
+//   k_rank_splitters / _bucket / _scan / _scatter / _sort   ranks R and sorted values V
 //   k_null_ratios   one wave per (row, 8 samples): the 8 samples' ranks of a bin share one 32-byte
 //                   piece (Rg[group][bin][8]); per sample: min/max, 64 buckets (LDS atomics), scan
 //                   to the bucket holding the median rank, exact ranks inside it; the median value
 //                   is V[rank] (mean of the two middle ones).
 // Roofline: gather bound in principle (k * 32 B per row and sample group through L2 = 22 GB at
 // 15 kb); the selection arithmetic still dominates -- see DESIGN.md.
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 
 #include "wave_sort.h"
@@ -29,7 +27,7 @@
 namespace {
 
 constexpr int NT = 256;        // 4 waves per workgroup
-constexpr int BIN_BITS = 25;   // payload = sample << 25 | bin
+constexpr int BIN_BITS = 25;   // bins per call (historic payload width; keeps the 2^31 element bound company)
 
 // order-preserving 64-bit image of a double; NaN sorts last, -0 == +0
 __device__ __forceinline__ unsigned long long dkey(double x) {
@@ -39,46 +37,219 @@ __device__ __forceinline__ unsigned long long dkey(double x) {
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-__global__ __launch_bounds__(NT) void k_nr_keys(const double *__restrict__ Xs, int64_t B,
-                                                const int32_t *__restrict__ sids,
-                                                unsigned int *__restrict__ k32,
-                                                unsigned int *__restrict__ pay,
-                                                int *__restrict__ n_nan) {
+// ---- Ranking of the null samples: every sample's B values sorted (own kernels; replaces a library
+// radix sort).  n_ids independent segments of B keys -> a SAMPLE SORT per segment:
+//   k_rank_splitters  one workgroup per sample: 4096 evenly spaced elements sorted in LDS (bitonic),
+//                     every fourth = one of 1023 splitters
+//   k_rank_bucket     every element: its bucket by binary search among the splitters (LDS), counted
+//   k_rank_scan       exclusive scan of the 1024 bucket sizes of every sample
+//   k_rank_scatter    elements -> their bucket's range (device-scope cursor per bucket)
+//   k_rank_sort       one wave per bucket (~178 elements; <= 1024 sorted in registers, anything bigger
+//                     ranked by counting): rank = bucket start + position; writes the rank pieces
+//                     Rg[group][bin][8] and the sorted values V
+// The sort key is the COMPOSITE (order-preserving image of the value, bin): all keys are distinct, so
+// equal values cannot pile into one bucket whatever the data (constant samples, integer counts), and
+// the ranks are those of a stable sort by value.
+constexpr int RK_NS = 4096;        // sampled elements per segment
+constexpr int RK_NB = 1024;        // buckets per segment
+constexpr int RK_WMAX = 1024;      // bucket size a wave sorts in registers (16 per lane)
+
+struct RKey { unsigned long long k; unsigned int b; };
+__device__ __forceinline__ bool rk_less(unsigned long long ka, unsigned int ba, unsigned long long kb,
+                                        unsigned int bb) {
+  return ka < kb || (ka == kb && ba < bb);
+}
+
+__global__ __launch_bounds__(1024) void k_rank_splitters(const double *__restrict__ Xs, int64_t B,
+                                                         const int32_t *__restrict__ sids,
+                                                         unsigned long long *__restrict__ spk,
+                                                         unsigned int *__restrict__ spb) {
+  __shared__ unsigned long long sk[RK_NS];
+  __shared__ unsigned int sb[RK_NS];
+  const int m = blockIdx.x;
+  const double *x = Xs + (int64_t)sids[m] * B;
+  for (int j = threadIdx.x; j < RK_NS; j += 1024) {
+    const int64_t b = (int64_t)j * B / RK_NS;                    // evenly spaced (B may be < RK_NS: repeats)
+    sk[j] = dkey(x[b]);
+    sb[j] = (unsigned int)b;
+  }
+  for (int size = 2; size <= RK_NS; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < RK_NS / 2; t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool asc = (lo & size) == 0;
+        const unsigned long long kl = sk[lo], kh = sk[hi];
+        const unsigned int bl = sb[lo], bh = sb[hi];
+        if (rk_less(kh, bh, kl, bl) == asc) { sk[lo] = kh; sk[hi] = kl; sb[lo] = bh; sb[hi] = bl; }
+      }
+    }
+  __syncthreads();
+  for (int j = threadIdx.x; j < RK_NB - 1; j += 1024) {
+    spk[(int64_t)m * RK_NB + j] = sk[(RK_NS / RK_NB) * (j + 1) - 1];
+    spb[(int64_t)m * RK_NB + j] = sb[(RK_NS / RK_NB) * (j + 1) - 1];
+  }
+}
+
+// bucket of an element = number of splitters strictly below it (composite order)
+__global__ __launch_bounds__(NT) void k_rank_bucket(const double *__restrict__ Xs, int64_t B,
+                                                    const int32_t *__restrict__ sids,
+                                                    const unsigned long long *__restrict__ spk,
+                                                    const unsigned int *__restrict__ spb,
+                                                    unsigned short *__restrict__ bkt,
+                                                    int *__restrict__ cnt, int *__restrict__ n_nan) {
+  __shared__ unsigned long long sk[RK_NB];
+  __shared__ unsigned int sb[RK_NB];
+  __shared__ int hist[RK_NB];
+  const int m = blockIdx.y;
+  for (int j = threadIdx.x; j < RK_NB; j += NT) {
+    sk[j] = j < RK_NB - 1 ? spk[(int64_t)m * RK_NB + j] : ~0ull;
+    sb[j] = j < RK_NB - 1 ? spb[(int64_t)m * RK_NB + j] : ~0u;
+    hist[j] = 0;
+  }
+  __syncthreads();
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (b < B) {
+    const double x = Xs[(int64_t)sids[m] * B + b];
+    const unsigned long long key = dkey(x);
+    int lo = 0, hi = RK_NB - 1;                       // first splitter that is not below the element
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (rk_less(sk[mid], sb[mid], key, (unsigned int)b)) lo = mid + 1; else hi = mid;
+    }
+    bkt[(int64_t)m * B + b] = (unsigned short)lo;
+    atomicAdd(&hist[lo], 1);
+    if (x != x) atomicAdd(&n_nan[m], 1);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < RK_NB; j += NT)
+    if (hist[j]) atomicAdd(&cnt[(int64_t)m * RK_NB + j], hist[j]);
+}
+
+__global__ __launch_bounds__(RK_NB) void k_rank_scan(const int *__restrict__ cnt, int *__restrict__ start,
+                                                     int *__restrict__ cursor) {
+  __shared__ int part[RK_NB];
+  const int m = blockIdx.x, t = threadIdx.x;
+  const int c = cnt[(int64_t)m * RK_NB + t];
+  part[t] = c;
+  __syncthreads();
+  for (int off = 1; off < RK_NB; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  start[(int64_t)m * RK_NB + t] = part[t] - c;
+  cursor[(int64_t)m * RK_NB + t] = part[t] - c;
+}
+
+__global__ __launch_bounds__(NT) void k_rank_scatter(const double *__restrict__ Xs, int64_t B,
+                                                     const int32_t *__restrict__ sids,
+                                                     const unsigned short *__restrict__ bkt,
+                                                     int *__restrict__ cursor,
+                                                     unsigned long long *__restrict__ tk,
+                                                     unsigned int *__restrict__ tb) {
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
   const int m = blockIdx.y;
   if (b >= B) return;
-  const double x = Xs[(int64_t)sids[m] * B + b];
-  k32[(int64_t)m * B + b] = (unsigned int)dkey(x);
-  pay[(int64_t)m * B + b] = ((unsigned int)m << BIN_BITS) | (unsigned int)b;
-  if (x != x) atomicAdd(&n_nan[m], 1);
+  const int pos = atomicAdd(&cursor[(int64_t)m * RK_NB + bkt[(int64_t)m * B + b]], 1);
+  tk[(int64_t)m * B + pos] = dkey(Xs[(int64_t)sids[m] * B + b]);
+  tb[(int64_t)m * B + pos] = (unsigned int)b;
 }
 
-__global__ __launch_bounds__(NT) void k_nr_key64(const double *__restrict__ Xs, int64_t B,
-                                                 const int32_t *__restrict__ sids,
-                                                 const unsigned int *__restrict__ pay, int64_t n,
-                                                 unsigned long long *__restrict__ k64) {
-  const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (i >= n) return;
-  const unsigned int p = pay[i];
-  const int m = (int)(p >> BIN_BITS);
-  const int64_t b = p & ((1u << BIN_BITS) - 1u);
-  k64[i] = ((unsigned long long)m << 32) | (dkey(Xs[(int64_t)sids[m] * B + b]) >> 32);
+// wave bitonic sort of 64 IPL composite keys, element e = r * 64 + lane (see wave_sort.h)
+template <int IPL>
+__device__ __forceinline__ void wave_sort_rkeys(unsigned long long (&kk)[IPL], unsigned int (&bb)[IPL]) {
+  constexpr int N = 64 * IPL;
+  const int lane = wcx::lane_id();
+#pragma unroll
+  for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+      if (stride >= 64) {
+        const int rs = stride >> 6;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          if ((r & rs) == 0) {
+            const bool asc = (((r * 64) & size) == 0);
+            const unsigned long long a = kk[r], b = kk[r | rs];
+            const unsigned int ia = bb[r], ib = bb[r | rs];
+            if (rk_less(b, ib, a, ia) == asc) { kk[r] = b; kk[r | rs] = a; bb[r] = ib; bb[r | rs] = ia; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const bool asc = (((r * 64 + lane) & size) == 0);
+          const bool lower = ((lane & stride) == 0);
+          const unsigned long long pk = __shfl_xor(kk[r], stride, 64);
+          const unsigned int pb = __shfl_xor(bb[r], stride, 64);
+          const bool p_less = rk_less(pk, pb, kk[r], bb[r]);
+          const bool take = (lower == asc) ? p_less : !p_less;
+          if (take) { kk[r] = pk; bb[r] = pb; }
+        }
+      }
+    }
+  }
 }
 
-// sorted position -> rank of (sample, bin), packed 8 samples to a 32-byte piece, + sorted values
-__global__ __launch_bounds__(NT) void k_nr_scatter(const double *__restrict__ Xs, int64_t B,
-                                                   const int32_t *__restrict__ sids,
-                                                   const unsigned int *__restrict__ pay, int64_t n,
-                                                   unsigned int *__restrict__ Rg,
-                                                   double *__restrict__ V) {
-  const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (i >= n) return;
-  const unsigned int p = pay[i];
-  const int m = (int)(p >> BIN_BITS);
-  const int64_t b = p & ((1u << BIN_BITS) - 1u);
-  const int64_t r = i - (int64_t)m * B;
-  Rg[((int64_t)(m >> 3) * B + b) * 8 + (m & 7)] = (unsigned int)r;
-  V[i] = Xs[(int64_t)sids[m] * B + b];
+template <int IPL>
+__device__ __forceinline__ void rank_bucket_sorted(const unsigned long long *__restrict__ tk,
+                                                   const unsigned int *__restrict__ tb, int n, int64_t base,
+                                                   int m, int64_t B, const double *__restrict__ x,
+                                                   unsigned int *__restrict__ Rg, double *__restrict__ V) {
+  const int lane = wcx::lane_id();
+  unsigned long long kk[IPL];
+  unsigned int bb[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = r * 64 + lane;
+    kk[r] = e < n ? tk[e] : ~0ull;
+    bb[r] = e < n ? tb[e] : ~0u;                      // (padding sorts behind every real key)
+  }
+  wave_sort_rkeys<IPL>(kk, bb);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = r * 64 + lane;
+    if (e < n) {
+      const int64_t b = bb[r];
+      Rg[((int64_t)(m >> 3) * B + b) * 8 + (m & 7)] = (unsigned int)(base + e);
+      V[(int64_t)m * B + base + e] = x[b];
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_rank_sort(const double *__restrict__ Xs, int64_t B,
+                                                  const int32_t *__restrict__ sids,
+                                                  const int *__restrict__ start, const int *__restrict__ cnt,
+                                                  const unsigned long long *__restrict__ tk,
+                                                  const unsigned int *__restrict__ tb,
+                                                  unsigned int *__restrict__ Rg, double *__restrict__ V) {
+  const int lane = wcx::lane_id();
+  const int m = blockIdx.y;
+  const int bk = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  const int n = cnt[(int64_t)m * RK_NB + bk];
+  if (n == 0) return;
+  const int64_t base = start[(int64_t)m * RK_NB + bk];
+  const unsigned long long *k0 = tk + (int64_t)m * B + base;
+  const unsigned int *b0 = tb + (int64_t)m * B + base;
+  const double *x = Xs + (int64_t)sids[m] * B;
+  if (n <= 64) rank_bucket_sorted<1>(k0, b0, n, base, m, B, x, Rg, V);
+  else if (n <= 128) rank_bucket_sorted<2>(k0, b0, n, base, m, B, x, Rg, V);
+  else if (n <= 256) rank_bucket_sorted<4>(k0, b0, n, base, m, B, x, Rg, V);
+  else if (n <= 512) rank_bucket_sorted<8>(k0, b0, n, base, m, B, x, Rg, V);
+  else if (n <= RK_WMAX) rank_bucket_sorted<16>(k0, b0, n, base, m, B, x, Rg, V);
+  else {
+    // a bucket the sample did not predict (never seen; P ~ 1e-7 per bucket): rank by counting
+    for (int e = lane; e < n; e += 64) {
+      const unsigned long long ke = k0[e];
+      const unsigned int be = b0[e];
+      int r = 0;
+      for (int j = 0; j < n; ++j) r += rk_less(k0[j], b0[j], ke, be) ? 1 : 0;
+      Rg[((int64_t)(m >> 3) * B + be) * 8 + (m & 7)] = (unsigned int)(base + r);
+      V[(int64_t)m * B + base + r] = x[be];
+    }
+  }
 }
 
 __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
@@ -418,61 +589,54 @@ extern "C" {
 // Ranking of every null sample (keys, two radix sorts, scatter into rank pieces + sorted values)
 // on stream `st` into the buffer at `base` (layout from rank_layout()).
 struct RankLayout {
-  size_t o_sid, o_nan, o_k32a, o_k32b, o_pa, o_pb, o_k64a, o_k64b, o_rg, o_v, o_tmp, total, tmp_a, tmp_b;
-  int sample_bits, n_sg;
+  size_t o_sid, o_nan, o_cnt, o_start, o_cursor, o_spk, o_spb, o_bkt, o_tk, o_tb, o_rg, o_v, total;
+  int n_sg;
 };
 
-static int rank_layout(int64_t B, int n_ids, hipStream_t st, RankLayout &L) {
+static int rank_layout(int64_t B, int n_ids, hipStream_t, RankLayout &L) {
   const int64_t n = (int64_t)n_ids * B;
   L.n_sg = (n_ids + 7) / 8;
-  L.sample_bits = 1;
-  while ((1 << L.sample_bits) < n_ids) ++L.sample_bits;
-  L.tmp_a = L.tmp_b = 0;
-  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, L.tmp_a, (const unsigned int *)nullptr,
-                                             (unsigned int *)nullptr, (const unsigned int *)nullptr,
-                                             (unsigned int *)nullptr, (int)n, 0, 32, st));
-  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, L.tmp_b, (const unsigned long long *)nullptr,
-                                             (unsigned long long *)nullptr,
-                                             (const unsigned int *)nullptr, (unsigned int *)nullptr,
-                                             (int)n, 0, 32 + L.sample_bits, st));
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   L.o_sid = carve((size_t)n_ids * 4);
   L.o_nan = carve((size_t)n_ids * 4);
-  L.o_k32a = carve((size_t)n * 4); L.o_k32b = carve((size_t)n * 4);
-  L.o_pa = carve((size_t)n * 4); L.o_pb = carve((size_t)n * 4);
-  L.o_k64a = carve((size_t)n * 8); L.o_k64b = carve((size_t)n * 8);
+  L.o_cnt = carve((size_t)n_ids * RK_NB * 4);
+  L.o_start = carve((size_t)n_ids * RK_NB * 4);
+  L.o_cursor = carve((size_t)n_ids * RK_NB * 4);
+  L.o_spk = carve((size_t)n_ids * RK_NB * 8);
+  L.o_spb = carve((size_t)n_ids * RK_NB * 4);
+  L.o_bkt = carve((size_t)n * 2);
+  L.o_tk = carve((size_t)n * 8);
+  L.o_tb = carve((size_t)n * 4);
   L.o_rg = carve((size_t)L.n_sg * B * 32);
   L.o_v = carve((size_t)n * 8);
-  L.o_tmp = carve(L.tmp_a > L.tmp_b ? L.tmp_a : L.tmp_b);
   L.total = off;
   return WCX_OK;
 }
 
 static int rank_run(const double *dXs, int64_t B, int n_ids, const RankLayout &L, char *base,
                     hipStream_t st) {
-  const int64_t n = (int64_t)n_ids * B;
   int32_t *d_sids = reinterpret_cast<int32_t *>(base + L.o_sid);
   int *d_nan = reinterpret_cast<int *>(base + L.o_nan);
-  unsigned int *k32a = reinterpret_cast<unsigned int *>(base + L.o_k32a);
-  unsigned int *k32b = reinterpret_cast<unsigned int *>(base + L.o_k32b);
-  unsigned int *pa = reinterpret_cast<unsigned int *>(base + L.o_pa);
-  unsigned int *pb = reinterpret_cast<unsigned int *>(base + L.o_pb);
-  unsigned long long *k64a = reinterpret_cast<unsigned long long *>(base + L.o_k64a);
-  unsigned long long *k64b = reinterpret_cast<unsigned long long *>(base + L.o_k64b);
+  int *cnt = reinterpret_cast<int *>(base + L.o_cnt);
+  int *start = reinterpret_cast<int *>(base + L.o_start);
+  int *cursor = reinterpret_cast<int *>(base + L.o_cursor);
+  unsigned long long *spk = reinterpret_cast<unsigned long long *>(base + L.o_spk);
+  unsigned int *spb = reinterpret_cast<unsigned int *>(base + L.o_spb);
+  unsigned short *bkt = reinterpret_cast<unsigned short *>(base + L.o_bkt);
+  unsigned long long *tk = reinterpret_cast<unsigned long long *>(base + L.o_tk);
+  unsigned int *tb = reinterpret_cast<unsigned int *>(base + L.o_tb);
   unsigned int *Rg = reinterpret_cast<unsigned int *>(base + L.o_rg);
   double *V = reinterpret_cast<double *>(base + L.o_v);
-  void *tmp = base + L.o_tmp;
   WCX_HIP(hipMemsetAsync(d_nan, 0, (size_t)n_ids * 4, st));
+  WCX_HIP(hipMemsetAsync(cnt, 0, (size_t)n_ids * RK_NB * 4, st));
   if (n_ids & 7) WCX_HIP(hipMemsetAsync(Rg + (int64_t)(L.n_sg - 1) * B * 8, 0, (size_t)B * 32, st));
-  const unsigned gb = (unsigned)((B + NT - 1) / NT), gn = (unsigned)((n + NT - 1) / NT);
-  k_nr_keys<<<dim3(gb, (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, k32a, pa, d_nan);
-  size_t ta = L.tmp_a, tb = L.tmp_b;
-  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, ta, k32a, k32b, pa, pb, (int)n, 0, 32, st));
-  k_nr_key64<<<gn, NT, 0, st>>>(dXs, B, d_sids, pb, n, k64a);
-  WCX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k64a, k64b, pb, pa, (int)n, 0,
-                                             32 + L.sample_bits, st));
-  k_nr_scatter<<<gn, NT, 0, st>>>(dXs, B, d_sids, pa, n, Rg, V);
+  const unsigned gb = (unsigned)((B + NT - 1) / NT);
+  k_rank_splitters<<<(unsigned)n_ids, 1024, 0, st>>>(dXs, B, d_sids, spk, spb);
+  k_rank_bucket<<<dim3(gb, (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, spk, spb, bkt, cnt, d_nan);
+  k_rank_scan<<<(unsigned)n_ids, RK_NB, 0, st>>>(cnt, start, cursor);
+  k_rank_scatter<<<dim3(gb, (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, bkt, cursor, tk, tb);
+  k_rank_sort<<<dim3(RK_NB / (NT / 64), (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, start, cnt, tk, tb, Rg, V);
   WCX_HIP(hipGetLastError());
   return WCX_OK;
 }
