@@ -323,3 +323,44 @@ def test_predict_full_dev_applies_the_blacklist_like_the_host_path(tmp_path):
     for a, b in zip(rows, want):
         assert a[:3] == b[:3]
         np.testing.assert_allclose([float(a[3]), a[4]], [float(b[3]), b[4]], rtol=1e-9, atol=1e-9)
+
+
+def test_predict_cli_batch_equals_single_runs(built, g_pipe, tmp_path, monkeypatch):
+    """`predict --batch LIST` (device-resident batches, dist.predict_batch_dev; also striped over two
+    worker processes sharing the device): the tables of every sample are the ones the one-sample
+    CLI writes."""
+    from wisecondorx_amd import main, npz_io
+    from wisecondorx_amd.synth import Cohort
+    tmp, ref, _ = built
+    co = Cohort(4000000, struct_seed=11, female_y=0.1)
+    specs = [(9001, "M", [(3, 10, 25, 1.5)]), (9002, "F", [(7, 5, 15, 0.5)]), (9003, "M", None),
+             (9004, "F", [(12, 3, 12, 1.5)]), (9005, "F", None)]
+    files = []
+    for seed, g, cnv in specs:
+        f = str(tmp_path / "t{}.npz".format(seed))
+        npz_io.save_sample(f, co.sample(seed, g, reads=4e6, cnv=cnv), 4000000)
+        files.append(f)
+    common = ["--bed", "--minrefbins", "20", "--seed", "3", "--zscore", "4"]
+    for i, f in enumerate(files):
+        main.main(["predict", f, ref, str(tmp_path / "single{}".format(i))] + common)
+    for gpus, tag in ((1, "b"), (2, "p")):
+        lst = str(tmp_path / "list_{}.txt".format(tag))
+        with open(lst, "w") as fh:
+            for i, f in enumerate(files[1:], 1):
+                fh.write("{}\t{}\n".format(f, tmp_path / "{}{}".format(tag, i)))
+        monkeypatch.setenv("WCX_DIST_SHARE_DEVICE", "1")
+        main.main(["predict", files[0], ref, str(tmp_path / "{}0".format(tag)), "--batch", lst,
+                   "--gpus", str(gpus)] + common)
+        for i in range(len(files)):
+            for suffix in ("_bins.bed", "_segments.bed", "_aberrations.bed", "_statistics.txt"):
+                a = open(str(tmp_path / "single{}{}".format(i, suffix))).read()
+                b = open(str(tmp_path / "{}{}{}".format(tag, i, suffix))).read()
+                if a != b:          # same rows; numbers to 1e-9 (batch and single sums differ in order)
+                    la, lb = a.splitlines(), b.splitlines()
+                    assert len(la) == len(lb), (tag, i, suffix)
+                    for x, y in zip(la, lb):
+                        fx, fy = x.split("\t"), y.split("\t")
+                        assert len(fx) == len(fy)
+                        for u, v in zip(fx, fy):
+                            if u != v:
+                                np.testing.assert_allclose(float(u), float(v), rtol=1e-7, atol=1e-9)

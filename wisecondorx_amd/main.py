@@ -231,6 +231,30 @@ def output_gender(args):
     print("male" if predict_gender(sample, ref_file["trained_cutoff"]) == "M" else "female")
 
 
+def _check_mask_alignment(ref_file, ap):
+    """The merged result of predict is inflated with mask{ap}: its autosomal part must select the bins
+    the autosomal reference holds (see build_sub_reference)."""
+    n_aut_masked = int(np.sum(ref_file["mask"]))
+    n_aut = int(np.sum(ref_file["bins_per_chr"]))
+    mask_aut, mask_gon_aut = np.asarray(ref_file["mask"])[:n_aut], np.asarray(ref_file["mask" + ap])[:n_aut]
+    if int(np.sum(mask_gon_aut)) != n_aut_masked:
+        # Upstream fails on the same input: the merged null-ratio table has sum(mask{ap}) rows but
+        # ref_sizes one entry per merged result, so get_post_processed_result raises "IndexError:
+        # boolean index did not match" (predict_control.py:50; run of the reference itself recorded in
+        # tests/golden/mask_skew.npz).  Same outcome here, with the reason spelled out.
+        logging.critical("Reference mask{} holds {} autosomal bins but the autosomal reference {}: "
+                         "the reference was built with a PCA-distance filter skew "
+                         "(newref_control.py:48-54) and cannot be aligned (upstream raises IndexError "
+                         "at predict_control.py:50 for it); rebuild it with newref --aligned-masks".format(
+                             ap, int(np.sum(mask_gon_aut)), n_aut_masked))
+        sys.exit(1)
+    if not np.array_equal(mask_gon_aut, mask_aut):
+        logging.warning("Reference mask{} keeps the same NUMBER of autosomal bins as the autosomal "
+                        "reference but at {} different positions: autosomal results are reported "
+                        "at the positions of mask{} (as upstream does)".format(
+                            ap, int(np.sum(mask_gon_aut != mask_aut)), ap))
+
+
 def tool_test(args):
     logging.info("Starting CNA prediction")
     if not args.bed and not args.plot:
@@ -252,6 +276,15 @@ def tool_test(args):
         sys.exit()
     from . import predict_tools as pt
     from .predict_output import generate_output_tables
+
+    if getattr(args, "batch", None):
+        pairs = [(args.infile, args.outid)]
+        with open(args.batch) as fh:
+            for line in fh:
+                f = line.split()
+                if len(f) >= 2 and not line.startswith("#"):
+                    pairs.append((f[0], f[1]))
+        return tool_test_batch(args, pairs)
 
     logging.info("Importing data ...")
     ref_file = npz_io.load_reference(args.reference)
@@ -296,25 +329,7 @@ def tool_test(args):
         "masked_bins_per_chr_cum": ref_file["masked_bins_per_chr_cum" + ap],
     }
     m_lr = res_a[4]
-    n_aut_masked = int(np.sum(ref_file["mask"]))
-    n_aut = int(np.sum(ref_file["bins_per_chr"]))
-    mask_aut, mask_gon_aut = np.asarray(ref_file["mask"])[:n_aut], np.asarray(ref_file["mask" + ap])[:n_aut]
-    if int(np.sum(mask_gon_aut)) != n_aut_masked:
-        # Upstream fails on the same input: the merged null-ratio table has sum(mask{ap}) rows but
-        # ref_sizes one entry per merged result, so get_post_processed_result raises "IndexError:
-        # boolean index did not match" (predict_control.py:50; run of the reference itself recorded in
-        # tests/golden/mask_skew.npz).  Same outcome here, with the reason spelled out.
-        logging.critical("Reference mask{} holds {} autosomal bins but the autosomal reference {}: "
-                         "the reference was built with a PCA-distance filter skew "
-                         "(newref_control.py:48-54) and cannot be aligned (upstream raises IndexError "
-                         "at predict_control.py:50 for it); rebuild it with newref --aligned-masks".format(
-                             ap, int(np.sum(mask_gon_aut)), n_aut_masked))
-        sys.exit(1)
-    if not np.array_equal(mask_gon_aut, mask_aut):
-        logging.warning("Reference mask{} keeps the same NUMBER of autosomal bins as the autosomal "
-                        "reference but at {} different positions: autosomal results are reported "
-                        "at the positions of mask{} (as upstream does)".format(
-                            ap, int(np.sum(mask_gon_aut != mask_aut)), ap))
+    _check_mask_alignment(ref_file, ap)
     r, z, w, ref_sizes, weights_ok = pt.merge_autosomes_gonosomes(res_a, res_g)
     if not weights_ok:       # main.py:252-256
         logging.warning("Non-numeric values found in weights -- reference too small. "
@@ -346,6 +361,94 @@ def tool_test(args):
                         "the MI355X hot path and is skipped")
     logging.info("Finished prediction")
     return results
+
+
+# --------------------------------------------------------------------------- predict, batches
+def _batch_worker(rank, world, args, pairs):
+    """One process per GPU: this rank's stripe of the batch (dist.stripe -- no collective on this
+    path, docs/include/pipeline/predict.sh:21 loops the samples), device-resident end to end
+    (dist.predict_batch_dev): counts -> coverage normalisation + PCA projection -> three
+    normalisation passes for autosomes and gonosomes -> merge / post-processing -> ONE batched CBS and
+    segment-z call per chunk -> the reference's tables per sample."""
+    import torch
+    from . import _lib, dist as wd, predict_tools as pt
+    from .predict_output import generate_output_tables
+    n_dev = torch.cuda.device_count()
+    dev_index = rank % n_dev if os.environ.get("WCX_DIST_SHARE_DEVICE") else rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    ctx = _lib.Context(dev_index, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx)
+    mine = wd.stripe(pairs, rank, world)
+    if not mine:
+        return
+    ref_file = npz_io.load_reference(args.reference)
+    binsize = int(ref_file["binsize"])
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    A = {"idx": tt(ref_file["indexes"]), "dist": tt(ref_file["distances"]), "nr": tt(ref_file["null_ratios"]),
+         "cum": [int(v) for v in ref_file["masked_bins_per_chr_cum"]]}
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=npz_io._THREADS) as ex:
+        loaded = list(ex.map(lambda p_: npz_io.load_sample(p_[0]), mine))
+    groups = {}
+    for (infile, outid), (sample, sample_binsize) in zip(mine, loaded):
+        n_reads = sum([sum(sample[x]) for x in sample.keys()])
+        sample = scale_sample(sample, int(sample_binsize), binsize)
+        gender = predict_gender(sample, ref_file["trained_cutoff"])
+        if not ref_file["is_nipt"]:
+            gender = args.gender or gender
+            sample = gender_correct(sample, gender)
+            ref_gender = gender
+            if not ref_file["has_male"] and gender == "M":
+                ref_gender = "F"
+            elif not ref_file["has_female"] and gender == "F":
+                ref_gender = "M"
+        else:
+            gender = args.gender or gender
+            ref_gender = "F"
+        groups.setdefault(ref_gender, []).append((infile, outid, sample, gender, n_reads))
+    chunk = max(1, int(getattr(args, "batch_size", 96) or 96))
+    for ref_gender, items in groups.items():
+        ap = ".{}".format(ref_gender)
+        _check_mask_alignment(ref_file, ap)
+        G = {"idx": tt(ref_file["indexes" + ap]), "dist": tt(ref_file["distances" + ap]),
+             "nr": tt(ref_file["null_ratios" + ap]),
+             "cum": [int(v) for v in ref_file["masked_bins_per_chr_cum" + ap]]}
+        rem = {"args": args, "binsize": binsize, "ref_gender": ref_gender, "mask": ref_file["mask" + ap],
+               "bins_per_chr": ref_file["bins_per_chr" + ap],
+               "masked_bins_per_chr": ref_file["masked_bins_per_chr" + ap],
+               "masked_bins_per_chr_cum": ref_file["masked_bins_per_chr_cum" + ap]}
+        off = np.concatenate(([0], np.cumsum(rem["bins_per_chr"]))).astype(int)
+        prep_cache = {}
+        for c0 in range(0, len(items), chunk):
+            part = items[c0:c0 + chunk]
+            samples = [it[2] for it in part]
+            xA = pt.prepare_batch_dev(tt(pt.sample_counts_matrix(samples, ref_file, "")), ref_file, "", ctx,
+                                      prep_cache)
+            xG = pt.prepare_batch_dev(tt(pt.sample_counts_matrix(samples, ref_file, ap)), ref_file, ap, ctx,
+                                      prep_cache)
+            rows, host = wd.predict_batch_dev(be, A, G, xA, xG, rem, pt, want_host=True)
+            for i, (infile, outid, _, gender, n_reads) in enumerate(part):
+                results = {"results_nr": pt.ATTACHED, "results_c": rows[i]}
+                for row, key in enumerate(("results_r", "results_z", "results_w")):
+                    full = host[row, i]
+                    results[key] = [full[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+                a_i = argparse.Namespace(**dict(vars(args), infile=infile, outid=outid))
+                rem_i = dict(rem, args=a_i, n_reads=n_reads, gender=gender)
+                if args.bed:
+                    generate_output_tables(rem_i, results, ctx)
+                logging.info("Finished prediction of {} -> {}".format(infile, outid))
+
+
+def tool_test_batch(args, pairs):
+    """`predict ... --batch LIST`: every (infile, outid) of LIST next to the positional pair, striped
+    over --gpus devices (one process per GPU, no collective; BASELINE configs[4])."""
+    world = max(1, int(getattr(args, "gpus", 1) or 1))
+    if world == 1:
+        _batch_worker(0, 1, args, pairs)
+        return
+    import torch.multiprocessing as mp
+    mp.spawn(_batch_worker, args=(world, args, pairs), nprocs=world, join=True)
 
 
 # --------------------------------------------------------------------------- CLI
@@ -408,6 +511,12 @@ def build_parser():
     p.add_argument("--cairo", action="store_true", help="Uses cairo bitmap type for plotting.")
     p.add_argument("--add-plot-title", action="store_true", help="Add the output name as plot title")
     p.add_argument("--seed", type=int, default=None, help="Seed for segmentation algorithm")
+    p.add_argument("--batch", type=str, default=None,
+                   help="Text file with further 'infile outid' pairs, one per line: all samples are "
+                        "predicted device-resident in batches (the positional infile / outid is the first)")
+    p.add_argument("--batch-size", type=int, default=96, help="Samples per device batch (--batch)")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="--batch: stripe the samples over this many MI355X devices (one process each)")
     p.add_argument("--regions", type=str, default=None, help="Regions .bed to summarise")
     p.set_defaults(func=tool_test)
     return parser

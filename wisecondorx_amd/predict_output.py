@@ -15,10 +15,11 @@ def _chr_name(c):
     return {"23": "X", "24": "Y"}.get(name, name)
 
 
-def generate_output_tables(rem_input, results):
+def generate_output_tables(rem_input, results, ctx=None):
+    """ctx: the library context that holds the attached null matrix (default: the default context)."""
     _generate_bins_bed(rem_input, results)
     _generate_segments_and_aberrations_bed(rem_input, results)
-    _generate_chr_statistics_file(rem_input, results)
+    _generate_chr_statistics_file(rem_input, results, ctx)
     if rem_input["args"].regions is not None:
         _generate_regions_bed(rem_input, results)
 
@@ -76,7 +77,7 @@ def _generate_segments_and_aberrations_bed(rem_input, results):
                 abr_f.write(line + "\tloss\n")
 
 
-def _generate_chr_statistics_file(rem_input, results):
+def _generate_chr_statistics_file(rem_input, results, ctx=None):
     n_chr = len(results["results_r"])
     with np.errstate(all="ignore"):
         means = [np.ma.average(np.asarray(results["results_r"][c], dtype=float),
@@ -90,7 +91,7 @@ def _generate_chr_statistics_file(rem_input, results):
     results_c_chr = [[c, 0, rem_input["bins_per_chr"][c] - 1, means[c]] for c in range(n_chr)]
     msv = round(float(get_median_segment_variance(results["results_c"], results["results_r"])), 5)
     cpa = round(float(get_cpa(results["results_c"], rem_input["binsize"])), 5)
-    chr_z = get_z_score(results_c_chr, results)
+    chr_z = get_z_score(results_c_chr, results, ctx)
     with open("{}_statistics.txt".format(rem_input["args"].outid), "w") as fh:
         fh.write("chr\tratio.mean\tratio.median\tzscore\n")
         for c in range(n_chr):
