@@ -37,14 +37,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 vector == matrix (not in the guide)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA
 SPINUP_STEPS = int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "0"))   # extra untimed steps (0: only --warmup)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "screen_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "screen_traffic.json")
 
 
 def screen_source_sha():
     """Hash of the screen kernel's sources: roofline.traffic (PMC counters recorded by
     scripts/measure_traffic.sh) is only reported while the kernel is the one that was profiled."""
     h = hashlib.sha256()
-    for f in ("screen_kernel.h", "screen_common.h", "newref_topk_screen.hip"):
+    for f in ("screen_kernel.h", "screen_sym.h", "screen_common.h", "newref_topk_screen.hip"):
         h.update(open(os.path.join(ROOT, "wisecondorx_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -188,6 +188,16 @@ class Workload:
         if args.debug_flags:
             self.ctx.lib.wcx_debug_flags(self.ctx.h, args.debug_flags)
         self.backend = wd.GpuBackend(self.ctx)
+        # the gonosomal passes on their own contexts / streams, side by side with the autosomal pass
+        # (they search ~10 k rows each: less than one round of workgroups)
+        self.side = {}
+        if world == 1 and args.concurrent_passes and not args.debug_flags:
+            for tag in ("F", "M"):
+                st_ = torch.cuda.Stream(device=dev)
+                cx_ = _lib.Context(dev_index, st_.cuda_stream)
+                self.side[tag] = (st_, cx_, wd.GpuBackend(cx_))
+            self.sweep_event = _lib.vp()
+            _lib.check(self.ctx.lib.wcx_sweep_event(self.ctx.h, _lib.C.byref(self.sweep_event)))
         self.P = {}
         self.pairs_total = 0
         for tag in ("A", "F", "M"):
@@ -235,10 +245,25 @@ class Workload:
         self.stats_A = None
 
     def step(self, record):
+        from wisecondorx_amd import _lib as _lib_
         wd, ctx, torch = self.wd, self.ctx, self.torch
         ref = {}
+        side, done = self.side, {}
         for tag in ("A", "F", "M"):
             P = self.P[tag]
+            if tag in side:
+                # starts when the A pass's sweep is done: its MFMA sweep runs beside A's L2-bound refine
+                st_, cx_, be_ = side[tag]
+                cx_.timer_tag(tag + ":")
+                with torch.cuda.stream(st_):
+                    _lib_.check(ctx.lib.wcx_wait_event(cx_.h, self.sweep_event))
+                    idx, dist_, nr = wd.newref_gonosomal_sharded(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
+                                                                 be_, self.rank, self.world, P["bufs"])
+                    done[tag] = torch.cuda.Event()
+                    done[tag].record()
+                cx_.timer_tag("")
+                ref[tag] = {"idx": idx, "dist": dist_, "nr": nr, "cum": P["cum"]}
+                continue
             ctx.timer_tag(tag + ":")
             if tag == "A":
                 # ONE exchange (all-gather of the row shards of X over RCCL/xGMI), the search + null
@@ -270,6 +295,8 @@ class Workload:
                                                              self.backend, self.rank, self.world, P["bufs"])
             ref[tag] = {"idx": idx, "dist": dist_, "nr": nr, "cum": P["cum"]}
         ctx.timer_tag("")
+        for tag in done:
+            torch.cuda.current_stream().wait_event(done[tag])
         self.last_ref = ref
         # predict ONE sample, complete (replica on every rank): autosomes vs A, gonosomes vs F
         t0 = time.perf_counter()
@@ -281,8 +308,9 @@ class Workload:
             for name in ("cbs", "segment_z", "cutoff", "weights"):
                 self.ms[name].append(ctx.kernel_ms(name))
             for tag in ("A", "F", "M"):
+                cx_ = self.side[tag][1] if tag in self.side else ctx
                 for n_ in self.names:
-                    self.ms["{}:{}".format(tag, n_)].append(ctx.kernel_ms("{}:{}".format(tag, n_)))
+                    self.ms["{}:{}".format(tag, n_)].append(cx_.kernel_ms("{}:{}".format(tag, n_)))
             self.fb_rows.append(self.stats_A["fallback_rows"] if self.stats_A else -1)
 
     def mean_ms(self, name):
@@ -315,6 +343,10 @@ class Workload:
                  "executed_tflops": (0.5 + 1.0 / 16 if sym else 1.0) * 2.0 * nk * 16 * pairs_A / (screen_ms * 1e-3) / 1e12,
                  "prep_ms": self.mean_ms("A:topk_prep"), "refine_ms": self.mean_ms("A:topk_refine"),
                  "topk_total_ms": k_ms, "pairs_per_launch": pairs_A,
+                 "concurrent_passes": bool(self.side),
+                 "refine_ms_note": ("the F / M passes run beside this refine (--concurrent-passes 1): alone it "
+                                    "takes 22.6 ms at 15 kb x 500 (profiles/r04/kernel_stats_S500.csv)")
+                 if self.side else "",
                  "fallback_rows": stats["fallback_rows"], "fallback_rows_per_step": self.fb_rows,
                  "compactions": stats["compactions"], "appends": stats["appends"],
                  "refined_pairs": stats["refined"], "sym_gates": stats.get("sym_gates", 0),
@@ -536,6 +568,11 @@ def main():
                          "side by side, no collective on the data path; 'scaling': 'weak') instead of "
                          "row-sharding ONE reference over the ranks (the default, 'strong')")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling ablations (invalid results)")
+    ap.add_argument("--concurrent-passes", type=int, default=1,
+                    help="1 (default, one GPU) = the F / M passes run on their own contexts and streams and "
+                         "start when the A pass's sweep is done (wcx_sweep_event): their MFMA sweeps beside "
+                         "A's L2-bound refine (15 kb x 500: step 72.4 -> 71.3 ms, x 100: 39.8 -> 37.6 ms); "
+                         "0 = one pass after the other, clean per-pass kernel times")
     args = ap.parse_args()
 
     import torch
@@ -586,7 +623,7 @@ def main():
                 and (args.binsize, args.refsize) == (15000, 300):
             e = tj["workloads"][key]
             rf["traffic"] = e["fetch_bytes_per_sweep_corrected_x2"] + e["write_bytes_per_sweep"]
-            rf["traffic_source"] = "profiles/r03/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
+            rf["traffic_source"] = "profiles/r04/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
                                    "WRITE_SIZE; bytes per screen sweep; kernel_sha {})".format(
                                        tj["kernel_sha"])
     if screen_ms >= 0:

@@ -56,6 +56,13 @@ int wcx_ctx_destroy(wcx_ctx *ctx);
  * results are INVALID; bits 8.. = compaction trigger level.  Returns the previous value. */
 int wcx_debug_flags(wcx_ctx *ctx, int flags);
 int wcx_sync(wcx_ctx *ctx);
+/* Overlap of INDEPENDENT searches on several contexts of one device (the A, F and M passes of newref,
+ * newref_control.py:90-109 runs them one after another): wcx_sweep_event returns the event this context's
+ * searches record when their MFMA sweep is done and the L2-bound exact refine begins; another context
+ * told to wcx_wait_event on it starts its own (MFMA-bound) sweep beside that refine.  Must be called
+ * AFTER the search that records the event has been enqueued. */
+int wcx_sweep_event(wcx_ctx *ctx, void **out_event);
+int wcx_wait_event(wcx_ctx *ctx, void *event);
 int wcx_malloc(wcx_ctx *ctx, size_t bytes, void **dptr);
 int wcx_free(wcx_ctx *ctx, void *dptr);
 int wcx_memcpy_h2d(wcx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);

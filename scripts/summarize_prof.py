@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_r03 (scripts/measure_traffic.sh) into profiles/r03/:
+"""Condense gpurun_out/prof_<round> (scripts/measure_traffic.sh) into profiles/<round>/ (round = $WCX_PROF_ROUND, default r04):
   kernel_stats_S<S>.csv     rocprofv3 --kernel-trace --stats summary of the bench command
   pmc_S<S>.csv              per-kernel sums of every counter (all PMC passes) + dispatch counts
   screen_traffic.json       per-sweep HBM bytes and SQ breakdown of k_screen, keyed by workload, with
@@ -16,8 +16,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r03")
-DST = os.path.join(ROOT, "profiles", "r03")
+ROUND = os.environ.get("WCX_PROF_ROUND", "r04")
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
+DST = os.path.join(ROOT, "profiles", ROUND)
 
 
 def short_name(full):
@@ -58,7 +59,9 @@ def main():
                                recursive=True):
                 for r in csv.DictReader(open(f)):
                     name = short_name(r["Kernel_Name"])
-                    if "k_screen<" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]:
+                    if "k_screen_sym<" in r["Kernel_Name"]:
+                        name = "k_screen_sym"       # the symmetric sweep of the autosomal pass (one launch)
+                    elif "k_screen<" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]:
                         # the step runs three passes: the autosomal one (all S samples: the largest
                         # NK of the run) is the dominant kernel, the two gonosomal ones (S / 2
                         # samples) are kept apart
@@ -75,10 +78,16 @@ def main():
             for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0.0)):
                 fh.write(k.replace(",", ";") + "," + ",".join(str(agg[k].get(c, 0.0)) for c in counters)
                          + "," + str(len(disp[(k, 1)])) + "\n")
-        p = agg["k_screen"]
+        # the autosomal sweep = (symmetric path) the pre-pass k_screen + k_screen_sym, or k_screen alone
+        sym = "k_screen_sym" in agg
+        p = collections.defaultdict(float)
+        for part in (("k_screen", "k_screen_sym") if sym else ("k_screen",)):
+            for c_, v_ in agg[part].items():
+                p[c_] += v_
         wave = p.get("SQ_WAVE_CYCLES", 0.0)
         out["workloads"]["S%d" % S] = {
-            "launches_per_sweep": len(disp[("k_screen", 1)]) / sweeps,
+            "kernels": "k_screen (sampled pre-pass) + k_screen_sym" if sym else "k_screen",
+            "launches_per_sweep": (len(disp[("k_screen", 1)]) + len(disp[("k_screen_sym", 1)])) / sweeps,
             "fetch_bytes_per_sweep_raw": p.get("FETCH_SIZE", 0.0) * 1024 / sweeps,
             "fetch_bytes_per_sweep_corrected_x2": 2 * p.get("FETCH_SIZE", 0.0) * 1024 / sweeps,
             "write_bytes_per_sweep": p.get("WRITE_SIZE", 0.0) * 1024 / sweeps,

@@ -22,6 +22,8 @@ vp = C.c_void_p
 SIGNATURES = {
     "wcx_version": (C.c_int, []),
     "wcx_debug_flags": (C.c_int, [vp, C.c_int]),
+    "wcx_sweep_event": (C.c_int, [vp, C.POINTER(vp)]),
+    "wcx_wait_event": (C.c_int, [vp, vp]),
     "wcx_timer_tag": (C.c_int, [vp, C.c_char_p]),
     "wcx_predict_prep_dev": (C.c_int, [vp, vp, C.c_int, c_i64, vp, c_i64, vp, vp, C.c_int, vp]),
     "wcx_last_error": (C.c_char_p, []),

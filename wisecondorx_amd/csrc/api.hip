@@ -159,6 +159,21 @@ extern "C" {
 
 int wcx_version(void) { return 100; }
 
+int wcx_sweep_event(wcx_ctx *ctx, void **out_event) {
+  WCX_ARG(ctx && out_event, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  if (!ctx->ev_after_sweep) WCX_HIP(hipEventCreateWithFlags(&ctx->ev_after_sweep, hipEventDisableTiming));
+  *out_event = ctx->ev_after_sweep;
+  return WCX_OK;
+}
+
+int wcx_wait_event(wcx_ctx *ctx, void *event) {
+  WCX_ARG(ctx && event, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  WCX_HIP(hipStreamWaitEvent(ctx->stream, reinterpret_cast<hipEvent_t>(event), 0));
+  return WCX_OK;
+}
+
 int wcx_debug_flags(wcx_ctx *ctx, int flags) {
   if (!ctx) return 0;
   const int old = ctx->debug_flags;
@@ -228,6 +243,7 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
     hipEventDestroy(ctx->ev_sweep0);
     hipEventDestroy(ctx->ev_sweep1);
   }
+  if (ctx->ev_after_sweep) hipEventDestroy(ctx->ev_after_sweep);
   if (ctx->aux_stream) {
     hipStreamSynchronize(ctx->aux_stream);
     hipStreamDestroy(ctx->aux_stream);

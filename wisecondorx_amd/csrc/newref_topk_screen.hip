@@ -972,6 +972,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_screen");
   if (rc) return rc;
+  if (ctx->ev_after_sweep) WCX_HIP(hipEventRecord(ctx->ev_after_sweep, st));   // (wcx_sweep_event)
   if (kick_at == 1) {
     rc = wcx_aux_kick(ctx);
     if (rc) return rc;
@@ -1342,6 +1343,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_screen");
   if (rc) return rc;
+  if (ctx->ev_after_sweep) WCX_HIP(hipEventRecord(ctx->ev_after_sweep, st));   // (wcx_sweep_event)
   if (kick_at == 1) {
     rc = wcx_aux_kick(ctx);
     if (rc) return rc;

@@ -67,6 +67,7 @@ struct wcx_ctx {
   hipEvent_t ev_main = nullptr, ev_rank = nullptr;
   hipStream_t sweep_stream = nullptr;        // second stream of the screen sweep (see wcx_topk_screen_launch)
   hipEvent_t ev_sweep0 = nullptr, ev_sweep1 = nullptr;
+  hipEvent_t ev_after_sweep = nullptr;       // recorded by every search after its sweep (wcx_sweep_event)
   void *d_rank = nullptr;
   size_t rank_bytes = 0;
   const double *rank_X = nullptr;
