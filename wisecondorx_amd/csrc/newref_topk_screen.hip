@@ -606,9 +606,11 @@ __global__ __launch_bounds__(NT) void k_sym_final(const RowInfo *__restrict__ in
     }
     uint2 *row = sl + r * (int64_t)CAP2;
     unsigned int key[IPL], idx[IPL];
+    const int nq = (c + 63) >> 6;             // (wave-uniform: only the slices that hold entries are read)
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
-      const uint2 v = row[q * 64 + lane];
+      uint2 v = make_uint2(0u, 0u);
+      if (q < nq) v = row[q * 64 + lane];
       key[q] = (q * 64 + lane < c) ? f32_key(__uint_as_float(v.x)) : 0xffffffffu;
       idx[q] = v.y;
     }
