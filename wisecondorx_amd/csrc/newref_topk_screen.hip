@@ -671,6 +671,17 @@ bool wcx_screen_supported(int64_t B, int S, int k) {
   return S <= 508 && k <= 512 && k <= LIM && B >= 2048;
 }
 
+static int env_int(const char *name, int dflt);
+// Row pitch of the row-major copy Xr the refine gathers from, in doubles: rows start on 128-byte
+// lines (16 doubles), so that a 16-sample chunk of a candidate row is ONE aligned cache line -- with
+// a 32-byte-aligned pitch (4 000-byte rows at S = 500) every chunk straddles two lines and the L2s
+// see twice the requests.  WCX_ROW_ALIGN overrides (doubles; multiple of 4).
+static int row_pitch(int S) {
+  int a = env_int("WCX_ROW_ALIGN", 16);
+  if (a < 4 || (a & 3)) a = 4;
+  return (S + a - 1) / a * a;
+}
+
 static int env_int(const char *name, int dflt) {
   const char *e = getenv(name);
   return e && *e ? atoi(e) : dflt;
@@ -707,7 +718,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
                            int SF, int cut_r, int slots, int k, int32_t *d_out_idx,
                            double *d_out_dist) {
   const int NK = cfg.nk, CTG = cfg.ctg, GRr = CTG * 32;
-  const int Sp = (S + 3) & ~3;
+  const int Sp = row_pitch(S);
   const int64_t n_rows = B;
   const int64_t n_s = (B + SF - 1) / SF;
   const int64_t P_s = (n_s + CT - 1) / CT * CT;
@@ -1129,7 +1140,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_glob = carve(sizeof(ScreenGlobals));
   const size_t o_mean = carve((size_t)S * 8 * 5);   // mean | sum | count | min | max
-  const int Sp = (S + 3) & ~3;
+  const int Sp = row_pitch(S);
   const size_t o_xr = carve((size_t)B * Sp * 8 + 256);   // + slack: refine loads whole 128-B chunks
   const size_t o_F = carve((size_t)Bpad * NK * 32);  // Bpad/32 tiles * NK * 1 KiB
   const size_t o_info = carve((size_t)Bpad * sizeof(RowInfo));
