@@ -479,25 +479,35 @@ constexpr int SYM_NCLS = 32;               // coarse norm classes: float bits of
 constexpr int SYM_NCELL = SYM_NCLS * 32;   // (class, chromosome) cells, each padded to whole 32-row tiles
 constexpr float SYM_DMAX = 4.0e9f;         // thresholds at or above this: the row goes to the exact kernel
 
+constexpr int SYM_NSUB = 4;                // norm sub-steps inside a class (order only: no padding)
+
 __global__ __launch_bounds__(NT) void k_sym_hist(const unsigned int *__restrict__ rbits,
                                                  const int *__restrict__ rchr, int64_t B,
                                                  const ScreenGlobals *__restrict__ glob,
-                                                 int *__restrict__ rkey, int *__restrict__ cellcnt) {
-  __shared__ int lh[SYM_NCELL];
-  for (int i = threadIdx.x; i < SYM_NCELL; i += NT) lh[i] = 0;
+                                                 int *__restrict__ rkey, int *__restrict__ cellcnt,
+                                                 int suborder) {
+  __shared__ int lh[SYM_NCELL * SYM_NSUB];
+  for (int i = threadIdx.x; i < SYM_NCELL * SYM_NSUB; i += NT) lh[i] = 0;
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
   if (b < B) {
     const unsigned int umin = 0xffffffffu - glob->uinv;
     const unsigned int u = rbits[b];
-    unsigned int cls = SYM_NCLS - 1;                    // non-finite rows go last
-    if (u != 0xffffffffu && u >= umin) { cls = (u - umin) >> 2; if (cls > SYM_NCLS - 2) cls = SYM_NCLS - 2; }
-    const int key = (int)cls * 32 + rchr[b];
+    unsigned int cls = SYM_NCLS - 1, sub = 0;           // non-finite rows go last
+    if (u != 0xffffffffu && u >= umin) {
+      cls = (u - umin) >> 2;
+      sub = suborder ? ((u - umin) & 3u) : 0u;
+      if (cls > SYM_NCLS - 2) { cls = SYM_NCLS - 2; sub = SYM_NSUB - 1; }
+    }
+    // inside a (class, chromosome) cell the rows are ordered by the finer norm steps: the rows of a
+    // tile then have similar norms -- and similar thresholds, which is what the row-direction gate
+    // of the symmetric sweep (one threshold per streamed tile) wants
+    const int key = ((int)cls * 32 + rchr[b]) * SYM_NSUB + (int)sub;
     rkey[b] = key;
     atomicAdd(&lh[key], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < SYM_NCELL; i += NT)
+  for (int i = threadIdx.x; i < SYM_NCELL * SYM_NSUB; i += NT)
     if (lh[i]) atomicAdd(&cellcnt[i], lh[i]);
 }
 
@@ -509,7 +519,10 @@ __global__ __launch_bounds__(SYM_NCELL) void k_sym_scan(const int *__restrict__ 
                                                         ScreenGlobals *__restrict__ glob) {
   __shared__ int part[SYM_NCELL];
   const int t = threadIdx.x;
-  const int padded = (cellcnt[t] + 31) & ~31;
+  int sub[SYM_NSUB], total = 0;
+#pragma unroll
+  for (int j = 0; j < SYM_NSUB; ++j) { sub[j] = cellcnt[t * SYM_NSUB + j]; total += sub[j]; }
+  const int padded = (total + 31) & ~31;
   part[t] = padded;
   __syncthreads();
   for (int off = 1; off < SYM_NCELL; off <<= 1) {
@@ -519,7 +532,9 @@ __global__ __launch_bounds__(SYM_NCELL) void k_sym_scan(const int *__restrict__ 
     __syncthreads();
   }
   const int start = part[t] - padded;
-  cursor[t] = start;
+  int run = start;
+#pragma unroll
+  for (int j = 0; j < SYM_NSUB; ++j) { cursor[t * SYM_NSUB + j] = run; run += sub[j]; }
   for (int i = start >> 5; i < (start + padded) >> 5; ++i) tchr[i] = (unsigned char)(t & 31);
   if (t == SYM_NCELL - 1) glob->n_tiles = (unsigned int)((((start + padded) >> 5) + 3) & ~3);
 }
@@ -847,7 +862,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   WCX_HIP(hipMemsetAsync(cursor, 0, (size_t)2 * NCELL * 4, st));
   WCX_HIP(hipMemsetAsync(perm, 0xff, (size_t)PB * 4, st));
   WCX_HIP(hipMemsetAsync(tchr, 0xff, (size_t)NTb, st));
-  k_sym_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt);
+  k_sym_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt, env_int("WCX_SYM_SUBORDER", 1));
   k_sym_scan<<<1, SYM_NCELL, 0, st>>>(cellcnt, cursor, tchr, glob);
   k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
   const unsigned gprep = (unsigned)((PB + NT - 1) / NT), gprep_s = (unsigned)((P_s + NT - 1) / NT);
