@@ -364,3 +364,25 @@ def test_predict_cli_batch_equals_single_runs(built, g_pipe, tmp_path, monkeypat
                         for u, v in zip(fx, fy):
                             if u != v:
                                 np.testing.assert_allclose(float(u), float(v), rtol=1e-7, atol=1e-9)
+
+
+def test_newref_cli_multi_process_equals_one_process(built, tmp_path, monkeypatch):
+    """`newref --gpus 2`: one process per rank (here gloo, both ranks on the one device), every rank
+    prepares the pass, keeps its row shard of the corrected matrix, ONE all-gather per pass
+    (dist.newref_sharded / newref_gonosomal_sharded), rank 0 writes -- the same reference file as the
+    one-process build: masks, PCA, indexes, distances and null ratios bit for bit."""
+    from wisecondorx_amd import main
+    tmp, ref1, infiles = built
+    monkeypatch.setenv("WCX_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("WCX_DIST_SHARE_DEVICE", "1")
+    out = str(tmp_path / "ref2.npz")
+    random.seed(11)
+    main.main(["newref"] + infiles + [out, "--binsize", "4000000", "--refsize", "60", "--yfrac", "0.004",
+                                      "--gpus", "2"])
+    a, b = np.load(ref1, allow_pickle=True), np.load(out, allow_pickle=True)
+    assert sorted(a.files) == sorted(b.files)
+    for key in a.files:
+        if a[key].dtype.kind == "f":
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+        else:
+            assert np.array_equal(a[key], b[key]), key

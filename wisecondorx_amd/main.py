@@ -84,7 +84,58 @@ def train_gender_model(args, samples):
     return genders.tolist(), cut_off
 
 
-def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, contexts, dc=None, sel=None):
+class _DevMatrix:
+    """A device pointer as a zero-copy torch tensor (`torch.as_tensor` reads __cuda_array_interface__)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": "<f8",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def _build_sub_reference_sharded(args, gender, total_mask, bins_per_chr, dc, sel, frozen, rd):
+    """One pass of a multi-process build (newref --gpus N, one process per GPU; rd = rank, world,
+    dist backend object): every rank prepares the pass on its own device, keeps ITS rows of the corrected
+    matrix (newref_tools._get_part over the rows, newref_tools.py:244-247), and the ranks exchange them
+    with ONE all-gather over RCCL / xGMI (dist.newref_sharded); each searches its own target rows and the
+    finished row blocks are all-gathered so that rank 0 can write the file (newref_control.py:90-109
+    does the same split into parts, through files)."""
+    import ctypes as C
+    import torch
+    from . import _lib, dist as wd
+    rank, world, backend = rd
+    ctx = backend.ctx
+    p = prep.prepare_dev(dc, sel, gender, total_mask, bins_per_chr, frozen=frozen)
+    p.pop("X")
+    S = int(p.pop("n_samples"))
+    cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
+    B, k = cum[-1], int(args.refsize)
+    sample_ids = np.asarray(random.sample(range(S), min(S, 100)), dtype=np.int32)   # newref_tools.py:214-217
+    dX = C.c_void_p()
+    _lib.check(ctx.lib.wcx_pca_corrected_dev(ctx.h, C.byref(dX)))
+    Xs = torch.as_tensor(_DevMatrix(dX.value, (S, B)), device=torch.device("cuda", ctx.device))
+    rb, re_ = wd.row_shard(rank, world, B)
+    local = torch.zeros((wd.max_shard_rows(world, B), S), dtype=torch.float64, device=Xs.device)
+    local[:re_ - rb] = Xs[:, rb:re_].t()
+    if gender == "A":
+        idx_l, dist_l, nr_l, _ = wd.newref_sharded(local, B, cum, k, sample_ids, backend, rank, world)
+        idx, dist_, nr = wd.gather_reference3(idx_l, dist_l, nr_l, B, world, backend)
+    else:
+        dev = Xs.device
+        full = (torch.empty((B, k), dtype=torch.int32, device=dev),
+                torch.empty((B, k), dtype=torch.float64, device=dev),
+                torch.empty((B, len(sample_ids)), dtype=torch.float64, device=dev))
+        idx, dist_, nr = wd.newref_gonosomal_sharded(local, B, cum, k, sample_ids, backend, rank, world, full)
+    out = dict(p)
+    out["binsize"] = args.binsize
+    if rank == 0:
+        out["indexes"], out["distances"], out["null_ratios"] = (t.cpu().numpy() for t in (idx, dist_, nr))
+    else:
+        torch.cuda.synchronize()
+    return out
+
+
+def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, contexts, dc=None, sel=None,
+                        rd=None):
     """One of the A / F / M passes: tool_newref_prep + tool_newref_main + tool_newref_post
     (newref_control.py:24-189) without the temp-file round trips.
     dc / sel: the cohort's device-resident counts (prep.DeviceCounts) and this pass's sample
@@ -100,6 +151,8 @@ def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, context
     frozen = 0
     if gender != "A" and getattr(args, "aligned_masks", False):
         frozen = int(np.sum(bins_per_chr[:22]))
+    if rd is not None:
+        return _build_sub_reference_sharded(args, gender, total_mask, bins_per_chr, dc, sel, frozen, rd)
     n_parts = len(contexts)
     if dc is not None:
         p = prep.prepare_dev(dc, sel, gender, total_mask, bins_per_chr, frozen=frozen,
@@ -123,6 +176,32 @@ def build_sub_reference(args, samples, gender, total_mask, bins_per_chr, context
     return out
 
 
+def _newref_rank(rank, world, args, port, rnd_state):
+    """One process per GPU of `newref --gpus N`: torch.distributed over RCCL ("nccl"; WCX_DIST_BACKEND=gloo
+    with WCX_DIST_SHARE_DEVICE=1 lets the tests run several ranks on one device)."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib, dist as wd
+    backend_name = os.environ.get("WCX_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    dev_index = rank % n_dev if os.environ.get("WCX_DIST_SHARE_DEVICE") else rank
+    torch.cuda.set_device(dev_index)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if backend_name == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group(backend_name, rank=rank, world_size=world)
+    random.setstate(rnd_state)          # every rank draws the parent's sequence (the null samples)
+    logging.basicConfig(format="[%(levelname)s - %(asctime)s]: %(message)s", datefmt="%Y-%m-%d %H:%M:%S",
+                        level=getattr(logging, str(args.loglevel).upper(), None) if rank == 0 else logging.ERROR)
+    try:
+        ctx = _lib.Context(dev_index, torch.cuda.current_stream().cuda_stream)
+        _newref_body(args, [ctx], (rank, world, wd.GpuBackend(ctx)))
+    finally:
+        dist.destroy_process_group()
+
+
 def tool_newref(args):
     logging.info("Creating new reference")
     if args.yfrac is not None and (args.yfrac < 0 or args.yfrac > 1):
@@ -130,7 +209,23 @@ def tool_newref(args):
         sys.exit()
     from . import _lib
     n_gpus = max(1, int(getattr(args, "gpus", 1) or 1))
+    if n_gpus > 1 and not os.environ.get("WCX_NEWREF_ONE_PROCESS"):
+        # one process per GPU; the row shards of the corrected matrix meet in ONE all-gather per pass
+        import socket
+        import torch.multiprocessing as mp
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        mp.spawn(_newref_rank, args=(n_gpus, args, port, random.getstate()), nprocs=n_gpus, join=True)
+        return
     contexts = [_lib.default_context(d) for d in range(n_gpus)]
+    _newref_body(args, contexts, None)
+
+
+def _newref_body(args, contexts, rd):
+    """tool_newref (main.py:43-138).  rd = None: one process (all devices of `contexts`); rd = (rank,
+    world, backend): this process is one rank of a multi-process build."""
+    rank, world = (rd[0], rd[1]) if rd else (0, 1)
 
     samples = []
     logging.info("Importing data ...")
@@ -144,7 +239,14 @@ def tool_newref(args):
             logging.info("Binsize: {}".format(binsize))
             samples.append(sample)
     samples = np.array(samples)
-    genders, trained_cutoff = train_gender_model(args, samples)
+    if world > 1:
+        # the gender model fits a Gaussian mixture from a random start: rank 0 decides for everybody
+        import torch.distributed as dist
+        box = [train_gender_model(args, samples) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        genders, trained_cutoff = box[0]
+    else:
+        genders, trained_cutoff = train_gender_model(args, samples)
 
     if genders.count("F") < 5 and args.nipt:
         logging.warning("A NIPT reference should have at least 5 female feti samples. "
@@ -162,6 +264,9 @@ def tool_newref(args):
         dc = prep.DeviceCounts(contexts[0], samples)
     except (TypeError, ValueError, RuntimeError) as e:      # non-integer counts, a count beyond int32,
         logging.info("Host-side masks / normalisation: {}".format(e))   # no room in HBM: the host path works
+    if rd is not None and dc is None:
+        logging.critical("newref --gpus N needs the device-resident counts (integer counts that fit the device)")
+        sys.exit(1)
     sel_of = {"A": np.arange(len(genders)), "F": np.flatnonzero(g == "F"), "M": np.flatnonzero(g == "M")}
     get_mask = (lambda k: dc.get_mask(sel_of[k])) if dc is not None else \
         (lambda k: prep.get_mask(samples[sel_of[k]]))
@@ -175,7 +280,7 @@ def tool_newref(args):
     try:
         if len(genders) > 9:
             logging.info("Starting autosomal reference creation ...")
-            sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts, dc, sel_of["A"])
+            sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts, dc, sel_of["A"], rd)
             final_ref.update({k: v for k, v in sub.items() if k != "gender"})
         else:
             logging.critical("Provide at least 10 samples to enable the generation of a reference.")
@@ -183,7 +288,7 @@ def tool_newref(args):
         if genders.count("F") > 4:
             logging.info("Starting female gonosomal reference creation ...")
             sub = build_sub_reference(args, samples[g == "F"], "F", total_mask, bins_per_chr, contexts, dc,
-                                      sel_of["F"])
+                                      sel_of["F"], rd)
             final_ref["has_female"] = True
             final_ref.update({k + ".F": v for k, v in sub.items() if k != "gender"})
         else:
@@ -192,7 +297,7 @@ def tool_newref(args):
             if genders.count("M") > 4:
                 logging.info("Starting male gonosomal reference creation ...")
                 sub = build_sub_reference(args, samples[g == "M"], "M", total_mask, bins_per_chr, contexts, dc,
-                                          sel_of["M"])
+                                          sel_of["M"], rd)
                 final_ref["has_male"] = True
                 final_ref.update({k + ".M": v for k, v in sub.items() if k != "gender"})
             else:
@@ -204,6 +309,8 @@ def tool_newref(args):
             dc.close()
             contexts[0].lib.wcx_pca_end(contexts[0].h)
             contexts[0].release_buffers()
+    if rank != 0:
+        return                      # rank 0 holds the gathered tables and writes the file
     final_ref["is_nipt"] = args.nipt
     final_ref["trained_cutoff"] = trained_cutoff
     n_aut = int(np.sum(final_ref["bins_per_chr"]))
