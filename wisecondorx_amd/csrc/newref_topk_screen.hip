@@ -904,7 +904,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     a.F = Fs; a.Ft = F; a.info = info; a.glob = glob; a.perm = perm2; a.rowpos = rowpos; a.gmask = gmask;
     a.blocks = d_blocks; a.sl = sl; a.cnt = cnt_out; a.flags = flags; a.g_state = g_state;
     a.stats = ctx->d_stats; a.row_begin = 0; a.n_rows_all = n_rows;
-    a.k = k; a.dbg = ctx->debug_flags & ~3; a.n_seg = 1; a.n_blocks = (int)blocks.size();
+    a.k = k; a.dbg = (ctx->debug_flags & ~3) | env_int("WCX_PRE_DBG", 0); a.n_seg = 1; a.n_blocks = (int)blocks.size();
     int trig_a = 4 * cut_r + 64;
     if (trig_a > LIM) trig_a = LIM;
     const int64_t g_end = P_s / GRr;
