@@ -270,7 +270,7 @@ class Workload:
                 # ratios of this rank's target rows, then every rank gets the whole tables
                 idx_l, dist_l, nr_l, _ = wd.newref_sharded(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
                                                            self.backend, self.rank, self.world, out=P["bufs"])
-                if self.args.debug_flags & 27:           # (ablations leave garbage neighbour tables)
+                if self.args.debug_flags & 59:           # (ablations leave garbage neighbour tables)
                     ctx.timer_tag("")
                     ctx.sync()
                     if record:

@@ -152,14 +152,6 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
     scnt += total;
     return o;
   };
-  auto put = [&](int off, uint4 rec, int total) {
-    if (total > STG) {
-      if ((unsigned int)direct_base + (unsigned int)off < A.pool_cap) A.pool[(unsigned int)direct_base + (unsigned int)off] = rec;
-    } else {
-      stg[off] = rec;
-    }
-  };
-
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto fetch = [&](int g, int slot) {
     const half8 *src = A.F + (int64_t)g * TILE_H8;
@@ -320,18 +312,46 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
       // One scalar-skipped, fully unrolled pass over the 16 outputs (static register indices; a
       // per-lane walk of the hits through LDS was measured slower: its dependent LDS reads are
       // exposed, 2 000 SIMD cycles per event at K = 512).
+      // records of this event go to the staging area (LDS) or, for an event bigger than it, straight
+      // to the pool: two separate loops, so that every store has ONE address space
+      const bool direct = rtotal > STG;
+      uint4 *rec_dst = direct ? A.pool + (unsigned int)direct_base : nullptr;
+      const unsigned int rec_room = direct ? (A.pool_cap > (unsigned int)direct_base ? A.pool_cap - (unsigned int)direct_base : 0u) : 0u;
       if (anym) {
+        if (excl) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (anym & (0x8000u >> r)) {
-            asm volatile("" ::: "memory");                 // (keeps the two tests separate)
-            if (pm & (0x8000u >> r)) {
-              const unsigned int cp = cposb + (unsigned int)(8 * (r >> 2) + (r & 3));
-              if (excl) {
-                if (ofs < CAP2) mine[ofs] = make_uint2(__float_as_uint(-2.f * acc[s][r]), cp);
+          for (int r = 0; r < 16; ++r) {
+            if (anym & (0x8000u >> r)) {
+              asm volatile("" ::: "memory");               // (keeps the two tests separate)
+              if (pm & (0x8000u >> r)) {
+                if (ofs < CAP2)
+                  mine[ofs] = make_uint2(__float_as_uint(-2.f * acc[s][r]),
+                                         cposb + (unsigned int)(8 * (r >> 2) + (r & 3)));
                 ++ofs;
-              } else {
-                put(coff, make_uint4((unsigned int)rowj, cp, __float_as_uint(-2.f * acc[s][r]), 0u), rtotal);
+              }
+            }
+          }
+        } else if (!direct) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (anym & (0x8000u >> r)) {
+              asm volatile("" ::: "memory");
+              if (pm & (0x8000u >> r)) {
+                stg[coff] = make_uint4((unsigned int)rowj, cposb + (unsigned int)(8 * (r >> 2) + (r & 3)),
+                                       __float_as_uint(-2.f * acc[s][r]), 0u);
+                ++coff;
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (anym & (0x8000u >> r)) {
+              asm volatile("" ::: "memory");
+              if (pm & (0x8000u >> r)) {
+                if ((unsigned int)coff < rec_room)
+                  rec_dst[coff] = make_uint4((unsigned int)rowj, cposb + (unsigned int)(8 * (r >> 2) + (r & 3)),
+                                             __float_as_uint(-2.f * acc[s][r]), 0u);
                 ++coff;
               }
             }
@@ -339,14 +359,29 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
         }
       }
       if (rany) {
+        if (!direct) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (rany & (0x8000u >> r)) {
-            asm volatile("" ::: "memory");
-            if (rm & (0x8000u >> r)) {
-              const unsigned int rowi = ti[32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
-              put(roff, make_uint4(rowi, posj, __float_as_uint(-2.f * acc[s][r]), 0u), rtotal);
-              ++roff;
+          for (int r = 0; r < 16; ++r) {
+            if (rany & (0x8000u >> r)) {
+              asm volatile("" ::: "memory");
+              if (rm & (0x8000u >> r)) {
+                stg[roff] = make_uint4(ti[32 + 8 * (r >> 2) + 4 * hf + (r & 3)], posj,
+                                       __float_as_uint(-2.f * acc[s][r]), 0u);
+                ++roff;
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (rany & (0x8000u >> r)) {
+              asm volatile("" ::: "memory");
+              if (rm & (0x8000u >> r)) {
+                if ((unsigned int)roff < rec_room)
+                  rec_dst[roff] = make_uint4(ti[32 + 8 * (r >> 2) + 4 * hf + (r & 3)], posj,
+                                             __float_as_uint(-2.f * acc[s][r]), 0u);
+                ++roff;
+              }
             }
           }
         }
