@@ -1143,10 +1143,11 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     const int cut_r1 = sample_rank(1);     // (the symmetric sweep has no candidate segments)
     // WCX_SCREEN_SYM: 0 = never, 1 = where it pays (default), 2 = whenever possible (tests).  Small K
     // is bound by the appends, not by the matrix pipe, and the symmetric sweep's hit path is the dearer
-    // one (15 kb x 100 samples, K = 112: 19.2 ms against 11.5 ms; x 500 samples, K = 512: 25.2 against 31.5)
+    // one (15 kb, symmetric against one-directional: K = 112: 13.9 / 11.3 ms; K = 192: 17.3 / 15.6; K = 256: 17.4 /
+    // 20.0; K = 512: 23.4 / 31.5)
     const int sym_mode = env_int("WCX_SCREEN_SYM", 1);
     if (cut_r1 && row_begin == 0 && n_rows == B && covered == B && cfg.tt == 1 && cfg.wpb == 4 &&
-        cfg.ring >= 2 && (sym_mode == 2 || (sym_mode == 1 && NK >= 20)))
+        cfg.ring >= 2 && (sym_mode == 2 || (sym_mode == 1 && NK >= 16)))
       return screen_sym_path(ctx, dXs, B, S, chr_cum, n_chr, blocks, cfg, SF, cut_r1, slots, k, d_out_idx,
                              d_out_dist);
   }
