@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NT) void k_merge_segments(
     row_budget(info[rowpos[row_begin + r]], e_max, N_max, gamma, na, E, Q);
     min_threshold(g_state[i0], (c0 >> 30) & 1, g_state[i1], (c1 >> 30) & 1, Gm, em);
     int n_new, e_new;
-    const float Gn = compact_loaded(raw, n0 + n1, sl + i0 * CAP, k, na, E, Q, Gm, em, 2, is_root != 0,
+    const float Gn = compact_loaded<CAP / 64>(raw, n0 + n1, sl + i0 * CAP, k, na, E, Q, Gm, em, 2, is_root != 0,
                                     &flags[i0], n_new, e_new);
     if (lane == 0) { cnt[i0] = n_new | (e_new << 30); g_state[i0] = Gn; }
   }

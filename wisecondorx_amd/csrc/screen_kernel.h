@@ -64,10 +64,11 @@ constexpr int CNT_MASK = 0x3fffffff;   // shortlist count; bit 30 of the stored 
 // All CAP slots of a shortlist exist in memory: load unconditionally (16 independent loads in
 // flight; a load under `if (e < n)` made the compiler wait for each one in turn -- 16 serial
 // round trips to HBM, ~40k cycles per cut) and mask afterwards.
-__device__ __forceinline__ void load_shortlist(const uint2 *__restrict__ sl_row, uint2 (&raw)[CAP / 64]) {
+template <int NSL>
+__device__ __forceinline__ void load_shortlist(const uint2 *__restrict__ sl_row, uint2 (&raw)[NSL]) {
   const int lane = wcx::lane_id();
 #pragma unroll
-  for (int q = 0; q < CAP / 64; ++q) raw[q] = sl_row[q * 64 + lane];
+  for (int q = 0; q < NSL; ++q) raw[q] = sl_row[q * 64 + lane];
 }
 
 // Wave-level cut of one target's shortlist (entries = float bits of t, sweep position).
@@ -83,15 +84,16 @@ __device__ __forceinline__ void load_shortlist(const uint2 *__restrict__ sl_row,
 //   mode 2  final cut, exact k-th key.
 // fail_if_est: the last cut of a row -- an estimate that is still unproven hands the row to the
 // exact kernel.  Returns the new G; n_out / est_out.
-__device__ __forceinline__ float compact_loaded(const uint2 (&raw)[CAP / 64], int n,
+template <int NSL>
+__device__ __forceinline__ float compact_loaded(const uint2 (&raw)[NSL], int n,
                                                 uint2 *__restrict__ sl_row, int kk, float na, float E,
                                                 float Q, float G_old, int est_old, int mode,
                                                 bool fail_if_est, unsigned int *overflow_flag,
                                                 int &n_out, int &est_out) {
   const int lane = wcx::lane_id();
-  unsigned int key[CAP / 64], idx[CAP / 64];
+  unsigned int key[NSL], idx[NSL];
 #pragma unroll
-  for (int q = 0; q < CAP / 64; ++q) {
+  for (int q = 0; q < NSL; ++q) {
     const bool in = q * 64 + lane < n;
     key[q] = in ? f32_key(__uint_as_float(raw[q].x)) : 0xffffffffu;
     idx[q] = in ? raw[q].y : 0u;
@@ -105,7 +107,7 @@ __device__ __forceinline__ float compact_loaded(const uint2 (&raw)[CAP / 64], in
     const unsigned int kref = (unsigned int)__builtin_amdgcn_readfirstlane((int)key[0]);
     unsigned int x = 0;
 #pragma unroll
-    for (int q = 0; q < CAP / 64; ++q) x |= (q * 64 + lane < n) ? (key[q] ^ kref) : 0u;
+    for (int q = 0; q < NSL; ++q) x |= (q * 64 + lane < n) ? (key[q] ^ kref) : 0u;
     x = wcx::wave_or_u32(x);
     const int hb = 31 - __builtin_clz(x | 1u);              // highest differing bit (0 if none)
     unsigned int prefix = kref & ~((2u << hb) - 1u);
@@ -114,7 +116,7 @@ __device__ __forceinline__ float compact_loaded(const uint2 (&raw)[CAP / 64], in
       const unsigned int trial = prefix | (1u << bit);
       int c = 0;
 #pragma unroll
-      for (int q = 0; q < CAP / 64; ++q) c += __popcll(__ballot(key[q] < trial));
+      for (int q = 0; q < NSL; ++q) c += __popcll(__ballot(key[q] < trial));
       if (c < kk) prefix = trial;
     }
     if (!exact && hb >= 12) prefix |= 0xfffu;
@@ -135,7 +137,7 @@ __device__ __forceinline__ float compact_loaded(const uint2 (&raw)[CAP / 64], in
   const unsigned int gkey = f32_key(G);
   int base = 0;
 #pragma unroll
-  for (int q = 0; q < CAP / 64; ++q) {
+  for (int q = 0; q < NSL; ++q) {
     const bool keep = (q * 64 + lane < n) && (key[q] <= gkey);
     const unsigned long long m = __ballot(keep);
     const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
@@ -170,7 +172,7 @@ __device__ __forceinline__ void encode_threshold(float G, _Float16 &w1, _Float16
 // shortlists at w_srow + bit); in a burst the next target's shortlist is loaded while the current
 // one is selected and written back.  tpos / G / cntr / est are the tile's per-lane state (lanes l
 // and l + 32 hold target l), th_last the last k-step of its B operand (augmented columns).
-template <int NK, bool LOOKAHEAD>
+template <int NK, bool LOOKAHEAD, int NSL>
 __device__ __forceinline__ void cut_targets(const ScreenArgs &A, unsigned int need, int mode,
                                             int64_t w_srow, float e_max, float N_max, float gamma,
                                             int tpos, float &G, float &Gp, int &cntr, int &est,
@@ -183,12 +185,12 @@ __device__ __forceinline__ void cut_targets(const ScreenArgs &A, unsigned int ne
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   int c = __ffs((int)need) - 1;
   need &= need - 1;
-  uint2 raw[CAP / 64];
+  uint2 raw[NSL];
   load_shortlist(A.sl + (w_srow + c) * (int64_t)CAP, raw);
   for (;;) {
     const int cn = need ? __ffs((int)need) - 1 : -1;
     need &= need - 1;
-    uint2 rawn[LOOKAHEAD ? CAP / 64 : 1];
+    uint2 rawn[LOOKAHEAD ? NSL : 1];
     if constexpr (LOOKAHEAD) {
       if (cn >= 0) load_shortlist(A.sl + (w_srow + cn) * (int64_t)CAP, rawn);
     }
@@ -208,7 +210,7 @@ __device__ __forceinline__ void cut_targets(const ScreenArgs &A, unsigned int ne
     c = cn;
     if constexpr (LOOKAHEAD) {
 #pragma unroll
-      for (int q = 0; q < CAP / 64; ++q) raw[q] = rawn[q];
+      for (int q = 0; q < NSL; ++q) raw[q] = rawn[q];
     } else {                       // no registers to spare for the look-ahead
       load_shortlist(A.sl + (w_srow + c) * (int64_t)CAP, raw);
     }
@@ -318,6 +320,8 @@ __global__ __launch_bounds__(64 * WPB, LBW) void k_screen(
     if (hf) { th[tt][NK - 1][4] = (_Float16)AUG; th[tt][NK - 1][5] = (_Float16)AUG;
               th[tt][NK - 1][6] = w1; th[tt][NK - 1][7] = w2; }
   }
+  constexpr int SMALL_NSL = 5;
+  const bool small_cut = A.trig + 64 <= SMALL_NSL * 64;     // wave-uniform (a kernel argument)
   int n_compact = 0, n_app = 0;
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0;
   auto stamp = [&](int ph) {
@@ -575,10 +579,18 @@ __global__ __launch_bounds__(64 * WPB, LBW) void k_screen(
       for (int tt = 0; tt < TT; ++tt) {
         if (anym[tt]) {
           const unsigned int need = (unsigned int)__ballot(tvalid[tt] && cntr[tt] > A.trig);  // low half
-          if (need)
-            cut_targets<NK, LOOKAHEAD>(A, need, A.cut_mode, wg_srow + wave * WT + tt * 32, e_max, N_max,
-                                       gamma, tpos[tt], G[tt], Gp[tt], cntr[tt], est[tt],
-                                       th[tt][NK - 1], n_compact);
+          if (need) {
+            // (the sampled pre-pass cuts at r << k: its lists never exceed trig + 64 entries -- five
+            //  64-entry slices instead of sixteen to load, select and write back)
+            if (small_cut)
+              cut_targets<NK, LOOKAHEAD, SMALL_NSL>(A, need, A.cut_mode, wg_srow + wave * WT + tt * 32, e_max,
+                                                    N_max, gamma, tpos[tt], G[tt], Gp[tt], cntr[tt], est[tt],
+                                                    th[tt][NK - 1], n_compact);
+            else
+              cut_targets<NK, LOOKAHEAD, CAP / 64>(A, need, A.cut_mode, wg_srow + wave * WT + tt * 32, e_max,
+                                                   N_max, gamma, tpos[tt], G[tt], Gp[tt], cntr[tt], est[tt],
+                                                   th[tt][NK - 1], n_compact);
+          }
         }
       }
     }
@@ -590,10 +602,17 @@ __global__ __launch_bounds__(64 * WPB, LBW) void k_screen(
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       const int nv = blk.nrows - (wave * WT + tt * 32);
-      if (nv > 0)
-        cut_targets<NK, LOOKAHEAD>(A, nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u), A.end_cut,
-                                   wg_srow + wave * WT + tt * 32, e_max, N_max, gamma, tpos[tt], G[tt],
-                                   Gp[tt], cntr[tt], est[tt], th[tt][NK - 1], n_compact);
+      if (nv > 0) {
+        const unsigned int all = nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u);
+        if (small_cut)
+          cut_targets<NK, LOOKAHEAD, SMALL_NSL>(A, all, A.end_cut, wg_srow + wave * WT + tt * 32, e_max, N_max,
+                                                gamma, tpos[tt], G[tt], Gp[tt], cntr[tt], est[tt],
+                                                th[tt][NK - 1], n_compact);
+        else
+          cut_targets<NK, LOOKAHEAD, CAP / 64>(A, all, A.end_cut, wg_srow + wave * WT + tt * 32, e_max, N_max,
+                                               gamma, tpos[tt], G[tt], Gp[tt], cntr[tt], est[tt],
+                                               th[tt][NK - 1], n_compact);
+      }
     }
   }
 #pragma unroll
