@@ -23,8 +23,9 @@ def _oracle(X, cum, k):
 
 
 @pytest.fixture(autouse=True)
-def _force_sym(monkeypatch):
-    monkeypatch.setenv("WCX_SCREEN_SYM", "2")      # also where the default policy prefers the other sweep
+def _force_sym(monkeypatch, request):
+    if "bench_cohort" not in request.node.name:    # (that one runs the DEFAULT policy)
+        monkeypatch.setenv("WCX_SCREEN_SYM", "2")  # also where the default policy prefers the other sweep
 
 
 def _run(nt, X, cum, k):
@@ -136,3 +137,23 @@ def test_symmetric_sweep_wide_norm_spread(nt, monkeypatch):
     idx, dist, st = _run(nt, X, cum, k)
     assert st["sym_gates"] > 0
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def test_symmetric_sweep_all_rows_of_the_bench_cohort(nt):
+    """The autosomal pass of bench.py's default workload -- the PCA-CORRECTED matrix of the 500-sample
+    synthetic cohort at 15 kb, not a synthetic corrected matrix -- through the default path (symmetric
+    sweep): EVERY one of the 182 k rows, indices and distances, bit for bit against the tiled C oracle;
+    no row may need the exact kernel."""
+    import bench
+    from wisecondorx_amd import _lib
+    co, passes, _ = bench.make_full_workload(15000, 500)
+    p = passes["A"]
+    X = p["X"]
+    cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
+    B, k = cum[-1], 300
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, B, mode=0)
+    st = _lib.default_context().topk_stats()
+    assert st["sym_gates"] > 0 and st["fallback_rows"] == 0 and st["rows"] == B
+    oi, od = _oracle(X, cum, k)
+    bad = np.flatnonzero((idx != oi).any(axis=1) | (dist != od).any(axis=1))
+    assert bad.size == 0, "{} of {} rows differ (first {})".format(bad.size, B, bad[:5])
