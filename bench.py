@@ -460,16 +460,16 @@ def config5_block(w, batch=96, runs=3):
                                             "per batch + 32 B per (sample, bin, pass)"}}
 
 
-def e2e_cli_block(w, workdir="/tmp/wcx_bench_e2e"):
+def e2e_cli_block(w, workdir=None):
     """BASELINE.json's literal metric: wall-clock of the CLI -- `newref` on the cohort's sample files
     (load, gender model, masks, PCA, A / F / M searches + null ratios, reference .npz written, QC) and
     `predict --bed` of one sample.  Sample files are written before the clock starts."""
     import random
     import shutil
     from concurrent.futures import ThreadPoolExecutor
+    import tempfile
     from wisecondorx_amd import main as cli, npz_io
-    shutil.rmtree(workdir, ignore_errors=True)
-    os.makedirs(workdir)
+    workdir = workdir or tempfile.mkdtemp(prefix="wcx_bench_e2e_")
     samples, genders = w.co.cohort_corrected
     def raw(s_, g_):                     # undo gender_correct (males' gonosomal counts were doubled)
         return s_ if g_ != "M" else dict(s_, **{"23": s_["23"] // 2, "24": s_["24"] // 2})

@@ -284,3 +284,24 @@ def test_device_reproduces_the_references_shipped_dnacopy_segments(bdry):
     assert [tuple(s[:3]) for s in got] == [tuple(int(v) for v in s[:3]) for s in want]
     ora = O.cbs_r_wrapper(results_r, results_w, "F", 1e-4, binsize, 1, CO.cbs_segment)
     np.testing.assert_allclose([s[3] for s in got], [s[3] for s in ora], rtol=0, atol=1e-12)
+
+
+def test_shipped_dnacopy_segments_do_not_depend_on_the_seed_or_alpha(bdry):
+    """The permutation stream is the one deliberate difference from DNAcopy: on the one
+    real DNAcopy run the reference ships (docs/include/example.bed) the 50 segments must not move for
+    any seed 0 ... 31, nor for alpha 1e-3 (one decade looser than CBS.R's 1e-4 default) -- i.e. none of
+    that run's decisions hangs on a borderline permutation count."""
+    from test_oracle_cbs import example_case
+    from wisecondorx_amd import _lib, predict_tools
+    results_r, results_w, binsize, want = example_case()
+    res = {"results_r": [v.tolist() for v in results_r], "results_w": [v.tolist() for v in results_w]}
+    want3 = [tuple(int(v) for v in s[:3]) for s in want]
+    ctx = _lib.default_context(0)
+    moved = []
+    for seed in range(32):
+        got = predict_tools.run_cbs(res, "F", 1e-4, binsize, seed, ctx)
+        if [tuple(s[:3]) for s in got] != want3:
+            moved.append(seed)
+    assert not moved, "segments differ from DNAcopy's for seeds {}".format(moved)
+    got = predict_tools.run_cbs(res, "F", 1e-3, binsize, 1, ctx)
+    assert [tuple(s[:3]) for s in got] == want3
