@@ -41,6 +41,7 @@ SHAPES = [
     ([1500, 1400, 1300, 1000, 800, 400], 30, 128, 8),             # K = 48
     ([1600, 1500, 1400, 1200, 1100, 900, 500], 260, 150, 8),      # K = 320 (NK 20)
     ([1700, 1500, 1300, 1200, 1000, 0, 700, 650], 150, 100, 8),   # K = 160 (NK 10), an empty chromosome
+    ([2100, 1900, 1600, 1400, 1300, 1100], 250, 200, 8),           # K = 256 (NK 16): where the default policy starts
 ]
 
 
