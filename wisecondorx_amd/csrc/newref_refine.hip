@@ -58,70 +58,84 @@ __device__ __forceinline__ void wave_sort_pairs(double (&d)[IPL], int (&ix)[IPL]
 constexpr int RCH = 16;                 // doubles per chunk
 constexpr int RPITCH = RCH + 2;         // LDS row pitch in doubles (144 B)
 
-template <int IPL>
-__device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S, int Sp,
-                                           int64_t row, int64_t cs, int64_t own,
-                                           const uint2 *__restrict__ sl_row,
-                                           const int *__restrict__ perm, int n, int k,
-                                           int32_t *__restrict__ oi, double *__restrict__ od,
-                                           double *__restrict__ tile, double *__restrict__ xt_s,
-                                           int *__restrict__ g_s) {
+// Exact distances of 64 candidate rows (row ids in g_s, one per lane) to the target row held in
+// xt_s, each summed strictly left to right; returns the lane's candidate's distance.
+__device__ __forceinline__ double pass_distances(const double *__restrict__ Xr, int S, int Sp,
+                                                 double *__restrict__ tile,
+                                                 const double *__restrict__ xt_s,
+                                                 const int *__restrict__ g_s) {
   const int lane = wcx::lane_id();
-  double d[IPL];
-  int ix[IPL];
-  const double *xt = Xr + row * (int64_t)Sp;
-  for (int j = lane; j < Sp; j += 64) xt_s[j] = xt[j];     // target row -> LDS (broadcast reads)
   const int sub = lane >> 3, part = lane & 7;               // load role: candidate sub, 16-B piece
+  int64_t base[8];
 #pragma unroll
-  for (int q = 0; q < IPL; ++q) {
-    d[q] = 0.0;
-    ix[q] = 0x7fffffff;
-    if (q * 64 >= n) continue;                               // wave-uniform
-    const int e = q * 64 + lane;
-    int g = (int)row;                                        // padding lanes read the target row
-    if (e < n) {
-      g = perm[sl_row[e].y];                                // shortlists hold sweep positions
-      ix[q] = g < cs ? g : g - (int)own;                     // own-chromosome-excluded index
-    }
-    g_s[lane] = g;
+  for (int i = 0; i < 8; ++i) base[i] = (int64_t)g_s[i * 8 + sub] * Sp + part * 2;
+  double acc = 0.0;
+  // the chunk loop is a chain of L2 round trips: the next chunk's loads are issued before the
+  // current one is consumed (three chunks = 24 KB per wave in flight)
+  // (eight named registers per buffer: arrays carried around the loop end up in scratch)
+  double2 va0, va1, va2, va3, va4, va5, va6, va7, vb0, vb1, vb2, vb3, vb4, vb5, vb6, vb7,
+      vc0, vc1, vc2, vc3, vc4, vc5, vc6, vc7;
+#define WCX_LD(i, C0) (*reinterpret_cast<const double2 *>(Xr + base[i] + (C0)))
+#define WCX_FETCH(P, C0)                                                                         \
+  P##0 = WCX_LD(0, C0); P##1 = WCX_LD(1, C0); P##2 = WCX_LD(2, C0); P##3 = WCX_LD(3, C0);        \
+  P##4 = WCX_LD(4, C0); P##5 = WCX_LD(5, C0); P##6 = WCX_LD(6, C0); P##7 = WCX_LD(7, C0);
+#define WCX_ST(i, V) *reinterpret_cast<double2 *>(&tile[((i) * 8 + sub) * RPITCH + part * 2]) = V
+#define WCX_PUT(P)                                                                               \
+  WCX_ST(0, P##0); WCX_ST(1, P##1); WCX_ST(2, P##2); WCX_ST(3, P##3);                            \
+  WCX_ST(4, P##4); WCX_ST(5, P##5); WCX_ST(6, P##6); WCX_ST(7, P##7);
+  auto dot = [&](int c0) __attribute__((always_inline)) {
     __builtin_amdgcn_wave_barrier();
-    int64_t base[8];
+    const int jn = (S - c0) < RCH ? (S - c0) : RCH;
+    const double *mine = &tile[lane * RPITCH];
+    if (jn == RCH) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) base[i] = (int64_t)g_s[i * 8 + sub] * Sp + part * 2;
-    double acc = 0.0;
-    for (int c0 = 0; c0 < S; c0 += RCH) {
-      // coalesced load of chunk [c0, c0+16) of 64 candidate rows: 8 instructions x 8 rows x 128 B
-      double2 v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(Xr + base[i] + c0);
-      __builtin_amdgcn_wave_barrier();                       // previous chunk fully consumed
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<double2 *>(&tile[(i * 8 + sub) * RPITCH + part * 2]) = v[i];
-      __builtin_amdgcn_wave_barrier();
-      const int jn = (S - c0) < RCH ? (S - c0) : RCH;
-      const double *mine = &tile[lane * RPITCH];
-      if (jn == RCH) {
-#pragma unroll
-        for (int jj = 0; jj < RCH; jj += 2) {
-          const double2 cv = *reinterpret_cast<const double2 *>(mine + jj);
-          const double2 tv = *reinterpret_cast<const double2 *>(xt_s + c0 + jj);
-          double diff = cv.x - tv.x;
-          double sq = diff * diff;
-          acc = acc + sq;
-          diff = cv.y - tv.y; sq = diff * diff; acc = acc + sq;
-        }
-      } else {
-        for (int jj = 0; jj < jn; ++jj) {
-          const double diff = mine[jj] - xt_s[c0 + jj];
-          const double sq = diff * diff;
-          acc = acc + sq;
-        }
+      for (int jj = 0; jj < RCH; jj += 2) {
+        const double2 cv = *reinterpret_cast<const double2 *>(mine + jj);
+        const double2 tv = *reinterpret_cast<const double2 *>(xt_s + c0 + jj);
+        double diff = cv.x - tv.x;
+        double sq = diff * diff;
+        acc = acc + sq;
+        diff = cv.y - tv.y; sq = diff * diff; acc = acc + sq;
+      }
+    } else {
+      for (int jj = 0; jj < jn; ++jj) {
+        const double diff = mine[jj] - xt_s[c0 + jj];
+        const double sq = diff * diff;
+        acc = acc + sq;
       }
     }
-    d[q] = acc;
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();                       // chunk fully consumed
+  };
+  // coalesced loads of chunk [c0, c0+16) of 64 candidate rows: 8 instructions x 8 rows x 128 B
+  WCX_FETCH(va, 0)
+  if (RCH < S) { WCX_FETCH(vb, RCH) }
+  for (int c0 = 0; c0 < S; c0 += 3 * RCH) {
+    if (c0 + 2 * RCH < S) { WCX_FETCH(vc, c0 + 2 * RCH) }
+    WCX_PUT(va)
+    dot(c0);
+    if (c0 + RCH < S) {
+      if (c0 + 3 * RCH < S) { WCX_FETCH(va, c0 + 3 * RCH) }
+      WCX_PUT(vb)
+      dot(c0 + RCH);
+      if (c0 + 2 * RCH < S) {
+        if (c0 + 4 * RCH < S) { WCX_FETCH(vb, c0 + 4 * RCH) }
+        WCX_PUT(vc)
+        dot(c0 + 2 * RCH);
+      }
+    }
   }
+#undef WCX_LD
+#undef WCX_FETCH
+#undef WCX_ST
+#undef WCX_PUT
+  return acc;
+}
+
+// Sort the wave's (distance, index) pairs and emit the k best (NaN / >= 1e10 never admitted).
+template <int IPL>
+__device__ __forceinline__ void sort_emit(double (&d)[IPL], int (&ix)[IPL], int k,
+                                          int32_t *__restrict__ oi, double *__restrict__ od) {
+  const int lane = wcx::lane_id();
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
     const bool ok = (ix[q] != 0x7fffffff) && (d[q] < 1e10);   // NaN / >= 1e10 never admitted
@@ -137,6 +151,40 @@ __device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S,
       od[e] = ok ? d[q] : 1e10;
     }
   }
+}
+
+
+template <int IPL>
+__device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S, int Sp,
+                                           int64_t row, int64_t cs, int64_t own,
+                                           const uint2 *__restrict__ sl_row,
+                                           const int *__restrict__ perm, int n, int k,
+                                           int32_t *__restrict__ oi, double *__restrict__ od,
+                                           double *__restrict__ tile, double *__restrict__ xt_s,
+                                           int *__restrict__ g_s) {
+  const int lane = wcx::lane_id();
+  double d[IPL];
+  int ix[IPL];
+  const double *xt = Xr + row * (int64_t)Sp;
+  for (int j = lane; j < Sp; j += 64) xt_s[j] = xt[j];     // target row -> LDS (broadcast reads)
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    d[q] = 0.0;
+    ix[q] = 0x7fffffff;
+    if (q * 64 >= n) continue;                               // wave-uniform
+    const int e = q * 64 + lane;
+    int g = (int)row;                                        // padding lanes read the target row
+    if (e < n) {
+      g = perm[sl_row[e].y];                                // shortlists hold sweep positions
+      ix[q] = g < cs ? g : g - (int)own;                     // own-chromosome-excluded index
+    }
+    g_s[lane] = g;
+    __builtin_amdgcn_wave_barrier();
+    const double acc = pass_distances(Xr, S, Sp, tile, xt_s, g_s);
+    d[q] = acc;
+    __builtin_amdgcn_wave_barrier();
+  }
+  sort_emit<IPL>(d, ix, k, oi, od);
 }
 
 // Rows whose shortlist fits 512 entries (8 per lane): the common case.
