@@ -84,14 +84,14 @@ def main():
     random.seed(1)
     newref_argv = ["--loglevel", "warning", "newref"] + files + [
         ref_file, "--binsize", str(a.binsize), "--refsize", str(a.refsize), "--yfrac", "0.004",
-        "--gpus", str(a.gpus)]
+        "--gpus", str(a.gpus), "--aligned-masks"]   # (the synthetic cohort's F / M filters drop autosomal bins)
     t0 = time.perf_counter()
     if a.profile:
         import cProfile
         import pstats
         pr = cProfile.Profile()
         pr.runcall(cli.main, newref_argv)
-        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats(os.environ.get("WCX_PROF_SORT", "cumulative")).print_stats(45)
     else:
         cli.main(newref_argv)
     t_newref = time.perf_counter() - t0
@@ -109,9 +109,16 @@ def main():
     outid = os.path.join(a.workdir, "out")
     t0 = time.perf_counter()
     predict_error = None
+    predict_argv = ["--loglevel", "warning", "predict", test_file, ref_file, outid, "--bed", "--seed", "1"]
     try:
-        cli.main(["--loglevel", "warning", "predict", test_file, ref_file, outid, "--bed",
-                  "--seed", "1"])
+        if a.profile:
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.runcall(cli.main, predict_argv)
+            pstats.Stats(pr, stream=sys.stderr).sort_stats(os.environ.get("WCX_PROF_SORT", "cumulative")).print_stats(45)
+        else:
+            cli.main(predict_argv)
     except SystemExit as e:     # e.g. a reference whose gonosomal pass dropped autosomal bins
         predict_error = "predict exited ({})".format(e.code)
     t_predict = time.perf_counter() - t0

@@ -503,3 +503,33 @@ def test_newref_mask_skew_default_follows_upstream():
     assert g["mask"][:n_aut].sum() == g["mask_F"][:n_aut].sum() + 1
     assert str(g["predict_results_nr"]) == "IndexError"
     assert g["len_merged"].tolist()[0] == g["len_merged"].tolist()[1] + 1
+
+
+def test_npz_writer_streams_members_and_aborts_cleanly(tmp_path):
+    """NpzWriter (the reference file is written while newref still computes): members added one by
+    one with early write-back in between load back bit for bit; an aborted writer leaves no file."""
+    from wisecondorx_amd import npz_io
+    rng = np.random.default_rng(5)
+    big = rng.standard_normal((3000, 300))
+    idx = np.asfortranarray(rng.integers(0, 1 << 30, (2000, 300)).astype(np.int32))
+    path = str(tmp_path / "ref.npz")
+    w = npz_io.NpzWriter(path)
+    w.add("distances", big)
+    w.flush_async()
+    w.add("indexes", idx)
+    w.add("mask", np.arange(1000) % 3 == 0)
+    w.flush_async()
+    w.add("trained_cutoff", 0.25)
+    w.add("is_nipt", False)
+    assert w.close() == path
+    with np.load(path) as z:
+        assert set(z.files) == {"distances", "indexes", "mask", "trained_cutoff", "is_nipt"}
+        assert np.array_equal(z["distances"], big) and np.array_equal(z["indexes"], idx)
+        assert float(z["trained_cutoff"]) == 0.25 and not bool(z["is_nipt"])
+    import zipfile
+    assert zipfile.ZipFile(path).testzip() is None          # every CRC-32 right
+    w = npz_io.NpzWriter(str(tmp_path / "gone.npz"))
+    w.add("distances", big)
+    w.flush_async()
+    w.abort()
+    assert sorted(os.listdir(tmp_path)) == ["ref.npz"]

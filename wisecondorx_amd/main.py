@@ -35,8 +35,8 @@ def tool_convert(args):
 # --------------------------------------------------------------------------- newref
 def _y_fractions(samples):
     """Share of the reads of each sample that fall on chrY (key "24")."""
-    tot = np.array([float(sum(np.sum(v) for v in s.values())) for s in samples])
-    y = np.array([float(np.sum(s["24"])) for s in samples])
+    tot = np.array([float(sum(v.sum() for v in s.values())) for s in samples])     # (the method: a third of
+    y = np.array([float(s["24"].sum()) for s in samples])                           #  np.sum's call overhead)
     return y / tot
 
 
@@ -218,8 +218,10 @@ def tool_newref(args):
             port = sk.getsockname()[1]
         mp.spawn(_newref_rank, args=(n_gpus, args, port, random.getstate()), nprocs=n_gpus, join=True)
         return
-    contexts = [_lib.default_context(d) for d in range(n_gpus)]
-    _newref_body(args, contexts, None)
+    # (the device contexts come up -- HIP runtime, streams, workspaces: ~80 ms -- beside the sample import)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as ex:
+        _newref_body(args, ex.submit(lambda: [_lib.default_context(d) for d in range(n_gpus)]), None)
 
 
 def _newref_body(args, contexts, rd):
@@ -233,7 +235,7 @@ def _newref_body(args, contexts, rd):
         sample, binsize = npz_io.load_sample(infile)
         return scale_sample(sample, binsize, args.binsize), int(binsize)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=npz_io._THREADS) as ex:
+    with ThreadPoolExecutor(max_workers=npz_io._LOAD_THREADS) as ex:
         for infile, (sample, binsize) in zip(args.infiles, ex.map(load_one, args.infiles)):
             logging.info("Loading: {}".format(infile))
             logging.info("Binsize: {}".format(binsize))
@@ -257,6 +259,8 @@ def _newref_body(args, contexts, rd):
             samples[i] = gender_correct(sample, genders[i])
 
     g = np.array(genders)
+    if hasattr(contexts, "result"):
+        contexts = contexts.result()
     # the (gender-corrected) counts go to the device once; masks, every pass's normalisation and
     # PCA read them there.  Non-integer counts (not something `convert` writes) take the host path.
     dc = None
@@ -277,11 +281,24 @@ def _newref_body(args, contexts, rd):
         total_mask = total_mask & get_mask("M")[0]
 
     final_ref = {"has_female": False, "has_male": False}
+    # the reference file is written WHILE it is built: a pass's tables go to the writer's threads as
+    # soon as they are on the host and land in the file beside the next pass's device work
+    writer = npz_io.NpzWriter(args.outfile) if rank == 0 else None
+    written = set()
+
+    def stream_out():
+        if writer is not None:
+            for k_, v_ in final_ref.items():
+                if k_ not in written and k_ not in ("has_female", "has_male"):
+                    writer.add(k_, v_)
+                    written.add(k_)
+            writer.flush_async()
     try:
         if len(genders) > 9:
             logging.info("Starting autosomal reference creation ...")
             sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts, dc, sel_of["A"], rd)
             final_ref.update({k: v for k, v in sub.items() if k != "gender"})
+            stream_out()
         else:
             logging.critical("Provide at least 10 samples to enable the generation of a reference.")
             sys.exit()
@@ -291,6 +308,7 @@ def _newref_body(args, contexts, rd):
                                       sel_of["F"], rd)
             final_ref["has_female"] = True
             final_ref.update({k + ".F": v for k, v in sub.items() if k != "gender"})
+            stream_out()
         else:
             logging.warning("Provide at least 5 female samples to enable normalization of female gonosomes.")
         if not args.nipt:
@@ -300,8 +318,13 @@ def _newref_body(args, contexts, rd):
                                           sel_of["M"], rd)
                 final_ref["has_male"] = True
                 final_ref.update({k + ".M": v for k, v in sub.items() if k != "gender"})
+                stream_out()
             else:
                 logging.warning("Provide at least 5 male samples to enable normalization of male gonosomes.")
+    except BaseException:
+        if writer is not None:
+            writer.abort()
+        raise
     finally:
         # (also on an error in any pass: the device counts, the PCA stage and the buffers must not
         # outlive the call while the context does)
@@ -324,11 +347,19 @@ def _newref_body(args, contexts, rd):
                             "align the two -- rebuild with --aligned-masks".format(
                                 ap[1:], int(np.sum(final_ref["mask"]) -
                                             np.sum(final_ref["mask" + ap][:n_aut]))))
-    npz_io.save_npz(args.outfile, final_ref)
-    logging.info("Finished creating reference")
-    logging.info("Running QC on the newly created reference...")       # main.py:134-135
+    for k_ in ("has_female", "has_male", "is_nipt", "trained_cutoff"):
+        writer.add(k_, final_ref[k_])
+    # the last writes and the sync run beside the QC of the tables (main.py:134-135)
+    from concurrent.futures import ThreadPoolExecutor
     from .ref_qc import qc_reference
-    qc_reference(final_ref)
+    with ThreadPoolExecutor(max_workers=1) as ex:
+        closing = ex.submit(writer.close)
+        logging.info("Running QC on the newly created reference...")
+        try:
+            qc_reference(final_ref)
+        finally:
+            closing.result()
+    logging.info("Finished creating reference")
 
 
 # --------------------------------------------------------------------------- gender / predict

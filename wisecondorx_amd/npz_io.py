@@ -47,6 +47,7 @@ def _cpu_budget():
 
 
 _THREADS = max(2, min(16, _cpu_budget()))
+_LOAD_THREADS = max(2, min(32, _cpu_budget()))      # sample import: inflate + unpickle, mostly GIL-free
 _Z64 = 0xFFFFFFFF           # sizes / offsets from here on go into ZIP64 extra fields
 _DOS_TIME, _DOS_DATE = 0, (1980 - 1980) << 9 | 1 << 5 | 1      # 1980-01-01 00:00, like np.savez
 
@@ -77,63 +78,92 @@ def _crc_chunks(mv, nparts):
     return [(o, min(o + step, n)) for o in range(0, n, step)]
 
 
-def save_npz(path, arrays, compress_small=True):
-    if not str(path).endswith(".npz"):
-        path = str(path) + ".npz"
-    # ---- plan: every member as (name, header bytes, payload view | deflated bytes, method)
-    members = []
-    for name, val in arrays.items():
+class NpzWriter:
+    """A .npz written member by member: add() plans the member, fixes its place in the file and hands
+    its payload (CRC-32 + positional writes, in pieces) to the worker threads at once, so a table can
+    be on its way to the file while the next one is still being computed; close() writes the local
+    headers and the central directory, syncs and renames.  The file appears under its final name only
+    after EVERY write has succeeded (a failed write -- disk full -- must not leave a plausible-looking
+    archive behind); the temporary name is unique (two writers of one target, or somebody's stale
+    .tmp, must not trample each other).  Arrays handed to add() must stay unchanged until close()."""
+
+    def __init__(self, path, compress_small=True):
+        if not str(path).endswith(".npz"):
+            path = str(path) + ".npz"
+        self.final_path = str(path)
+        self.compress_small = compress_small
+        self.members, self.jobs, self.keep, self.flushes = [], [], [], []
+        self.off = 0
+        self.fd, self.tmp_path = tempfile.mkstemp(dir=os.path.dirname(os.path.abspath(self.final_path)) or ".",
+                                                  prefix=os.path.basename(self.final_path) + ".", suffix=".tmp")
+        os.fchmod(self.fd, 0o644 & ~_UMASK)
+        self.ex = ThreadPoolExecutor(max_workers=_THREADS)
+        self.closed = False
+
+    def add(self, name, val):
         arr = np.asanyarray(val)
         fname = (name + ".npy").encode("utf-8")
         big = (arr.nbytes >= _BIG and arr.dtype != object and not arr.dtype.hasobject
                and (arr.flags.c_contiguous or arr.flags.f_contiguous))
         if big:
-            members.append({"name": fname, "head": _npy_header(arr), "raw": _raw_view(arr), "method": 0})
+            m = {"name": fname, "head": _npy_header(arr), "raw": _raw_view(arr), "method": 0}
+            self.keep.append(arr)
         else:
             buf = io.BytesIO()
             np.lib.format.write_array(buf, arr, allow_pickle=True)
             data = buf.getvalue()
-            if compress_small and len(data) < _DEFLATE_MAX:
+            if self.compress_small and len(data) < _DEFLATE_MAX:
                 co = zlib.compressobj(zlib.Z_DEFAULT_COMPRESSION, zlib.DEFLATED, -15)
                 comp = co.compress(data) + co.flush()
-                members.append({"name": fname, "head": b"", "raw": memoryview(comp), "method": 8,
-                                "usize": len(data), "crc": zlib.crc32(data)})
+                m = {"name": fname, "head": b"", "raw": memoryview(comp), "method": 8,
+                     "usize": len(data), "crc": zlib.crc32(data)}
             else:
-                members.append({"name": fname, "head": b"", "raw": memoryview(data), "method": 0})
-    # ---- layout (stored members have known sizes: nothing depends on the CRCs yet)
-    off = 0
-    for m in members:
+                m = {"name": fname, "head": b"", "raw": memoryview(data), "method": 0}
+        # layout (stored members have known sizes: nothing depends on the CRCs yet)
         m.setdefault("usize", len(m["head"]) + len(m["raw"]))
         m["csize"] = len(m["head"]) + len(m["raw"])
-        m["offset"] = off
+        m["offset"] = self.off
         m["z64"] = m["usize"] >= _Z64 or m["csize"] >= _Z64
         m["lhdr_len"] = 30 + len(m["name"]) + (20 if m["z64"] else 0)
-        m["data_off"] = off + m["lhdr_len"]
-        off = m["data_off"] + m["csize"]
-    cd_off = off
-    # written next to the target and renamed once EVERY write has succeeded: a failed write (disk
-    # full) must not leave a plausible-looking archive behind
-    # (a unique name: two writers of one target, or somebody's stale .tmp, must not trample each other)
-    final_path = str(path)
-    fd, path = tempfile.mkstemp(dir=os.path.dirname(os.path.abspath(final_path)) or ".",
-                                prefix=os.path.basename(final_path) + ".", suffix=".tmp")
-    os.fchmod(fd, 0o644 & ~_UMASK)
-    ok = False
-    try:
-        with ThreadPoolExecutor(max_workers=_THREADS) as ex:
-            # payload writes (positional, in pieces) and the CRC-32 of each stored member run side
-            # by side on the worker threads (zlib and os.pwrite release the GIL)
-            # every chunk of a stored member: CRC-32 and positional write on one worker (zlib and
-            # os.pwrite release the GIL); the member's CRC is the chunks' combined in order
-            jobs = []
-            for m in members:
-                if "crc" in m:
-                    jobs.append((m, [ex.submit(_pwrite_all, fd, m["raw"], m["data_off"])]))
-                    continue
-                base = m["data_off"] + len(m["head"])
-                jobs.append((m, [ex.submit(_crc_and_write, fd, m["raw"][a:b], base + a)
-                                 for a, b in _crc_chunks(m["raw"], 4 * _THREADS)]))
-            for m, fs in jobs:
+        m["data_off"] = self.off + m["lhdr_len"]
+        self.off = m["data_off"] + m["csize"]
+        self.members.append(m)
+        # every chunk of a stored member: CRC-32 and positional write on one worker (zlib and
+        # os.pwrite release the GIL); the member's CRC is the chunks' combined in order
+        if "crc" in m:
+            self.jobs.append((m, [self.ex.submit(_pwrite_all, self.fd, m["raw"], m["data_off"])]))
+        else:
+            base = m["data_off"] + len(m["head"])
+            self.jobs.append((m, [self.ex.submit(_crc_and_write, self.fd, m["raw"][a:b], base + a)
+                                  for a, b in _crc_chunks(m["raw"], 4 * _THREADS)]))
+
+    def flush_async(self):
+        """Start writing back what has been added so far (an fsync on a worker thread once those
+        members' payload writes are done): close()'s own fsync then finds little left to do."""
+        pending = [f for _, fs in self.jobs for f in fs]
+
+        def sync():
+            for f in pending:
+                f.exception()           # (wait; a failed write is reported by close())
+            os.fsync(self.fd)
+        self.flushes.append(self.ex.submit(sync))
+
+    def abort(self):
+        if self.closed:
+            return
+        self.closed = True
+        self.ex.shutdown(wait=True, cancel_futures=True)
+        os.close(self.fd)
+        try:
+            os.unlink(self.tmp_path)
+        except OSError:
+            pass
+
+    def close(self):
+        ok = False
+        fd, members = self.fd, self.members
+        try:
+            for m, fs in self.jobs:
                 if "crc" in m:
                     fs[0].result()
                     continue
@@ -142,6 +172,9 @@ def save_npz(path, arrays, compress_small=True):
                     c, n = f.result()
                     crc = crc32_combine(crc, c, n)
                 m["crc"] = crc
+            for f in self.flushes:
+                f.result()
+            cd_off = self.off
             # ---- headers and central directory
             cd = b""
             for m in members:
@@ -178,18 +211,32 @@ def save_npz(path, arrays, compress_small=True):
                                 0xFFFFFFFF if len(cd) >= _Z64 else len(cd),
                                 0xFFFFFFFF if cd_off >= _Z64 else cd_off, 0)
             _pwrite_all(fd, memoryview(cd + tail), cd_off)
-        os.fsync(fd)            # the bytes are on disk before the name points at them
-        ok = True
-    finally:
-        os.close(fd)
-        if ok:
-            os.replace(path, final_path)
-        else:
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
-    return final_path
+            os.fsync(fd)            # the bytes are on disk before the name points at them
+            ok = True
+        finally:
+            self.closed = True
+            self.ex.shutdown(wait=True, cancel_futures=True)
+            os.close(fd)
+            self.keep = []
+            if ok:
+                os.replace(self.tmp_path, self.final_path)
+            else:
+                try:
+                    os.unlink(self.tmp_path)
+                except OSError:
+                    pass
+        return self.final_path
+
+
+def save_npz(path, arrays, compress_small=True):
+    w = NpzWriter(path, compress_small)
+    try:
+        for name, val in arrays.items():
+            w.add(name, val)
+    except BaseException:
+        w.abort()
+        raise
+    return w.close()
 
 
 def _pwrite_all(fd, view, offset):

@@ -214,8 +214,9 @@ class DeviceCounts:
 
 def filter_from_dist(dist_to_med):
     """newref_control.py:42-47 on a precomputed distance profile."""
-    mad = np.median(np.abs(dist_to_med - np.median(dist_to_med)))
-    cutoff = max(np.median(dist_to_med) + 10 * mad, 5.0)
+    med = np.median(dist_to_med)
+    mad = np.median(np.abs(dist_to_med - med))
+    cutoff = max(med + 10 * mad, 5.0)
     return dist_to_med > cutoff, cutoff
 
 
