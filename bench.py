@@ -442,7 +442,16 @@ def config5_block(w, batch=96, runs=3):
         xG = pt.prepare_batch_dev(dG, ref, ".F", w.ctx, cache)
         torch.cuda.synchronize()
         t_prep.append(time.perf_counter() - t0)
-        rows = wd.predict_batch_dev(w.backend, A, G, xA, xG, w.rem, pt)
+        if os.environ.get("WCX_PROFILE_CONFIG5") and _ == runs - 1:      # dev aid: host profile -> stderr
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            w.ctx.lib.wcx_debug_flags(w.ctx.h, 8)          # CBS stage laps -> stderr
+            rows = pr.runcall(wd.predict_batch_dev, w.backend, A, G, xA, xG, w.rem, pt)
+            w.ctx.lib.wcx_debug_flags(w.ctx.h, 0)
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(8)
+        else:
+            rows = wd.predict_batch_dev(w.backend, A, G, xA, xG, w.rem, pt)
         torch.cuda.synchronize()
         t_all.append(time.perf_counter() - t0)
     ms = {k_: w.ctx.kernel_ms(k_) for k_ in ("aut:normalize", "normalize", "cbs", "segment_z")}

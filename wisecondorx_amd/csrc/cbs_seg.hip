@@ -1264,7 +1264,12 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
   auto is_na = [](double v) { return v == 0.0 || v != v; };               // CBS.R:41 ratio == 0 -> NA; is.na()
   auto is_drop = [](double v) { return v == 0.0 || !std::isfinite(v); };  // DNAcopy segment(): is.finite()
   auto for_samples = [&](auto &&fn) {
-    const int nt = std::min(n_samples, 8);
+    // (host threads for the per-sample assembly / wrap-up loops: up to 32, within what the machine has)
+    static const int hw_threads = [] {
+      const unsigned h = std::thread::hardware_concurrency();
+      return (int)std::max(1u, std::min(32u, h ? h : 8u));
+    }();
+    const int nt = std::min(n_samples, hw_threads);
     if (nt <= 1) { for (int s = 0; s < n_samples; ++s) fn(s); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t)
