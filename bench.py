@@ -436,8 +436,7 @@ def config5_block(w, batch=96, runs=3):
     for _ in range(runs):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dA = torch.from_numpy(pt.sample_counts_matrix(tests, ref, "")).to(dev)
-        dG = torch.from_numpy(pt.sample_counts_matrix(tests, ref, ".F")).to(dev)
+        dA, dG = pt.batch_counts_dev(tests, ref, ("", ".F"), dev, cache)
         xA = pt.prepare_batch_dev(dA, ref, "", w.ctx, cache)
         xG = pt.prepare_batch_dev(dG, ref, ".F", w.ctx, cache)
         torch.cuda.synchronize()

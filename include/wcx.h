@@ -302,9 +302,12 @@ int wcx_cbs(wcx_ctx *ctx, const double *r, const double *w, const int64_t *chr_o
 int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples, int64_t n_bins,
                   const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
                   double *out_seg, int cap, int *out_count);
-/* wcx_cbs_batch on DEVICE-resident r, w (wcx_post_process_merge_dev's outputs): they are copied once
- * into pinned host memory (the NA-free series are assembled and the segments post-processed on the
- * host, CBS.R:41-63,84-129); everything else as wcx_cbs_batch. */
+/* wcx_cbs_batch on DEVICE-resident r, w (wcx_post_process_merge_dev's outputs).  The NA-free series
+ * (CBS.R:41-63) are compacted on the device; the host's share of the work -- the decisions between
+ * the rounds, the segments' post-processing (CBS.R:84-129) -- reads the compacted x | w | bin
+ * positions, exported into pinned memory beside the first round's kernels.  r and w themselves only
+ * come down when they hold +-inf (dropped from the series, but not "NA" to CBS.R:84-113).  Same
+ * results, bit for bit, as wcx_cbs_batch on host copies of r and w. */
 int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_samples,
                       int64_t n_bins, const int64_t *chr_off, int n_chr, double alpha, int64_t binsize,
                       uint64_t seed, double *out_seg, int cap, int *out_count);

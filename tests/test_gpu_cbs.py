@@ -170,3 +170,61 @@ def test_cbs_short_arc_bound_is_an_exact_shortcut(pt):
     assert fired >= 4
     segs0 = sorted(s for s in with_shortcut[0] if s[0] == 0)
     assert len(segs0) == 3 and abs(segs0[1][1] - 500) <= 2 and abs(segs0[1][2] - 1700) <= 2
+
+
+@pytest.mark.parametrize("with_inf", [False, True])
+def test_cbs_batch_dev_equals_the_host_api(pt, with_inf):
+    """wcx_cbs_batch_dev (per-bin vectors in HBM: series compacted on the device, x | w | positions
+    exported beside the first round, CBS.R:84-129 restated on the compacted series) == wcx_cbs_batch
+    on the same vectors from the host: the same segments and bit-identical means -- NA runs (zeros,
+    NaN) short and long, leading / trailing NAs, an all-NA chromosome, zero weights, planted
+    change-points.  with_inf: +-inf values are dropped from the series but are not NA to the
+    post-processing; the device path then falls back to the host's r / w (same answer)."""
+    import torch
+    from wisecondorx_amd import _lib
+    rng = np.random.default_rng(12)
+    n_per_chr = [700, 500, 433, 301] + [260] * 19
+    ns, n_chr = 5, 23
+    off = np.concatenate(([0], np.cumsum(n_per_chr))).astype(np.int64)
+    n_bins = int(off[-1]) + 37                               # (bins beyond the 23 chromosomes: ignored)
+    r = rng.normal(0, 0.05, (ns, n_bins))
+    w = rng.uniform(0.5, 2.0, (ns, n_bins))
+    for s in range(ns):
+        c = [1, 3, 0, 2, 5][s]
+        a = int(off[c]) + 120
+        r[s, a:a + 90] += 0.5                                # a change-point pair
+        r[s, off[2] + 50:off[2] + 58] = 0                    # short NA run
+        r[s, off[4] + 100:off[4] + 130] = np.nan             # long NA run (30 > 4 at 500 kb): split
+        r[s, off[6]:off[6] + 11] = 0                         # leading NAs
+        r[s, off[7] + 255:off[7 + 1]] = 0                    # trailing NAs
+        w[s, off[8] + 10:off[8] + 20] = 0                    # zero weights -> 1
+    r[2, off[9]:off[10]] = 0                                 # all-NA chromosome
+    if with_inf:
+        r[1, off[11] + 40] = np.inf
+        r[3, off[4] + 110] = -np.inf                         # inside the NaN run: breaks it for CBS.R:84-113
+    ctx = _lib.default_context()
+    off_a, off_p = _lib.i64_array(off)
+    cap = 512
+
+    def host():
+        seg = np.empty((ns, cap, 4)); cnt = np.zeros(ns, dtype=np.int32)
+        _lib.check(ctx.lib.wcx_cbs_batch(ctx.h, _lib.ptr(np.ascontiguousarray(r)), _lib.ptr(np.ascontiguousarray(w)),
+                                         ns, n_bins, off_p, n_chr, 1e-4, 500000, 3, _lib.ptr(seg), cap, _lib.ptr(cnt)))
+        return [seg[i, :cnt[i]].copy() for i in range(ns)]
+
+    def device():
+        d_r = torch.from_numpy(r).cuda(); d_w = torch.from_numpy(w).cuda()
+        torch.cuda.synchronize()
+        seg = np.empty((ns, cap, 4)); cnt = np.zeros(ns, dtype=np.int32)
+        _lib.check(ctx.lib.wcx_cbs_batch_dev(ctx.h, d_r.data_ptr(), d_w.data_ptr(), ns, n_bins, off_p, n_chr,
+                                             1e-4, 500000, 3, _lib.ptr(seg), cap, _lib.ptr(cnt)))
+        return [seg[i, :cnt[i]].copy() for i in range(ns)]
+
+    want, got = host(), device()
+    assert sum(len(x) for x in want) > ns * 22               # (change-points and NA splits were found)
+    for a, b in zip(want, got):
+        assert a.shape == b.shape
+        assert np.array_equal(a, b, equal_nan=True)
+    again = device()                                          # (staging buffers reused)
+    for a, b in zip(want, again):
+        assert np.array_equal(a, b, equal_nan=True)

@@ -533,3 +533,24 @@ def test_npz_writer_streams_members_and_aborts_cleanly(tmp_path):
     w.flush_async()
     w.abort()
     assert sorted(os.listdir(tmp_path)) == ["ref.npz"]
+
+
+def test_sample_counts_matrix_threaded_and_in_place():
+    """The batch count matrix (predict_tools.py:36-44 layout: truncate / zero-pad every chromosome to the
+    reference's bin count): threaded fill == the plain statement, also into a dirty preallocated buffer."""
+    from wisecondorx_amd import predict_tools as pt
+    rng = np.random.default_rng(0)
+    bpc = [50, 40, 30, 7]
+    ref = {"bins_per_chr": np.array(bpc)}
+    samples = [{str(c + 1): rng.integers(0, 100, size=n + int(rng.integers(-3, 4))).astype(np.int32)
+                for c, n in enumerate(bpc)} for _ in range(20)]
+    starts = np.concatenate(([0], np.cumsum(bpc)))
+    want = np.zeros((len(samples), int(starts[-1])), dtype=np.int32)
+    for i, s in enumerate(samples):
+        for c, n_ref in enumerate(bpc):
+            n = min(n_ref, len(s[str(c + 1)]))
+            want[i, starts[c]:starts[c] + n] = s[str(c + 1)][:n]
+    assert np.array_equal(pt.sample_counts_matrix(samples, ref, ""), want)
+    buf = np.full((25, int(starts[-1])), -7, dtype=np.int32)
+    got = pt.sample_counts_matrix(samples[:5], ref, "", out=buf)
+    assert got.shape == (5, int(starts[-1])) and np.array_equal(got, want[:5])

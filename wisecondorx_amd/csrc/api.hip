@@ -244,6 +244,12 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
     hipEventDestroy(ctx->ev_sweep1);
   }
   if (ctx->ev_after_sweep) hipEventDestroy(ctx->ev_after_sweep);
+  if (ctx->copy_stream) {
+    hipStreamSynchronize(ctx->copy_stream);
+    hipStreamDestroy(ctx->copy_stream);
+    hipEventDestroy(ctx->ev_cbs_fill);
+    hipEventDestroy(ctx->ev_cbs_xw);
+  }
   if (ctx->aux_stream) {
     hipStreamSynchronize(ctx->aux_stream);
     hipStreamDestroy(ctx->aux_stream);

@@ -356,14 +356,6 @@ constexpr int PBS = 64;
 struct BlkStat { double smin, smax, wlo, whi; int amin, amax; };
 struct WorkItem { int seg, I, J; };
 
-__device__ __forceinline__ int find_seg(const int *__restrict__ boff, int ns, int blk) {
-  int lo = 0, hi = ns - 1;                      // largest s with boff[s] <= blk
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (boff[mid] <= blk) lo = mid; else hi = mid - 1;
-  }
-  return lo;
-}
 __device__ __forceinline__ double arc_bss(double si, double wi, double sj, double wj, double W) {
   const double d = sj - si, wa = wj - wi;
   return d * d / (wa * (W - wa) / W);
@@ -373,11 +365,12 @@ __global__ __launch_bounds__(256) void k_cbs_blockstats(const double *__restrict
                                                         const double *__restrict__ Wp,
                                                         const SegIn *__restrict__ segs,
                                                         const SegOut *__restrict__ so,
-                                                        const int *__restrict__ boff, int ns,
+                                                        const int *__restrict__ boff,
+                                                        const int *__restrict__ bseg,
                                                         int total_blocks, BlkStat *__restrict__ bs) {
   const int blk = (int)blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (blk >= total_blocks) return;
-  const int s = find_seg(boff, ns, blk);
+  const int s = bseg[blk];
   const SegIn sg = segs[s];
   const double W = so[s].W;
   const int p0 = (blk - boff[s]) * PBS, p = p0 + lane;
@@ -395,23 +388,27 @@ __global__ __launch_bounds__(256) void k_cbs_blockstats(const double *__restrict
   }
 }
 
-// lower bound L[s] of the maximum: arcs between the extreme positions of every block pair
+// lower bound L[s] of the maximum: arcs between the extreme positions of every block pair.
+// ONE WAVE per block row I (a 256-thread workgroup per row left most of its threads idle -- a series
+// has <= ~260 blocks -- and paid a dependent-load chain per workgroup: 273 k workgroups of a 96-sample
+// call cost 1 ms here and 3 ms in k_cbs_prune); bseg[blk] = the row's segment (host table).
 __global__ __launch_bounds__(256) void k_cbs_coarse(const double *__restrict__ S,
                                                     const double *__restrict__ Wp,
                                                     const SegIn *__restrict__ segs,
                                                     const SegOut *__restrict__ so,
-                                                    const int *__restrict__ boff, int ns,
+                                                    const int *__restrict__ boff,
+                                                    const int *__restrict__ bseg, int total_blocks,
                                                     const BlkStat *__restrict__ bs, int minw,
                                                     unsigned int *__restrict__ L) {
-  __shared__ float red[4];
-  const int blk = blockIdx.x;
-  const int s = find_seg(boff, ns, blk);
+  const int blk = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blk >= total_blocks) return;
+  const int s = bseg[blk];
   const SegIn sg = segs[s];
   const double W = so[s].W;
   const int n = sg.n, I = blk - boff[s], nb = boff[s + 1] - boff[s];
   const BlkStat bi = bs[blk];
   float best = 0.f;
-  for (int J = I + (int)threadIdx.x; J < nb; J += 256) {
+  for (int J = I + lane; J < nb; J += 64) {
     const BlkStat bj = bs[boff[s] + J];
     const int pa[2] = {bi.amin, bi.amax}, pb[2] = {bj.amin, bj.amax};
 #pragma unroll
@@ -427,44 +424,75 @@ __global__ __launch_bounds__(256) void k_cbs_coarse(const double *__restrict__ S
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(best, m, 64); best = o > best ? o : best; }
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float b = red[0];
-    for (int q = 1; q < 4; ++q) b = red[q] > b ? red[q] : b;
-    if (b > 0.f) atomicMax(&L[s], __float_as_uint(b));
-  }
+  if (lane == 0 && best > 0.f) atomicMax(&L[s], __float_as_uint(best));
 }
 
-// block pairs whose bound reaches L -> work list
+// block pairs whose bound reaches L -> work list.  A wave walks PRW consecutive block rows and stages
+// the kept pairs in LDS; the list's tail counter -- ONE address for the whole call -- is bumped once
+// per flush (~1 per 16 rows) instead of once per kept pair or row chunk: the returning same-address
+// atomics (3e5 .. 6e5 of them for 96 samples) were this kernel's 3 ms, not its arithmetic.
+constexpr int PRW = 16;          // rows per wave
+constexpr int PSTAGE = 256;      // staged pairs per wave
 __global__ __launch_bounds__(256) void k_cbs_prune(const SegOut *__restrict__ so,
-                                                   const int *__restrict__ boff, int ns,
+                                                   const int *__restrict__ boff,
+                                                   const int *__restrict__ bseg, int total_blocks,
                                                    const BlkStat *__restrict__ bs,
                                                    const unsigned int *__restrict__ L,
                                                    WorkItem *__restrict__ work, unsigned int cap,
                                                    unsigned int *__restrict__ count) {
-  const int blk = blockIdx.x;
-  const int s = find_seg(boff, ns, blk);
-  const double W = so[s].W;
-  const int I = blk - boff[s], nb = boff[s + 1] - boff[s];
-  const BlkStat bi = bs[blk];
-  const double Ls = (double)__uint_as_float(L[s]) * (1.0 - 1e-9);
-  for (int J = I + (int)threadIdx.x; J < nb; J += 256) {
-    const BlkStat bj = bs[boff[s] + J];
-    const double d1 = bj.smax - bi.smin, d2 = bi.smax - bj.smin;
-    const double D = d1 > d2 ? d1 : d2;
-    const double wlo = bj.wlo - bi.whi, whi = bj.whi - bi.wlo;
-    const double g1 = wlo * (W - wlo) / W, g2 = whi * (W - whi) / W;
-    const double g = g1 < g2 ? g1 : g2;
-    const bool keep = !(g > 0.0) || D * D / g >= Ls;     // (g <= 0: same / touching blocks, or the whole series)
-    if (keep) {
-      const unsigned int at = atomicAdd(count, 1u);
-      if (at < cap) { work[at].seg = s; work[at].I = I; work[at].J = J; }
+  __shared__ WorkItem stage[4][PSTAGE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  WorkItem *mine = stage[wave];
+  int staged = 0;                                            // wave-uniform
+  auto flush = [&]() {
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned int)staged);
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    for (int e = lane; e < staged; e += 64)
+      if (base + (unsigned int)e < cap) work[base + (unsigned int)e] = mine[e];
+    __builtin_amdgcn_wave_barrier();
+    staged = 0;
+  };
+  const int row0 = ((int)blockIdx.x * 4 + wave) * PRW;
+  for (int blk = row0; blk < row0 + PRW && blk < total_blocks; ++blk) {
+    const int s = bseg[blk];
+    const double W = so[s].W;
+    const int I = blk - boff[s], nb = boff[s + 1] - boff[s];
+    const BlkStat bi = bs[blk];
+    const double Ls = (double)__uint_as_float(L[s]) * (1.0 - 1e-9);
+    for (int J0 = I; J0 < nb; J0 += 64) {
+      const int J = J0 + lane;
+      bool keep = false;
+      if (J < nb) {
+        const BlkStat bj = bs[boff[s] + J];
+        const double d1 = bj.smax - bi.smin, d2 = bi.smax - bj.smin;
+        const double D = d1 > d2 ? d1 : d2;
+        const double wlo = bj.wlo - bi.whi, whi = bj.whi - bi.wlo;
+        const double g1 = wlo * (W - wlo) / W, g2 = whi * (W - whi) / W;
+        const double g = g1 < g2 ? g1 : g2;
+        keep = !(g > 0.0) || D * D / g >= Ls;            // (g <= 0: same / touching blocks, or the whole series)
+      }
+      const unsigned long long km = __ballot(keep);
+      if (km) {
+        if (staged + 64 > PSTAGE) flush();
+        if (keep) {
+          WorkItem wi;
+          wi.seg = s; wi.I = I; wi.J = J;
+          mine[staged + __popcll(km & ((1ull << lane) - 1ull))] = wi;
+        }
+        staged += __popcll(km);
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
+  if (staged) flush();
 }
 
-// the arcs of the listed block pairs, exactly (fp32 screen, fp64 formula, ties -> smallest (i, j))
+// the arcs of the listed block pairs, exactly (fp32 screen, fp64 formula, ties -> smallest (i, j)).
+// ONE WAVE per pair, no LDS, no barrier: lane q holds position i0 + q of block I and position j0 + q
+// of block J; the lane walks its own i against the 64 j (broadcast by readlane), then the wave's best
+// is a butterfly.  (A 256-thread workgroup per pair spent its time in the dependent loads of the
+// item and three barriers: 2.7 ms for the 6e5 pairs of a 96-sample call.)
 __global__ __launch_bounds__(256) void k_cbs_pairmax(const double *__restrict__ S,
                                                      const double *__restrict__ Wp,
                                                      const SegIn *__restrict__ segs,
@@ -473,60 +501,44 @@ __global__ __launch_bounds__(256) void k_cbs_pairmax(const double *__restrict__ 
                                                      const unsigned int *__restrict__ count, int minw,
                                                      ArcBest *__restrict__ res,
                                                      unsigned long long *__restrict__ bbits) {
-  __shared__ double sI[PBS], wI[PBS], sJ[PBS], wJ[PBS];
-  __shared__ double sb[256];
-  __shared__ int si_[256], sj_[256];
   const unsigned int nitem = *count < cap ? *count : cap;
-  const int tid = threadIdx.x;
-  for (unsigned int it = blockIdx.x; it < nitem; it += gridDim.x) {
+  const int lane = threadIdx.x & 63;
+  const unsigned int w0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwv = (gridDim.x * 256u) >> 6;
+  for (unsigned int it = w0; it < nitem; it += nwv) {
     const WorkItem wk = work[it];
     const SegIn sg = segs[wk.seg];
     const double W = so[wk.seg].W;
     const float Wf = (float)W;
     const int n = sg.n, i0 = wk.I * PBS, j0 = wk.J * PBS;
-    __syncthreads();
-    if (tid < PBS) {
-      const int p = i0 + tid;
-      sI[tid] = p <= n ? seg_S(S, sg, p) : 0.0; wI[tid] = p <= n ? seg_W(Wp, sg, W, p) : 0.0;
-    } else if (tid < 2 * PBS) {
-      const int q = tid - PBS, p = j0 + q;
-      sJ[q] = p <= n ? seg_S(S, sg, p) : 0.0; wJ[q] = p <= n ? seg_W(Wp, sg, W, p) : 0.0;
-    }
-    __syncthreads();
+    const int i = i0 + lane, pj = j0 + lane;
+    const double si = i <= n ? seg_S(S, sg, i) : 0.0, wi = i <= n ? seg_W(Wp, sg, W, i) : 0.0;
+    const double sJ = pj <= n ? seg_S(S, sg, pj) : 0.0, wJ = pj <= n ? seg_W(Wp, sg, W, pj) : 0.0;
     double bb = -1.0;
     float bf = -1.f;
     int bi = 0, bj = 0;
-    const int qi = tid >> 2, i = i0 + qi;
-    if (i <= n) {
-      const double si = sI[qi], wi = wI[qi];
-      for (int qj = (tid & 3); qj < PBS; qj += 4) {
-        const int j = j0 + qj, a = j - i;
-        if (j > n || a < minw || n - a < minw) continue;
-        const double d = sJ[qj] - si, wa = wJ[qj] - wi;
-        const float df = (float)d, waf = (float)wa;
-        const float b32 = df * df * Wf * __builtin_amdgcn_rcpf(waf * (Wf - waf));
-        if (b32 >= bf) {
-          const double b = d * d / (wa * (W - wa) / W);
-          if (b > bb || (b == bb && (i < bi || (i == bi && j < bj)))) {
-            bb = b; bi = i; bj = j; bf = (float)b * 0.999996f;
-          }
-        }
+    const int jmax = n - j0 < PBS - 1 ? n - j0 : PBS - 1;      // last position of block J inside the segment
+    for (int qj = 0; qj <= jmax; ++qj) {
+      const double sj = wcx::readlane_f64(sJ, qj), wj = wcx::readlane_f64(wJ, qj);
+      const int j = j0 + qj, a = j - i;
+      if (i > n || a < minw || n - a < minw) continue;
+      const double d = sj - si, wa = wj - wi;
+      const float df = (float)d, waf = (float)wa;
+      const float b32 = df * df * Wf * __builtin_amdgcn_rcpf(waf * (Wf - waf));
+      if (b32 >= bf) {
+        const double b = d * d / (wa * (W - wa) / W);
+        if (b > bb) { bb = b; bi = i; bj = j; bf = (float)b * 0.999996f; }   // (j ascending: first j wins ties)
       }
     }
-    sb[tid] = bb; si_[tid] = bi; sj_[tid] = bj;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-      if (tid < off) {
-        const int o = tid + off;
-        const bool take = sb[o] > sb[tid] ||
-                          (sb[o] == sb[tid] && (si_[o] < si_[tid] || (si_[o] == si_[tid] && sj_[o] < sj_[tid])));
-        if (take) { sb[tid] = sb[o]; si_[tid] = si_[o]; sj_[tid] = sj_[o]; }
-      }
-      __syncthreads();
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const double ob = wcx::shfl_xor_f64(bb, m);
+      const int oi = __shfl_xor(bi, m, 64), oj = __shfl_xor(bj, m, 64);
+      const bool take = ob > bb || (ob == bb && (oi < bi || (oi == bi && oj < bj)));
+      if (take) { bb = ob; bi = oi; bj = oj; }
     }
-    if (tid == 0) {
-      res[it].b = sb[0]; res[it].i = si_[0]; res[it].j = sj_[0];
-      if (sb[0] > 0.0) atomicMax(&bbits[wk.seg], (unsigned long long)__double_as_longlong(sb[0]));
+    if (lane == 0) {
+      res[it].b = bb; res[it].i = bi; res[it].j = bj;
+      if (bb > 0.0) atomicMax(&bbits[wk.seg], (unsigned long long)__double_as_longlong(bb));
     }
   }
 }
@@ -1220,6 +1232,75 @@ static void eval_sequential(const unsigned int *bits, int upto, int nperm, int n
   if (upto >= nperm) { r.decided = 1; r.significant = 1; }
 }
 
+// ---- series assembly on the device (wcx_cbs_batch_dev): the NA-free compaction of CBS.R:41-42 /
+// DNAcopy's is.finite() of every (sample, chromosome), straight from the per-bin vectors in HBM
+struct ChrOff { int64_t off[32]; };
+__device__ __forceinline__ bool cbs_is_drop(double v) { return v == 0.0 || !(fabs(v) < HUGE_VAL); }
+
+// cnt[sample * n_chr + chr] = number of kept bins
+// cnt[n_samples * n_chr] = number of +-inf values anywhere (dropped from the series but NOT "NA" to
+// the post-processing of CBS.R:84-129: with any of them the host falls back to the full r / w)
+__global__ __launch_bounds__(256) void k_cbs_count(const double *__restrict__ r, int64_t n_bins, ChrOff co,
+                                                   int n_chr, int n_samples, int *__restrict__ cnt) {
+  __shared__ int red[4];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const double *rr = r + (int64_t)s * n_bins + co.off[c];
+  const int nall = (int)(co.off[c + 1] - co.off[c]);
+  int m = 0, ninf = 0;
+  for (int i = threadIdx.x; i < nall; i += 256) {
+    const double v = rr[i];
+    m += cbs_is_drop(v) ? 0 : 1;
+    ninf += (v == HUGE_VAL || v == -HUGE_VAL) ? 1 : 0;
+  }
+  m = wcx::wave_sum_i(m);
+  if (__any(ninf != 0)) { ninf = wcx::wave_sum_i(ninf); if ((threadIdx.x & 63) == 0) atomicAdd(&cnt[n_samples * n_chr], ninf); }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[s * n_chr + c] = red[0] + red[1] + red[2] + red[3];
+}
+
+// device -> PINNED HOST copy by a small grid: the runtime's own device-to-host copy is a blit kernel
+// that fills every CU while it moves data at PCIe speed -- a kernel launched beside it waits (measured:
+// k_cbs_prepare 0.2 -> 8.8 ms beside 600 MB of such copies).  64 workgroups keep the link busy and
+// leave the chip to the round's kernels.
+__global__ __launch_bounds__(256) void k_cbs_export(const uint4 *__restrict__ src, uint4 *__restrict__ dst_host,
+                                                    int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+    dst_host[i] = src[i];
+}
+
+// x[lo + j] / w[lo + j] / pos[lo + j] = the j-th kept bin of the (sample, chromosome), in bin order; weight 0 -> 1
+__global__ __launch_bounds__(256) void k_cbs_fill(const double *__restrict__ r, const double *__restrict__ w,
+                                                  int64_t n_bins, ChrOff co, int n_chr,
+                                                  const int64_t *__restrict__ lo, double *__restrict__ x,
+                                                  double *__restrict__ xw, int *__restrict__ pos) {
+  __shared__ int wtot[4];
+  const int c = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t o = (int64_t)s * n_bins + co.off[c];
+  const int nall = (int)(co.off[c + 1] - co.off[c]);
+  int64_t at = lo[s * n_chr + c];
+  for (int i0 = 0; i0 < nall; i0 += 256) {
+    const int i = i0 + (int)threadIdx.x;
+    const double v = i < nall ? r[o + i] : 0.0;
+    const bool keep = i < nall && !cbs_is_drop(v);
+    const unsigned long long m = __ballot(keep);
+    __syncthreads();                                   // (wtot of the previous chunk fully read)
+    if (lane == 0) wtot[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int t = wtot[q]; before += q < wave ? t : 0; all += t; }
+    if (keep) {
+      const int64_t dst = at + before + __popcll(m & ((1ull << lane) - 1ull));
+      const double wt = w[o + i];
+      x[dst] = v;
+      xw[dst] = wt == 0.0 ? 1.0 : wt;
+      pos[dst] = i + 1;                                // 1-based bin within the chromosome (CBS.R:49)
+    }
+    at += all;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1233,10 +1314,20 @@ int wcx_cbs_getbdry(double eta, int nperm, int max_ones, int32_t *out) {
   return WCX_OK;
 }
 
-int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples, int64_t n_bins,
-                  const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
-                  double *out_seg, int cap, int *out_count) {
+}  // extern "C"
+
+// r / w: the per-bin vectors on the host.  d_r / d_w != NULL (wcx_cbs_batch_dev): the vectors are in
+// HBM and r / w are PINNED host buffers still to be filled.  The series are then compacted on the
+// device (no upload); what the host reads comes down on the auxiliary stream `aux` beside the first
+// round's kernels, in the order it is needed: the compacted x | w (the decisions after the first round
+// of statistics: short-arc bound, edge statistics), then r and w themselves (bin positions and the
+// segments' post-processing, CBS.R:84-129, after the last round).
+static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const double *d_r, const double *d_w,
+                          hipStream_t aux, int n_samples, int64_t n_bins,
+                          const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
+                          double *out_seg, int cap, int *out_count) {
   WCX_ARG(ctx && r && w && chr_off && out_seg && out_count, "NULL argument");
+  WCX_ARG(n_chr <= 31, "more than 31 chromosomes");
   WCX_ARG(n_samples > 0 && n_chr > 0 && alpha > 0 && alpha <= 1 && binsize > 0 && cap >= 0,
           "bad parameters");
   WCX_ARG(chr_off[n_chr] <= n_bins, "chr_off beyond n_bins");
@@ -1276,41 +1367,67 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       th.emplace_back([&, t] { for (int s = t; s < n_samples; s += nt) fn(s); });
     for (auto &x : th) x.join();
   };
-  for_samples([&](int s) {
-    for (int c = 0; c < n_chr; ++c) {
-      const double *rr = r + (int64_t)s * n_bins + chr_off[c];
-      const int nall = (int)(chr_off[c + 1] - chr_off[c]);
-      int64_t m = 0;
-      for (int i = 0; i < nall; ++i) m += is_drop(rr[i]) ? 0 : 1;
-      cnt_sc[(size_t)s * n_chr + c] = m;
-    }
-  });
+  ChrOff co;
+  for (int c = 0; c <= n_chr; ++c) co.off[c] = chr_off[c];
+  int64_t *d_lo = nullptr;
+  int n_inf = 0;            // device path: +-inf values in r (then the host needs r / w themselves)
+  bool copies_queued = false, xw_waited = false;
+  if (d_r) {
+    void *scr2 = nullptr;
+    const size_t nsc = cnt_sc.size();
+    const int rc2 = wcx_scratch2(ctx, nsc * 16 + 64, &scr2);
+    if (rc2) return rc2;
+    d_lo = reinterpret_cast<int64_t *>(scr2);
+    int *d_cnt = reinterpret_cast<int *>(d_lo + nsc);
+    WCX_HIP(hipMemsetAsync(d_cnt + nsc, 0, 4, st));
+    k_cbs_count<<<dim3((unsigned)n_chr, (unsigned)n_samples), 256, 0, st>>>(d_r, n_bins, co, n_chr, n_samples,
+                                                                             d_cnt);
+    WCX_HIP(hipGetLastError());
+    std::vector<int> hc(nsc + 1);
+    WCX_HIP(hipMemcpyAsync(hc.data(), d_cnt, (nsc + 1) * 4, hipMemcpyDeviceToHost, st));
+    WCX_HIP(hipStreamSynchronize(st));
+    for (size_t q = 0; q < nsc; ++q) cnt_sc[q] = hc[q];
+    n_inf = hc[nsc];
+  } else {
+    for_samples([&](int s) {
+      for (int c = 0; c < n_chr; ++c) {
+        const double *rr = r + (int64_t)s * n_bins + chr_off[c];
+        const int nall = (int)(chr_off[c + 1] - chr_off[c]);
+        int64_t m = 0;
+        for (int i = 0; i < nall; ++i) m += is_drop(rr[i]) ? 0 : 1;
+        cnt_sc[(size_t)s * n_chr + c] = m;
+      }
+    });
+  }
   int64_t total = 0;
   std::vector<int64_t> lo_sc(cnt_sc.size());
   for (size_t q = 0; q < cnt_sc.size(); ++q) { lo_sc[q] = total; total += cnt_sc[q]; }
   // x | w | 1-based bin index within the chromosome (CBS.R:49), in the context's pinned staging area
+  // (each part padded to whole 16-byte words: the device path fills them with 16-byte stores)
+  const int64_t totp = (total + 3) & ~(int64_t)3;
   void *hstage = nullptr;
   {
-    const int rcs = wcx_host_scratch(ctx, (size_t)total * 20 + 64, &hstage);
+    const int rcs = wcx_host_scratch(ctx, (size_t)totp * 20 + 64, &hstage);
     if (rcs) return rcs;
   }
-  double *hx = reinterpret_cast<double *>(hstage), *hw = hx + total;
-  int *hpos = reinterpret_cast<int *>(hw + total);
-  for_samples([&](int s) {
-    for (int c = 0; c < n_chr; ++c) {
-      const int64_t o = (int64_t)s * n_bins + chr_off[c];
-      const int nall = (int)(chr_off[c + 1] - chr_off[c]);
-      int64_t at = lo_sc[(size_t)s * n_chr + c];
-      for (int i = 0; i < nall; ++i) {
-        const double v = r[o + i];
-        if (is_drop(v)) continue;
-        hx[at] = v;
-        hw[at] = w[o + i] == 0.0 ? 1.0 : w[o + i];   // weight == 0 -> 1 (1^-99 == 1)
-        hpos[at] = i + 1;
-        ++at;
+  double *hx = reinterpret_cast<double *>(hstage), *hw = hx + totp;
+  int *hpos = reinterpret_cast<int *>(hw + totp);
+  if (!d_r)
+    for_samples([&](int s) {
+      for (int c = 0; c < n_chr; ++c) {
+        const int64_t o = (int64_t)s * n_bins + chr_off[c];
+        const int nall = (int)(chr_off[c + 1] - chr_off[c]);
+        int64_t at = lo_sc[(size_t)s * n_chr + c];
+        for (int i = 0; i < nall; ++i) {
+          const double v = r[o + i];
+          if (is_drop(v)) continue;
+          hx[at] = v;
+          hw[at] = w[o + i] == 0.0 ? 1.0 : w[o + i];   // weight == 0 -> 1 (1^-99 == 1)
+          hpos[at] = i + 1;
+          ++at;
+        }
       }
-    }
-  });
+    });
   for (int s = 0; s < n_samples; ++s)
     for (int c = 0; c < n_chr; ++c) {
       const size_t q = (size_t)s * n_chr + c;
@@ -1337,12 +1454,12 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     const unsigned int work_cap = 1u << 22;                  // block pairs evaluated per round at most
     const size_t qtab_floats = (size_t)(KMAXC - 1) * ((size_t)N + (size_t)NTP * max_segs) +
                                (size_t)max_segs * (KMAXC + 1) * QC_W;
-    const size_t need = (size_t)N * (8 * 5 + 4 * 2) + (size_t)max_segs * (sizeof(SegIn) + sizeof(SegOut) + 8) +
+    const size_t need = (size_t)N * (8 * 5 + 4 * 3) + 4096 + (size_t)max_segs * (sizeof(SegIn) + sizeof(SegOut) + 8) +
                         (size_t)max_segs * P.ngrid * 16 + max_items * (sizeof(ArcItem) + sizeof(ArcBest)) +
                         (size_t)max_jobs * (2 * sizeof(PermJob) + (size_t)(nw + NCH) * 4) +
                         (any_big ? (size_t)BIG_GRID * (npad_max + 64) * 4 : 0) +
                         (size_t)EXACT_GRID * npad_max * 8 + FLAG_CAP * sizeof(uint2) + qtab_floats * 4 +
-                        max_blocks * sizeof(BlkStat) + (size_t)work_cap * (sizeof(WorkItem) + sizeof(ArcBest)) +
+                        max_blocks * (sizeof(BlkStat) + 4) + (size_t)work_cap * (sizeof(WorkItem) + sizeof(ArcBest)) +
                         (size_t)max_segs * 32 + (1 << 16);
     void *scr = nullptr;
     rc = wcx_scratch(ctx, need, &scr);
@@ -1351,6 +1468,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     A.base = reinterpret_cast<char *>(scr);
     double *dX = A.take<double>(N), *dW = A.take<double>(N), *dS = A.take<double>(N), *dWp = A.take<double>(N);
     double *dYd = A.take<double>(N);
+    int *dpos = A.take<int>((size_t)N + 4);
     float *dy = A.take<float>(N), *drw = A.take<float>(N);
     SegIn *dseg = A.take<SegIn>(max_segs);
     SegOut *dso = A.take<SegOut>(max_segs);
@@ -1370,12 +1488,38 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     WorkItem *dwork = A.take<WorkItem>(work_cap);
     ArcBest *dres = A.take<ArcBest>(work_cap);
     int *dboff = A.take<int>(max_segs + 1);
+    int *dbseg = A.take<int>(max_blocks);
     unsigned int *dL = A.take<unsigned int>(max_segs + 2);     // [ns] lower bounds | work count
     unsigned long long *dbbits = A.take<unsigned long long>(max_segs);
     unsigned long long *dbij = A.take<unsigned long long>(max_segs);
     static const bool no_prune = getenv("WCX_CBS_NOPRUNE") && atoi(getenv("WCX_CBS_NOPRUNE"));
-    WCX_HIP(hipMemcpyAsync(dX, hx, (size_t)N * 8, hipMemcpyHostToDevice, st));
-    WCX_HIP(hipMemcpyAsync(dW, hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
+    if (d_r) {
+      WCX_HIP(hipMemcpyAsync(d_lo, lo_sc.data(), lo_sc.size() * 8, hipMemcpyHostToDevice, st));
+      k_cbs_fill<<<dim3((unsigned)n_chr, (unsigned)n_samples), 256, 0, st>>>(d_r, d_w, n_bins, co, n_chr, d_lo,
+                                                                            dX, dW, dpos);
+      WCX_HIP(hipGetLastError());
+      // what the host reads, in the order it needs it, on the copy stream beside this round's
+      // kernels: x | w (decisions after the first statistics), then the bin positions (wrap-up)
+      WCX_HIP(hipEventRecord(ctx->ev_cbs_fill, st));
+      WCX_HIP(hipStreamWaitEvent(aux, ctx->ev_cbs_fill, 0));
+      const int64_t n16 = ((int64_t)N * 8 + 15) / 16;      // (arena slots and the staging area are padded)
+      k_cbs_export<<<64, 256, 0, aux>>>(reinterpret_cast<const uint4 *>(dX), reinterpret_cast<uint4 *>(hx), n16);
+      k_cbs_export<<<64, 256, 0, aux>>>(reinterpret_cast<const uint4 *>(dW), reinterpret_cast<uint4 *>(hw), n16);
+      WCX_HIP(hipGetLastError());
+      WCX_HIP(hipEventRecord(ctx->ev_cbs_xw, aux));
+      k_cbs_export<<<64, 256, 0, aux>>>(reinterpret_cast<const uint4 *>(dpos), reinterpret_cast<uint4 *>(hpos),
+                                        ((int64_t)N * 4 + 15) / 16);
+      WCX_HIP(hipGetLastError());
+      if (n_inf > 0) {
+        const size_t rw_bytes = (size_t)n_samples * n_bins * 8;
+        WCX_HIP(hipMemcpyAsync(const_cast<double *>(r), d_r, rw_bytes, hipMemcpyDeviceToHost, aux));
+        WCX_HIP(hipMemcpyAsync(const_cast<double *>(w), d_w, rw_bytes, hipMemcpyDeviceToHost, aux));
+      }
+      copies_queued = true;
+    } else {
+      WCX_HIP(hipMemcpyAsync(dX, hx, (size_t)N * 8, hipMemcpyHostToDevice, st));
+      WCX_HIP(hipMemcpyAsync(dW, hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
+    }
     const size_t lds_small = (size_t)(std::min(npad_max, LDS_KEYS_MAX) + 32) * 4;
     WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cbs_perm_hyb<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
@@ -1539,10 +1683,14 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
         WCX_HIP(hipMemsetAsync(dL, 0, (size_t)(ns + 1) * 4, st));
         WCX_HIP(hipMemsetAsync(dbbits, 0, (size_t)ns * 8, st));
         WCX_HIP(hipMemsetAsync(dbij, 0xff, (size_t)ns * 8, st));
-        k_cbs_blockstats<<<(unsigned)((total_blocks + 3) / 4), 256, 0, st>>>(dS, dWp, dseg, dso, dboff, ns,
-                                                                             total_blocks, dbs);
-        k_cbs_coarse<<<(unsigned)total_blocks, 256, 0, st>>>(dS, dWp, dseg, dso, dboff, ns, dbs, P.minw, dL);
-        k_cbs_prune<<<(unsigned)total_blocks, 256, 0, st>>>(dso, dboff, ns, dbs, dL, dwork, work_cap, dcount);
+        std::vector<int> bseg((size_t)total_blocks);
+        for (int a = 0; a < ns; ++a) std::fill(bseg.begin() + boff[a], bseg.begin() + boff[a + 1], a);
+        WCX_HIP(hipMemcpyAsync(dbseg, bseg.data(), (size_t)total_blocks * 4, hipMemcpyHostToDevice, st));
+        const unsigned rows4 = (unsigned)((total_blocks + 3) / 4);
+        k_cbs_blockstats<<<rows4, 256, 0, st>>>(dS, dWp, dseg, dso, dboff, dbseg, total_blocks, dbs);
+        k_cbs_coarse<<<rows4, 256, 0, st>>>(dS, dWp, dseg, dso, dboff, dbseg, total_blocks, dbs, P.minw, dL);
+        k_cbs_prune<<<(unsigned)((total_blocks + 4 * PRW - 1) / (4 * PRW)), 256, 0, st>>>(
+            dso, dboff, dbseg, total_blocks, dbs, dL, dwork, work_cap, dcount);
         k_cbs_pairmax<<<8192, 256, 0, st>>>(dS, dWp, dseg, dso, dwork, work_cap, dcount, P.minw, dres, dbbits);
         k_cbs_pairtie<<<2048, 256, 0, st>>>(dwork, work_cap, dcount, dres, dbbits, dbij);
         k_cbs_pairfinal<<<(unsigned)((ns + 256) / 256), 256, 0, st>>>(ns, dbbits, dbij, dbest, dfirst);
@@ -1567,6 +1715,12 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       std::vector<SegOut> hso(ns);
       WCX_HIP(hipMemcpyAsync(hso.data(), dso, (size_t)ns * sizeof(SegOut), hipMemcpyDeviceToHost, st));
       WCX_HIP(hipStreamSynchronize(st));
+      lap("  stats");
+      if (copies_queued && !xw_waited) {    // (device path, first round: the host copy of the series)
+        WCX_HIP(hipEventSynchronize(ctx->ev_cbs_xw));
+        xw_waited = true;
+      }
+      lap("  host copy");
 
       // ---- decisions (DNAcopy wfindcpt, recalled) and the tests that need permutations
       std::vector<PermJob> jobs;
@@ -1627,6 +1781,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       }
       rc = run_jobs(jobs, seq);
       if (rc) return rc;
+      lap("  perms");
       std::vector<JobResult> seg_res(ns);
       for (int a = 0; a < ns; ++a)
         if (job_of[a] >= 0) { seg_res[a] = jres[(size_t)job_of[a]]; verdict[a] = seg_res[a].significant; }
@@ -1681,6 +1836,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
       }
       rc = run_jobs(ejobs, {});
       if (rc) return rc;
+      lap("  edges");
       std::vector<int> keep(ns * 2, 0), enrej(ns * 2, -2);
       for (const EdgeRef &er : eref) {
         bool ok;
@@ -1729,6 +1885,8 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
   if (rc) return rc;
   lap("rounds");
 
+  if (copies_queued) WCX_HIP(hipStreamSynchronize(aux));
+  const bool compact = d_r != nullptr && n_inf == 0;   // device path: r / w stayed in HBM
   // ---- CBS.R:84-129 on the host: NA-run splitting, >= 2-bin rule, weighted re-mean, 0-based start
   const int na_limit = (int)(1.0 / ((double)binsize / 2000000.0));   // as.integer((binsize/2e6)^-1)
   std::vector<int> count(n_samples, 0);
@@ -1740,6 +1898,40 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
     const int64_t o = (int64_t)s * n_bins + chr_off[c];
     const int *pos = hpos + se.lo;
     int prev = 0;
+    auto emit = [&](int a, int b, double num, double den) {
+      if (count[s] < cap) {
+        double *dst = out_seg + ((size_t)s * cap + count[s]) * 4;
+        dst[0] = c;
+        dst[1] = a - 1;                             // CBS.R:129
+        dst[2] = b;
+        dst[3] = den > 0 ? num / den : __builtin_nan("");
+      }
+      ++count[s];
+    };
+    if (compact) {
+      // The same statement on the compacted series (no +-inf in r: dropped == NA): the NA runs of a
+      // segment are the gaps between consecutive kept bins, a run of bins p_t + 1 .. p_u - 1 has
+      // start_pos = p_t, end_pos = p_u - 1; the weighted mean of an interval runs over its kept bins
+      // in order -- x | w | pos, which the host already holds, say everything r and w would.
+      const double *xs = hx + se.lo, *ws = hw + se.lo;
+      for (int e : se.change_loc) {
+        const int e1 = pos[e - 1];
+        int a = pos[prev], ia = prev;               // current interval: starts at bin a, first kept element ia
+        auto close = [&](int b, int ie) {           // interval [a, b], kept elements [ia, ie)
+          if (!(b - a > 0)) return;                 // CBS.R:103
+          double num = 0, den = 0;
+          for (int t = ia; t < ie; ++t) { num += xs[t] * ws[t]; den += ws[t]; }
+          emit(a, b, num, den);
+        };
+        for (int t = prev; t + 1 < e; ++t) {
+          const int sp = pos[t], ep = pos[t + 1] - 1;
+          if (ep - sp > na_limit) { close(sp, t + 1); a = ep; ia = t + 1; }
+        }
+        close(e1, e);
+        prev = e;
+      }
+      continue;
+    }
     for (int e : se.change_loc) {
       const int s1 = pos[prev], e1 = pos[e - 1];   // inclusive, 1-based
       prev = e;
@@ -1765,14 +1957,7 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
           const double wt = w[o + t - 1] == 0.0 ? 1.0 : w[o + t - 1];
           num += v * wt; den += wt;
         }
-        if (count[s] < cap) {
-          double *dst = out_seg + ((size_t)s * cap + count[s]) * 4;
-          dst[0] = c;
-          dst[1] = a - 1;                           // CBS.R:129
-          dst[2] = b;
-          dst[3] = den > 0 ? num / den : __builtin_nan("");
-        }
-        ++count[s];
+        emit(a, b, num, den);
       }
     }
   }
@@ -1787,13 +1972,24 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
   return WCX_OK;
 }
 
+extern "C" {
+
+int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples, int64_t n_bins,
+                  const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
+                  double *out_seg, int cap, int *out_count) {
+  return cbs_batch_impl(ctx, r, w, nullptr, nullptr, nullptr, n_samples, n_bins, chr_off, n_chr, alpha, binsize,
+                        seed, out_seg, cap, out_count);
+}
+
 int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_samples,
                       int64_t n_bins, const int64_t *chr_off, int n_chr, double alpha, int64_t binsize,
                       uint64_t seed, double *out_seg, int cap, int *out_count) {
   WCX_ARG(ctx && d_r && d_w && n_samples > 0 && n_bins > 0, "bad parameters");
   WCX_HIP(hipSetDevice(ctx->device));
-  // the series are assembled (NA-free compaction, CBS.R:41-63) and the segments post-processed
-  // (CBS.R:84-129) on the host: r and w come down once into pinned memory
+  // the series are assembled on the device (k_cbs_count / k_cbs_fill: NA-free compaction,
+  // CBS.R:41-63); the host still reads r and w -- the short-arc bound and the edge statistics of the
+  // decisions, the segments' post-processing (CBS.R:84-129) --, so they come down once into pinned
+  // memory, on the auxiliary stream, beside the first round's kernels
   const size_t bytes = (size_t)n_samples * n_bins * 8;
   if (ctx->host_scratch2_bytes < 2 * bytes) {
     if (ctx->host_scratch2) { WCX_HIP(hipStreamSynchronize(ctx->stream)); WCX_HIP(hipHostFree(ctx->host_scratch2)); }
@@ -1806,11 +2002,18 @@ int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_
     ctx->host_scratch2_bytes = 2 * bytes + bytes / 2;
   }
   double *hr = reinterpret_cast<double *>(ctx->host_scratch2), *hw = hr + (size_t)n_samples * n_bins;
-  WCX_HIP(hipMemcpyAsync(hr, d_r, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  WCX_HIP(hipMemcpyAsync(hw, d_w, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  WCX_HIP(hipStreamSynchronize(ctx->stream));
-  return wcx_cbs_batch(ctx, hr, hw, n_samples, n_bins, chr_off, n_chr, alpha, binsize, seed, out_seg, cap,
-                       out_count);
+  if (!ctx->copy_stream) {
+    WCX_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    WCX_HIP(hipEventCreateWithFlags(&ctx->ev_cbs_fill, hipEventDisableTiming));
+    WCX_HIP(hipEventCreateWithFlags(&ctx->ev_cbs_xw, hipEventDisableTiming));
+  }
+  hipStream_t aux = ctx->copy_stream;
+  const int rc = cbs_batch_impl(ctx, hr, hw, d_r, d_w, aux, n_samples, n_bins, chr_off, n_chr, alpha, binsize,
+                                seed, out_seg, cap, out_count);
+  // (an early error return may leave the copies in flight: the pinned buffer outlives them, but the
+  // next call must not start before they are done)
+  if (rc) hipStreamSynchronize(aux);
+  return rc;
 }
 
 int wcx_cbs_stats(wcx_ctx *ctx, int64_t out[4]) {

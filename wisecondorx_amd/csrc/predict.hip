@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NT) void k_normalize_pass(
     double med = 1.0;
     if (last_pass)
       med = wcx::wave_median_bucket<IPL>(v, keepmask, n, s_hist[threadIdx.x >> 6],
-                                         s_slots[threadIdx.x >> 6]);
+                                         s_slots[threadIdx.x >> 6], mean, sd);
     if (lane == 0) {
       const double xi = xs[i];
       const double z = (xi - mean) / sd;              // predict_tools.py:136
@@ -270,7 +270,8 @@ __global__ __launch_bounds__(NT) void k_normalize_pass_tile(
       double med = 1.0;                                 // (only the last pass's ratio is ever read)
       if (last_pass)
         med = wcx::wave_median_bucket<IPL>(vs, keepmask, n, s_hist[threadIdx.x >> 6],
-                                           s_slots[threadIdx.x >> 6]);
+                                           s_slots[threadIdx.x >> 6], mean,
+                                           (double)__builtin_sqrtf((float)qsum / (float)n));
       if (lane == s) { st_n = (double)n; st_mean = mean; st_q = qsum; st_med = med; }
     }
     if (lane < T && s0 + lane < n_samples) {

@@ -199,9 +199,12 @@ __device__ __forceinline__ double readlane_f64(double x, int src) {   // src wav
 // instead of ~12 quickselect rounds; falls back to quickselect for degenerate distributions.
 // hist: int[64], slots: double[64] of wave-private LDS.
 template <int IPL>
+__device__ __forceinline__ double wave_select_bucket_at(const double (&v)[IPL], unsigned int act,
+                                                        int rank, double lo, float scale, int *hist,
+                                                        double *slots);
+template <int IPL>
 __device__ __forceinline__ double wave_select_bucket(const double (&v)[IPL], unsigned int act,
                                                      int rank, int *hist, double *slots) {
-  const int lane = lane_id();
   double lo = HUGE_VAL, hi = -HUGE_VAL;
 #pragma unroll
   for (int q = 0; q < IPL; ++q)
@@ -212,6 +215,18 @@ __device__ __forceinline__ double wave_select_bucket(const double (&v)[IPL], uns
   if (range == 0.0) return lo;
   if (!(range > 0.0) || !(range < HUGE_VAL)) return wave_quickselect<IPL>(v, act, rank);
   const float scale = 64.0f / (float)range;
+  return wave_select_bucket_at<IPL>(v, act, rank, lo, scale, hist, slots);
+}
+
+// The same selection with the bucket grid GIVEN: bucket = clamp(int((v - lo) * scale), 0, 63).  Any
+// grid is exact (the bucket is monotone in v; a grid that fits the data badly only sends the call to
+// the quickselect fallback) -- a caller that already knows the set's mean and spread saves the two
+// wave-wide min / max reductions.
+template <int IPL>
+__device__ __forceinline__ double wave_select_bucket_at(const double (&v)[IPL], unsigned int act,
+                                                        int rank, double lo, float scale, int *hist,
+                                                        double *slots) {
+  const int lane = lane_id();
   hist[lane] = 0;
   __builtin_amdgcn_wave_barrier();
   int b[IPL];
@@ -260,11 +275,18 @@ __device__ __forceinline__ double wave_select_bucket(const double (&v)[IPL], uns
 }
 
 // np.median through wave_select_bucket (same contract as wave_median_select below).
+// centre / spread (optional; spread > 0): the set's mean and standard deviation if the caller has them
+// -- the bucket grid is then mean +- 3 spread (the median of ~250 values lies within 0.3 spread of
+// the mean; its bucket holds ~12 of them) and the min / max reductions are skipped.
 template <int IPL>
 __device__ __forceinline__ double wave_median_bucket(const double (&v)[IPL], unsigned int act,
-                                                     int n, int *hist, double *slots) {
+                                                     int n, int *hist, double *slots,
+                                                     double centre = 0.0, double spread = 0.0) {
   if (n <= 0) return __builtin_nan("");
-  const double a = wave_select_bucket<IPL>(v, act, (n - 1) >> 1, hist, slots);
+  const double a = spread > 0.0 && spread < HUGE_VAL
+                       ? wave_select_bucket_at<IPL>(v, act, (n - 1) >> 1, centre - 3.0 * spread,
+                                                    (float)(64.0 / 6.0) / (float)spread, hist, slots)
+                       : wave_select_bucket<IPL>(v, act, (n - 1) >> 1, hist, slots);
   if (n & 1) return a;
   int cle = 0;
   double mn = HUGE_VAL;

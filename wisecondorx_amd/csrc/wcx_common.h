@@ -68,6 +68,8 @@ struct wcx_ctx {
   hipStream_t sweep_stream = nullptr;        // second stream of the screen sweep (see wcx_topk_screen_launch)
   hipEvent_t ev_sweep0 = nullptr, ev_sweep1 = nullptr;
   hipEvent_t ev_after_sweep = nullptr;       // recorded by every search after its sweep (wcx_sweep_event)
+  hipStream_t copy_stream = nullptr;         // device -> host copies of wcx_cbs_batch_dev beside its kernels
+  hipEvent_t ev_cbs_fill = nullptr, ev_cbs_xw = nullptr;
   void *d_rank = nullptr;
   size_t rank_bytes = 0;
   const double *rank_X = nullptr;

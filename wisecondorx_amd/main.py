@@ -561,10 +561,9 @@ def _batch_worker(rank, world, args, pairs):
         for c0 in range(0, len(items), chunk):
             part = items[c0:c0 + chunk]
             samples = [it[2] for it in part]
-            xA = pt.prepare_batch_dev(tt(pt.sample_counts_matrix(samples, ref_file, "")), ref_file, "", ctx,
-                                      prep_cache)
-            xG = pt.prepare_batch_dev(tt(pt.sample_counts_matrix(samples, ref_file, ap)), ref_file, ap, ctx,
-                                      prep_cache)
+            dA, dG = pt.batch_counts_dev(samples, ref_file, ("", ap), dev, prep_cache)
+            xA = pt.prepare_batch_dev(dA, ref_file, "", ctx, prep_cache)
+            xG = pt.prepare_batch_dev(dG, ref_file, ap, ctx, prep_cache)
             rows, host = wd.predict_batch_dev(be, A, G, xA, xG, rem, pt, want_host=True)
             for i, (infile, outid, _, gender, n_reads) in enumerate(part):
                 results = {"results_nr": pt.ATTACHED, "results_c": rows[i]}
