@@ -358,6 +358,17 @@ int wcx_segment_z_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, 
                             const int64_t *chr_off, int n_chr, const double *seg,
                             const int *seg_count, double *out_z, double *out_nnull);
 
+/* ---- output tables (host code, no device work) --------------------------------
+ * The rows of ID_bins.bed for one chromosome (predict_output.py:51-75 of the reference):
+ *   "{chr}\t{start}\t{end}\t{chr}:{start}-{end}\t{ratio}\t{zscore}\n", start = i binsize + 1, end =
+ * (i + 1) binsize, a value of 0 printed as "nan", every other as Python's str(float) (shortest
+ * round-trip digits, exponent form below 1e-4 and from 1e16, ".0" on integers).  Returns the number of
+ * bytes written to out, or -1 if cap is too small (n * (2 strlen(chr) + 140) always suffices). */
+int64_t wcx_format_bins_bed(const char *chr_name, int64_t n, int64_t binsize, const double *r,
+                            const double *z, char *out, int64_t cap);
+/* str(float) of n doubles, each followed by `sep`; cap >= 26 n.  Returns the bytes written or -1. */
+int64_t wcx_format_floats(const double *v, int64_t n, char sep, char *out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -554,3 +554,41 @@ def test_sample_counts_matrix_threaded_and_in_place():
     buf = np.full((25, int(starts[-1])), -7, dtype=np.int32)
     got = pt.sample_counts_matrix(samples[:5], ref, "", out=buf)
     assert got.shape == (5, int(starts[-1])) and np.array_equal(got, want[:5])
+
+
+def test_native_float_format_is_pythons_repr():
+    """wcx_format_floats (the native writer of ID_bins.bed) == repr(float) on special values, random
+    doubles over 60 orders of magnitude and random bit patterns (host code: runs without a GPU)."""
+    import struct
+    from wisecondorx_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    vals = [0.1, 0.5, 1.0, -1.0, 1e-4, 1e-5, 9.999e-5, 1e15, 1e16, 1.5e16, 123456789.123, 1 / 3, -2 / 3, 5e-324,
+            1.7976931348623157e308, 2.5, 100.0, 1e22, 1e23, 0.30000000000000004, float("nan"), float("inf"),
+            float("-inf"), 1234567890123456.0, 12345678901234567.0, 0.001, 0.0001234, -0.0]
+    vals += list(rng.normal(0, 1, 20000)) + list(np.exp(rng.normal(0, 30, 20000)))
+    vals += [struct.unpack("d", struct.pack("Q", int(x)))[0] for x in rng.integers(0, 2 ** 63, 20000)]
+    a = np.array(vals, dtype=np.float64)
+    buf = np.empty(len(a) * 26, dtype=np.uint8)
+    m = L.wcx_format_floats(_lib.ptr(a), len(a), b"\n", _lib.ptr(buf), buf.size)
+    got = bytes(buf[:m]).decode().split("\n")[:-1]
+    assert got == [repr(float(x)) for x in a.tolist()]
+    assert L.wcx_format_floats(_lib.ptr(a), len(a), b"\n", _lib.ptr(buf), 10) == -1     # (capacity checked)
+
+
+def test_top_eigh_equals_the_full_solve():
+    """prep.top_eigh (LAPACK dsyevx for the 5 largest pairs) against numpy.linalg.eigh: eigenvalues to
+    1e-14 relative, eigenvectors to 1e-12 up to sign, also for S <= k and a rank-deficient Gram."""
+    from wisecondorx_amd import prep
+    rng = np.random.default_rng(4)
+    for S, B in ((3, 50), (12, 400), (60, 40), (200, 3000)):
+        A = rng.normal(size=(B, S)) * np.linspace(1, 20, S)
+        G = A.T @ A
+        w, v = prep.top_eigh(G, 5)
+        w0, v0 = np.linalg.eigh(G)
+        k = min(5, S)
+        w0, v0 = w0[::-1][:k], v0[:, ::-1][:, :k]
+        assert w.shape == (k,) and v.shape == (S, k)
+        np.testing.assert_allclose(w, w0, rtol=1e-13, atol=1e-13 * w0[0])
+        np.testing.assert_allclose(np.abs(v), np.abs(v0), atol=1e-11)
+        np.testing.assert_allclose(G @ v, v * w, atol=1e-11 * w0[0])

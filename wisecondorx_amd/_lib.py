@@ -21,6 +21,8 @@ vp = C.c_void_p
 # name -> (restype, argtypes): every symbol include/wcx.h declares.
 SIGNATURES = {
     "wcx_version": (C.c_int, []),
+    "wcx_format_bins_bed": (c_i64, [C.c_char_p, c_i64, c_i64, vp, vp, vp, c_i64]),
+    "wcx_format_floats": (c_i64, [vp, c_i64, C.c_char, vp, c_i64]),
     "wcx_debug_flags": (C.c_int, [vp, C.c_int]),
     "wcx_sweep_event": (C.c_int, [vp, C.POINTER(vp)]),
     "wcx_wait_event": (C.c_int, [vp, vp]),

@@ -276,16 +276,18 @@ __device__ __forceinline__ double wave_select_bucket_at(const double (&v)[IPL], 
 
 // np.median through wave_select_bucket (same contract as wave_median_select below).
 // centre / spread (optional; spread > 0): the set's mean and standard deviation if the caller has them
-// -- the bucket grid is then mean +- 3 spread (the median of ~250 values lies within 0.3 spread of
-// the mean; its bucket holds ~12 of them) and the min / max reductions are skipped.
+// -- the bucket grid is then mean +- 1 spread, everything beyond it in the two end buckets (the median
+// of n values lies within ~1.25 spread / sqrt(n) of the mean: 0.08 spread at n = 250, so its bucket is
+// an inner one, 1/32 spread wide, holding ~3 values instead of the ~9 of a min..max grid), and the
+// min / max reductions are skipped.  Any grid is exact; a bad one only costs time.
 template <int IPL>
 __device__ __forceinline__ double wave_median_bucket(const double (&v)[IPL], unsigned int act,
                                                      int n, int *hist, double *slots,
                                                      double centre = 0.0, double spread = 0.0) {
   if (n <= 0) return __builtin_nan("");
   const double a = spread > 0.0 && spread < HUGE_VAL
-                       ? wave_select_bucket_at<IPL>(v, act, (n - 1) >> 1, centre - 3.0 * spread,
-                                                    (float)(64.0 / 6.0) / (float)spread, hist, slots)
+                       ? wave_select_bucket_at<IPL>(v, act, (n - 1) >> 1, centre - spread,
+                                                    32.0f / (float)spread, hist, slots)
                        : wave_select_bucket<IPL>(v, act, (n - 1) >> 1, hist, slots);
   if (n & 1) return a;
   int cle = 0;
