@@ -303,9 +303,10 @@ int wcx_cbs_batch(wcx_ctx *ctx, const double *r, const double *w, int n_samples,
                   const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
                   double *out_seg, int cap, int *out_count);
 /* wcx_cbs_batch on DEVICE-resident r, w (wcx_post_process_merge_dev's outputs).  The NA-free series
- * (CBS.R:41-63) are compacted on the device; the host's share of the work -- the decisions between
- * the rounds, the segments' post-processing (CBS.R:84-129) -- reads the compacted x | w | bin
- * positions, exported into pinned memory beside the first round's kernels.  r and w themselves only
+ * (CBS.R:41-63) are compacted on the device and stay there: the host's decisions between the rounds
+ * fetch a series' x | w when one of its segments first needs them (a few per cent of the series), the
+ * segments' post-processing (CBS.R:84-129) reads the bin positions (exported into pinned memory beside
+ * the rounds' kernels) and takes its weighted means from a device kernel.  r and w themselves only
  * come down when they hold +-inf (dropped from the series, but not "NA" to CBS.R:84-113).  Same
  * results, bit for bit, as wcx_cbs_batch on host copies of r and w. */
 int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_samples,

@@ -1301,6 +1301,45 @@ __global__ __launch_bounds__(256) void k_cbs_fill(const double *__restrict__ r, 
   }
 }
 
+// x | w of the listed ranges -> the SAME offsets of the pinned host arrays (the host's decisions read a
+// series only once one of its segments is significant: ~5 % of them; exporting everything kept the
+// link busy for 5 ms beside the first round and slowed that round's kernels)
+struct RangeItem { int64_t lo; int32_t n, pad; };
+__global__ __launch_bounds__(256) void k_cbs_export_ranges(const double *__restrict__ x, const double *__restrict__ w,
+                                                           const RangeItem *__restrict__ items,
+                                                           double *__restrict__ hx, double *__restrict__ hw) {
+  const RangeItem it = items[blockIdx.x];
+  for (int i = threadIdx.x; i < it.n; i += 256) { hx[it.lo + i] = x[it.lo + i]; hw[it.lo + i] = w[it.lo + i]; }
+}
+
+// CBS.R:122-127 weighted.mean of the final intervals: num = sum x w, den = sum w over the interval's
+// kept bins IN ORDER (products and sums separately rounded, like the host loop it replaces: the file
+// is compiled with -ffp-contract=off).  One WAVE per interval: 64 elements are loaded coalesced, the
+// next 64 are in flight while the current ones are added one after the other out of the lanes
+// (readlane; every lane carries the same running sums).  (One THREAD per interval walked its 16 k
+// elements through 16 k dependent cache misses: 7 ms.)
+__global__ __launch_bounds__(256) void k_cbs_interval_means(const double *__restrict__ x, const double *__restrict__ w,
+                                                            const RangeItem *__restrict__ items, int n_items,
+                                                            double *__restrict__ out) {
+  const int q = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (q >= n_items) return;
+  const RangeItem it = items[q];
+  double num = 0.0, den = 0.0;
+  double xv = lane < it.n ? x[it.lo + lane] : 0.0, wv = lane < it.n ? w[it.lo + lane] : 0.0;
+  for (int base = 0; base < it.n; base += 64) {
+    const int nxt = base + 64 + lane;
+    const double xn = nxt < it.n ? x[it.lo + nxt] : 0.0, wn = nxt < it.n ? w[it.lo + nxt] : 0.0;
+    const double pr = xv * wv;
+    const int cnt = it.n - base < 64 ? it.n - base : 64;
+    for (int j = 0; j < cnt; ++j) {
+      num = num + wcx::readlane_f64(pr, j);
+      den = den + wcx::readlane_f64(wv, j);
+    }
+    xv = xn; wv = wn;
+  }
+  if (lane == 0) { out[2 * q] = num; out[2 * q + 1] = den; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1317,11 +1356,10 @@ int wcx_cbs_getbdry(double eta, int nperm, int max_ones, int32_t *out) {
 }  // extern "C"
 
 // r / w: the per-bin vectors on the host.  d_r / d_w != NULL (wcx_cbs_batch_dev): the vectors are in
-// HBM and r / w are PINNED host buffers still to be filled.  The series are then compacted on the
-// device (no upload); what the host reads comes down on the auxiliary stream `aux` beside the first
-// round's kernels, in the order it is needed: the compacted x | w (the decisions after the first round
-// of statistics: short-arc bound, edge statistics), then r and w themselves (bin positions and the
-// segments' post-processing, CBS.R:84-129, after the last round).
+// HBM and r / w are PINNED host buffers, filled only if the data hold +-inf.  The series are then
+// compacted on the device (no upload) and stay there; the host fetches a series' x | w when a decision
+// first needs them (ensure_resident), the bin positions come down on the stream `aux` beside the
+// rounds' kernels, and the wrap-up (CBS.R:84-129) takes its weighted means from a device kernel.
 static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const double *d_r, const double *d_w,
                           hipStream_t aux, int n_samples, int64_t n_bins,
                           const int64_t *chr_off, int n_chr, double alpha, int64_t binsize, uint64_t seed,
@@ -1371,7 +1409,7 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
   for (int c = 0; c <= n_chr; ++c) co.off[c] = chr_off[c];
   int64_t *d_lo = nullptr;
   int n_inf = 0;            // device path: +-inf values in r (then the host needs r / w themselves)
-  bool copies_queued = false, xw_waited = false;
+  bool copies_queued = false;
   if (d_r) {
     void *scr2 = nullptr;
     const size_t nsc = cnt_sc.size();
@@ -1438,6 +1476,7 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
       series.push_back(std::move(se));
     }
   const int64_t N = total;
+  const double *dXs_all = nullptr, *dWs_all = nullptr;    // the compacted series in HBM (for the wrap-up)
   lap("series");
   int rc = wcx_timer_begin(ctx, "cbs");
   if (rc) return rc;
@@ -1454,7 +1493,7 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
     const unsigned int work_cap = 1u << 22;                  // block pairs evaluated per round at most
     const size_t qtab_floats = (size_t)(KMAXC - 1) * ((size_t)N + (size_t)NTP * max_segs) +
                                (size_t)max_segs * (KMAXC + 1) * QC_W;
-    const size_t need = (size_t)N * (8 * 5 + 4 * 3) + 4096 + (size_t)max_segs * (sizeof(SegIn) + sizeof(SegOut) + 8) +
+    const size_t need = (size_t)N * (8 * 5 + 4 * 3) + 4096 + (series.size() + 8) * sizeof(RangeItem) + (size_t)max_segs * (sizeof(SegIn) + sizeof(SegOut) + 8) +
                         (size_t)max_segs * P.ngrid * 16 + max_items * (sizeof(ArcItem) + sizeof(ArcBest)) +
                         (size_t)max_jobs * (2 * sizeof(PermJob) + (size_t)(nw + NCH) * 4) +
                         (any_big ? (size_t)BIG_GRID * (npad_max + 64) * 4 : 0) +
@@ -1468,7 +1507,9 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
     A.base = reinterpret_cast<char *>(scr);
     double *dX = A.take<double>(N), *dW = A.take<double>(N), *dS = A.take<double>(N), *dWp = A.take<double>(N);
     double *dYd = A.take<double>(N);
+    dXs_all = dX; dWs_all = dW;
     int *dpos = A.take<int>((size_t)N + 4);
+    RangeItem *drng = A.take<RangeItem>(series.size() + 8);
     float *dy = A.take<float>(N), *drw = A.take<float>(N);
     SegIn *dseg = A.take<SegIn>(max_segs);
     SegOut *dso = A.take<SegOut>(max_segs);
@@ -1498,16 +1539,12 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
       k_cbs_fill<<<dim3((unsigned)n_chr, (unsigned)n_samples), 256, 0, st>>>(d_r, d_w, n_bins, co, n_chr, d_lo,
                                                                             dX, dW, dpos);
       WCX_HIP(hipGetLastError());
-      // what the host reads, in the order it needs it, on the copy stream beside this round's
-      // kernels: x | w (decisions after the first statistics), then the bin positions (wrap-up)
+      // the bin positions (wrap-up) come down on the copy stream beside the rounds' kernels
       WCX_HIP(hipEventRecord(ctx->ev_cbs_fill, st));
       WCX_HIP(hipStreamWaitEvent(aux, ctx->ev_cbs_fill, 0));
-      const int64_t n16 = ((int64_t)N * 8 + 15) / 16;      // (arena slots and the staging area are padded)
-      k_cbs_export<<<64, 256, 0, aux>>>(reinterpret_cast<const uint4 *>(dX), reinterpret_cast<uint4 *>(hx), n16);
-      k_cbs_export<<<64, 256, 0, aux>>>(reinterpret_cast<const uint4 *>(dW), reinterpret_cast<uint4 *>(hw), n16);
-      WCX_HIP(hipGetLastError());
-      WCX_HIP(hipEventRecord(ctx->ev_cbs_xw, aux));
-      k_cbs_export<<<64, 256, 0, aux>>>(reinterpret_cast<const uint4 *>(dpos), reinterpret_cast<uint4 *>(hpos),
+      // (x | w follow per series, on demand: ensure_resident below; arena slots and the staging area
+      //  are padded to whole 16-byte words)
+      k_cbs_export<<<16, 256, 0, aux>>>(reinterpret_cast<const uint4 *>(dpos), reinterpret_cast<uint4 *>(hpos),
                                         ((int64_t)N * 4 + 15) / 16);
       WCX_HIP(hipGetLastError());
       if (n_inf > 0) {
@@ -1624,6 +1661,25 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
       return WCX_OK;
     };
 
+    // device path: the host copy of a series (hx / hw at its own offsets) is made when a decision first
+    // needs it -- a segment that passed the p-value filters (short-arc bound) or is significant (edge
+    // statistics); the stream is idle at those points, the export costs one small launch + sync
+    std::vector<char> resident(series.size(), d_r ? 0 : 1);
+    auto ensure_resident = [&](const std::vector<int> &want) -> int {
+      std::vector<RangeItem> items;
+      for (int q : want)
+        if (!resident[(size_t)q]) {
+          resident[(size_t)q] = 1;
+          items.push_back({series[(size_t)q].lo, series[(size_t)q].n, 0});
+        }
+      if (items.empty()) return WCX_OK;
+      WCX_HIP(hipMemcpyAsync(drng, items.data(), items.size() * sizeof(RangeItem), hipMemcpyHostToDevice, st));
+      k_cbs_export_ranges<<<(unsigned)items.size(), 256, 0, st>>>(dX, dW, drng, hx, hw);
+      WCX_HIP(hipGetLastError());
+      WCX_HIP(hipStreamSynchronize(st));
+      return WCX_OK;
+    };
+
     // ---- level-synchronous recursion (DNAcopy changepoints(): stack of segment ends per series)
     struct Active { int series, lo, hi; };
     for (;;) {
@@ -1716,9 +1772,19 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
       WCX_HIP(hipMemcpyAsync(hso.data(), dso, (size_t)ns * sizeof(SegOut), hipMemcpyDeviceToHost, st));
       WCX_HIP(hipStreamSynchronize(st));
       lap("  stats");
-      if (copies_queued && !xw_waited) {    // (device path, first round: the host copy of the series)
-        WCX_HIP(hipEventSynchronize(ctx->ev_cbs_xw));
-        xw_waited = true;
+      if (d_r) {      // (device path: the series whose short-arc bound the loop below will ask for)
+        std::vector<int> want;
+        for (int a = 0; a < ns; ++a) {
+          const SegOut &o = hso[a];
+          if (!hseg[a].hybrid || !o.valid || o.range <= 1.4901161193847656e-08) continue;
+          const double ostat1 = sqrt(o.ostat);
+          const int arc = std::min(o.bj - o.bi, hseg[a].n - o.bj + o.bi);
+          if (ostat1 <= 0.1 || (!strict && ostat1 >= 7.0 && arc >= 10)) continue;
+          if (o.pval1 < 0.0 || o.pval1 > P.alpha) continue;
+          want.push_back(act[a].series);
+        }
+        rc = ensure_resident(want);
+        if (rc) return rc;
       }
       lap("  host copy");
 
@@ -1791,6 +1857,13 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
       std::vector<PermJob> ejobs;
       struct EdgeRef { int a, which, shortcut; };
       std::vector<EdgeRef> eref;
+      if (d_r) {      // (device path: the series of the significant segments with an interior arc)
+        std::vector<int> want;
+        for (int a = 0; a < ns; ++a)
+          if (verdict[a] && hso[a].bi != 0 && hso[a].bj != hseg[a].n) want.push_back(act[a].series);
+        rc = ensure_resident(want);
+        if (rc) return rc;
+      }
       for (int a = 0; a < ns; ++a) {
         if (!verdict[a]) continue;
         const int n = hseg[a].n, bi = hso[a].bi, bj = hso[a].bj;
@@ -1890,6 +1963,66 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
   // ---- CBS.R:84-129 on the host: NA-run splitting, >= 2-bin rule, weighted re-mean, 0-based start
   const int na_limit = (int)(1.0 / ((double)binsize / 2000000.0));   // as.integer((binsize/2e6)^-1)
   std::vector<int> count(n_samples, 0);
+  auto emit_seg = [&](int s, int c, int a, int b, double num, double den) {
+    if (count[s] < cap) {
+      double *dst = out_seg + ((size_t)s * cap + count[s]) * 4;
+      dst[0] = c;
+      dst[1] = a - 1;                               // CBS.R:129
+      dst[2] = b;
+      dst[3] = den > 0 ? num / den : __builtin_nan("");
+    }
+    ++count[s];
+  };
+  if (compact) {
+    // The same statement on the compacted series (no +-inf in r: dropped == NA): the NA runs of a
+    // segment are the gaps between consecutive kept bins, a run of bins p_t + 1 .. p_u - 1 has
+    // start_pos = p_t, end_pos = p_u - 1; the intervals come from the positions alone (host threads),
+    // their weighted means -- sums over the interval's kept bins in order -- from x | w where they
+    // are: in HBM (k_cbs_interval_means), so that x and w never cross the link as a whole.
+    struct Iv { int c, a, b, n; int64_t lo; };
+    std::vector<std::vector<Iv>> ivs((size_t)n_samples);
+    for_samples([&](int my_sample) {
+      for (Series &se : series) {
+        if (se.sample != my_sample) continue;
+        std::sort(se.change_loc.begin(), se.change_loc.end());
+        const int *pos = hpos + se.lo;
+        int prev = 0;
+        for (int e : se.change_loc) {
+          const int e1 = pos[e - 1];
+          int a = pos[prev], ia = prev;             // current interval: starts at bin a, first kept element ia
+          auto close = [&](int b, int ie) {         // interval [a, b], kept elements [ia, ie)
+            if (!(b - a > 0)) return;               // CBS.R:103
+            ivs[(size_t)my_sample].push_back({se.chr, a, b, ie - ia, se.lo + ia});
+          };
+          for (int t = prev; t + 1 < e; ++t) {
+            const int sp = pos[t], ep = pos[t + 1] - 1;
+            if (ep - sp > na_limit) { close(sp, t + 1); a = ep; ia = t + 1; }
+          }
+          close(e1, e);
+          prev = e;
+        }
+      }
+    });
+    std::vector<RangeItem> items;
+    for (const auto &v : ivs) for (const Iv &iv : v) items.push_back({iv.lo, iv.n, 0});
+    std::vector<double> sums(items.size() * 2);
+    if (!items.empty()) {
+      void *scr2 = nullptr;
+      rc = wcx_scratch2(ctx, items.size() * (sizeof(RangeItem) + 16) + 64, &scr2);
+      if (rc) return rc;
+      RangeItem *d_items = reinterpret_cast<RangeItem *>(scr2);
+      double *d_sums = reinterpret_cast<double *>(d_items + items.size());
+      WCX_HIP(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(RangeItem), hipMemcpyHostToDevice, st));
+      k_cbs_interval_means<<<(unsigned)((items.size() + 3) / 4), 256, 0, st>>>(dXs_all, dWs_all, d_items,
+                                                                              (int)items.size(), d_sums);
+      WCX_HIP(hipGetLastError());
+      WCX_HIP(hipMemcpyAsync(sums.data(), d_sums, sums.size() * 8, hipMemcpyDeviceToHost, st));
+      WCX_HIP(hipStreamSynchronize(st));
+    }
+    size_t q = 0;
+    for (int s = 0; s < n_samples; ++s)
+      for (const Iv &iv : ivs[(size_t)s]) { emit_seg(s, iv.c, iv.a, iv.b, sums[2 * q], sums[2 * q + 1]); ++q; }
+  } else {
   for_samples([&](int my_sample) {
   for (Series &se : series) {
     if (se.sample != my_sample) continue;
@@ -1898,40 +2031,7 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
     const int64_t o = (int64_t)s * n_bins + chr_off[c];
     const int *pos = hpos + se.lo;
     int prev = 0;
-    auto emit = [&](int a, int b, double num, double den) {
-      if (count[s] < cap) {
-        double *dst = out_seg + ((size_t)s * cap + count[s]) * 4;
-        dst[0] = c;
-        dst[1] = a - 1;                             // CBS.R:129
-        dst[2] = b;
-        dst[3] = den > 0 ? num / den : __builtin_nan("");
-      }
-      ++count[s];
-    };
-    if (compact) {
-      // The same statement on the compacted series (no +-inf in r: dropped == NA): the NA runs of a
-      // segment are the gaps between consecutive kept bins, a run of bins p_t + 1 .. p_u - 1 has
-      // start_pos = p_t, end_pos = p_u - 1; the weighted mean of an interval runs over its kept bins
-      // in order -- x | w | pos, which the host already holds, say everything r and w would.
-      const double *xs = hx + se.lo, *ws = hw + se.lo;
-      for (int e : se.change_loc) {
-        const int e1 = pos[e - 1];
-        int a = pos[prev], ia = prev;               // current interval: starts at bin a, first kept element ia
-        auto close = [&](int b, int ie) {           // interval [a, b], kept elements [ia, ie)
-          if (!(b - a > 0)) return;                 // CBS.R:103
-          double num = 0, den = 0;
-          for (int t = ia; t < ie; ++t) { num += xs[t] * ws[t]; den += ws[t]; }
-          emit(a, b, num, den);
-        };
-        for (int t = prev; t + 1 < e; ++t) {
-          const int sp = pos[t], ep = pos[t + 1] - 1;
-          if (ep - sp > na_limit) { close(sp, t + 1); a = ep; ia = t + 1; }
-        }
-        close(e1, e);
-        prev = e;
-      }
-      continue;
-    }
+    auto emit = [&](int a, int b, double num, double den) { emit_seg(s, c, a, b, num, den); };
     for (int e : se.change_loc) {
       const int s1 = pos[prev], e1 = pos[e - 1];   // inclusive, 1-based
       prev = e;
@@ -1962,6 +2062,7 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
     }
   }
   });
+  }
   lap("wrap-up");
   int over = 0;
   for (int s = 0; s < n_samples; ++s) { out_count[s] = count[s]; over = std::max(over, count[s]); }
@@ -1986,10 +2087,7 @@ int wcx_cbs_batch_dev(wcx_ctx *ctx, const double *d_r, const double *d_w, int n_
                       uint64_t seed, double *out_seg, int cap, int *out_count) {
   WCX_ARG(ctx && d_r && d_w && n_samples > 0 && n_bins > 0, "bad parameters");
   WCX_HIP(hipSetDevice(ctx->device));
-  // the series are assembled on the device (k_cbs_count / k_cbs_fill: NA-free compaction,
-  // CBS.R:41-63); the host still reads r and w -- the short-arc bound and the edge statistics of the
-  // decisions, the segments' post-processing (CBS.R:84-129) --, so they come down once into pinned
-  // memory, on the auxiliary stream, beside the first round's kernels
+  // (pinned destination of r | w for the rare +-inf fallback; see cbs_batch_impl)
   const size_t bytes = (size_t)n_samples * n_bins * 8;
   if (ctx->host_scratch2_bytes < 2 * bytes) {
     if (ctx->host_scratch2) { WCX_HIP(hipStreamSynchronize(ctx->stream)); WCX_HIP(hipHostFree(ctx->host_scratch2)); }
