@@ -228,3 +228,47 @@ def test_cbs_batch_dev_equals_the_host_api(pt, with_inf):
     again = device()                                          # (staging buffers reused)
     for a, b in zip(want, again):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_cbs_block_bound_search_equals_the_plain_search(pt):
+    """The best arc of every segment comes from the block-bound search (k_cbs_blockstats / coarse /
+    prune / pairmax: only block pairs whose bound reaches a lower bound of the maximum are evaluated)
+    once a call holds more than 4e9 arcs, from the plain striped search (k_cbs_arcmax) below that.
+    Six samples with 15 kb-sized chromosomes in ONE call (pruned) == the same samples one call each
+    (plain): identical segments and means -- the permutation keys do not depend on the batch."""
+    from wisecondorx_amd import _lib
+    rng = np.random.default_rng(21)
+    n_per_chr = [16600, 16100, 13200, 12700, 12100, 11400, 10600, 9700, 9200, 8900, 9000, 8900, 7600, 7100,
+                 6800, 6000, 5500, 5400, 3900, 4300, 3100, 3400, 10400]
+    ns = 6
+    off = np.concatenate(([0], np.cumsum(n_per_chr))).astype(np.int64)
+    n_bins = int(off[-1])
+    r = rng.normal(0, 0.06, (ns, n_bins))
+    w = rng.uniform(0.5, 2.0, (ns, n_bins))
+    for s in range(ns):
+        for _ in range(3):
+            c = int(rng.integers(0, 23)); a = int(off[c] + rng.integers(0, n_per_chr[c] - 400))
+            r[s, a:a + int(rng.integers(20, 400))] += rng.choice([-0.3, 0.25, 0.5])
+        for _ in range(20):
+            a = int(rng.integers(0, n_bins)); r[s, a:a + int(rng.integers(1, 40))] = 0
+    ctx = _lib.default_context()
+    off_a, off_p = _lib.i64_array(off)
+    cap = 1024
+    listed0 = ctx.cbs_stats()["arc_pairs_listed"]
+
+    def run(rows):
+        seg = np.empty((len(rows), cap, 4)); cnt = np.zeros(len(rows), dtype=np.int32)
+        rr = np.ascontiguousarray(r[rows]); ww = np.ascontiguousarray(w[rows])
+        _lib.check(ctx.lib.wcx_cbs_batch(ctx.h, _lib.ptr(rr), _lib.ptr(ww), len(rows), n_bins, off_p, 23, 1e-4,
+                                         15000, 5, _lib.ptr(seg), cap, _lib.ptr(cnt)))
+        return [seg[i, :cnt[i]].copy() for i in range(len(rows))]
+
+    batch = run(list(range(ns)))
+    listed1 = ctx.cbs_stats()["arc_pairs_listed"]
+    assert listed1 > listed0                                      # (the block-bound search ran)
+    assert sum(len(x) for x in batch) > ns * 23
+    for s in range(ns):
+        single = run([s])[0]
+        assert single.shape == batch[s].shape
+        assert np.array_equal(single, batch[s], equal_nan=True)
+    assert ctx.cbs_stats()["arc_pairs_listed"] == listed1         # (... and not in the one-sample calls)
