@@ -592,3 +592,55 @@ def test_top_eigh_equals_the_full_solve():
         np.testing.assert_allclose(w, w0, rtol=1e-13, atol=1e-13 * w0[0])
         np.testing.assert_allclose(np.abs(v), np.abs(v0), atol=1e-11)
         np.testing.assert_allclose(G @ v, v * w, atol=1e-11 * w0[0])
+
+
+def test_reference_npz_deferred_members(tmp_path):
+    """load_reference(defer=(".F", ".M")): the big members of the deferred suffixes are planned, not read
+    (a predict needs ONE gonosomal set); ensure_loaded reads a set later -- same arrays, same CRC check."""
+    from wisecondorx_amd import npz_io
+    rng = np.random.default_rng(1)
+    arrs = {"binsize": np.array(15000), "mask.F": rng.random(1000) < 0.5}
+    for sfx in ("", ".F", ".M"):
+        arrs["indexes" + sfx] = rng.integers(0, 1000, (30000, 100)).astype(np.int32)
+        arrs["distances" + sfx] = rng.random((30000, 100))
+    path = npz_io.save_npz(str(tmp_path / "ref.npz"), arrs)
+    ref = npz_io.load_reference(path, defer=(".F", ".M"))
+    assert sorted(ref.deferred) == ["distances.F", "distances.M", "indexes.F", "indexes.M"]
+    assert "indexes.F" not in ref and np.array_equal(ref["indexes"], arrs["indexes"])
+    assert np.array_equal(ref["mask.F"], arrs["mask.F"])                 # (small members are never deferred)
+    npz_io.ensure_loaded(ref, ".F")
+    assert sorted(ref.deferred) == ["distances.M", "indexes.M"]
+    assert np.array_equal(ref["indexes.F"], arrs["indexes.F"]) and np.array_equal(ref["distances.F"], arrs["distances.F"])
+    npz_io.ensure_loaded(ref, ".F")                                      # (idempotent)
+    everything = npz_io.load_reference(path, defer=("",))
+    assert len(everything.deferred) == 6 and int(everything["binsize"]) == 15000
+    # a corrupted deferred member is caught when it is read
+    with zipfile_member_offset(path, "distances.M.npy") as off:
+        with open(path, "r+b") as fh:
+            fh.seek(off + 4096)
+            c = fh.read(1)
+            fh.seek(off + 4096)
+            fh.write(bytes([c[0] ^ 1]))
+    ref2 = npz_io.load_reference(path, defer=(".M",))                    # (the other members are intact)
+    with pytest.raises(IOError, match="CRC-32 mismatch"):
+        npz_io.ensure_loaded(ref2, ".M")
+
+
+class zipfile_member_offset:
+    """Context manager: offset of the data of a stored member inside the archive."""
+
+    def __init__(self, path, name):
+        import struct
+        import zipfile
+        with zipfile.ZipFile(path) as zf, open(path, "rb") as fh:
+            info = zf.getinfo(name)
+            fh.seek(info.header_offset)
+            lh = fh.read(30)
+            nlen, elen = struct.unpack("<HH", lh[26:30])
+            self.off = info.header_offset + 30 + nlen + elen
+
+    def __enter__(self):
+        return self.off
+
+    def __exit__(self, *a):
+        return False

@@ -374,7 +374,7 @@ def _newref_body(args, contexts, rd):
 
 # --------------------------------------------------------------------------- gender / predict
 def output_gender(args):
-    ref_file = npz_io.load_reference(args.reference)
+    ref_file = npz_io.load_reference(args.reference, defer=("",))       # (only the small members are read)
     sample, _ = npz_io.load_sample(args.infile)
     print("male" if predict_gender(sample, ref_file["trained_cutoff"]) == "M" else "female")
 
@@ -435,7 +435,8 @@ def tool_test(args):
         return tool_test_batch(args, pairs)
 
     logging.info("Importing data ...")
-    ref_file = npz_io.load_reference(args.reference)
+    # (the gonosomal tables -- a third of the file each -- are read once the sample's gender says which)
+    ref_file = npz_io.load_reference(args.reference, defer=(".F", ".M"))
     sample, sample_binsize = npz_io.load_sample(args.infile)
     n_reads = sum([sum(sample[x]) for x in sample.keys()])
     sample = scale_sample(sample, int(sample_binsize), int(ref_file["binsize"]))
@@ -451,6 +452,19 @@ def tool_test(args):
             gender = args.gender
         ref_gender = "F"
 
+    # the gonosomal set this sample will use (the rules below, decided early): its tables are read on a
+    # worker thread beside the autosomal normalisation
+    early = ref_gender
+    if not ref_file["is_nipt"]:
+        if not ref_file["has_male"] and gender == "M":
+            early = "F"
+        elif not ref_file["has_female"] and gender == "F":
+            early = "M"
+    from concurrent.futures import ThreadPoolExecutor
+    gon_loader = ThreadPoolExecutor(max_workers=1)
+    gon_loaded = gon_loader.submit(npz_io.ensure_loaded, ref_file, ".{}".format(early))
+    gon_loader.shutdown(wait=False)
+
     cache = {}
     logging.info("Normalizing autosomes ...")
     res_a = pt.normalize(args, sample, ref_file, "A", cache)
@@ -465,6 +479,7 @@ def tool_test(args):
             ref_gender = "M"
     logging.info("Normalizing gonosomes ...")
     ap = ".{}".format(ref_gender)
+    gon_loaded.result()
     nr_aut = ref_file["null_ratios"]
     nr_gon = ref_file["null_ratios" + ap][len(nr_aut):]
     res_g = pt.normalize(args, sample, ref_file, ref_gender, cache)
@@ -530,7 +545,7 @@ def _batch_worker(rank, world, args, pairs):
     mine = wd.stripe(pairs, rank, world)
     if not mine:
         return
-    ref_file = npz_io.load_reference(args.reference)
+    ref_file = npz_io.load_reference(args.reference, defer=(".F", ".M"))
     binsize = int(ref_file["binsize"])
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
     A = {"idx": tt(ref_file["indexes"]), "dist": tt(ref_file["distances"]), "nr": tt(ref_file["null_ratios"]),
@@ -558,6 +573,7 @@ def _batch_worker(rank, world, args, pairs):
     chunk = max(1, int(getattr(args, "batch_size", 96) or 96))
     for ref_gender, items in groups.items():
         ap = ".{}".format(ref_gender)
+        npz_io.ensure_loaded(ref_file, ap)
         _check_mask_alignment(ref_file, ap)
         G = {"idx": tt(ref_file["indexes" + ap]), "dist": tt(ref_file["distances" + ap]),
              "nr": tt(ref_file["null_ratios" + ap]),

@@ -375,11 +375,62 @@ def crc32_combine_py(crc1, crc2, len2):
     return crc1 ^ crc2
 
 
-def load_reference(path):
+class Reference(dict):
+    """The members of a reference .npz.  `deferred`: big members not read yet (load_reference(defer=...)),
+    key -> read plan; ensure_loaded() brings a suffix's members in."""
+    path = None
+    check_crc = True
+
+    def __init__(self, *a, **k):
+        dict.__init__(self, *a, **k)
+        self.deferred = {}
+
+
+def _read_members(path, plans, check_crc, out):
+    """plans: [(key, arr, data offset, CRC of the header bytes, CRC of the directory)] -> out[key] = arr,
+    read by worker threads, CRC-32 checked."""
+    with ThreadPoolExecutor(max_workers=_THREADS) as ex:
+        pending = []
+        for key, arr, off, head_crc, want in plans:
+            view = _raw_view(arr)
+            futs = [(b - a, ex.submit(_read_into, path, off + a, view[a:b], check_crc))
+                    for a, b in _crc_chunks(view, _THREADS)]
+            pending.append((key, futs, head_crc, want))
+            out[key] = arr
+        yield                                   # (the caller's own reading runs beside the workers)
+        for key, futs, crc, want in pending:
+            for n, f in futs:
+                c = f.result()
+                if check_crc:
+                    crc = crc32_combine(crc, c, n)
+            if check_crc and crc != want:
+                raise IOError("{}: CRC-32 mismatch in member {}.npy (corrupted file)".format(path, key))
+
+
+def ensure_loaded(ref, suffix):
+    """Read the deferred big members of `ref` whose key ends with `suffix` ("" = all of them)."""
+    deferred = getattr(ref, "deferred", None)
+    if not deferred:
+        return ref
+    keys = [k for k in deferred if k.endswith(suffix)]
+    plans = []
+    for k in keys:
+        shape, dtype, fortran, off, head_crc, want = deferred.pop(k)
+        plans.append((k, np.empty(shape, dtype=dtype, order="F" if fortran else "C"), off, head_crc, want))
+    for _ in _read_members(ref.path, plans, ref.check_crc, ref):
+        pass
+    return ref
+
+
+def load_reference(path, defer=()):
     """All members of a reference .npz as a dict.  Stored (uncompressed) numeric members are read
     straight into their arrays by worker threads (sizes checked against the file, CRC-32 against
-    the directory); the rest (small deflated or pickled members) goes through np.load."""
-    out, direct = {}, []
+    the directory); the rest (small deflated or pickled members) goes through np.load.
+    defer: key suffixes (".F", ".M"; "" = every one) whose BIG members are only planned, not read --
+    a predict uses the autosomal tables and ONE gonosomal set, a third of the 2.5 GB at 15 kb is never
+    needed (ensure_loaded(ref, suffix) reads a set; indexing a deferred key raises KeyError)."""
+    out, direct = Reference(), []
+    out.path = path
     check_crc = os.environ.get("WCX_NPZ_NO_CRC", "") in ("", "0")
     fsize = os.path.getsize(path)
     with zipfile.ZipFile(path) as zf, open(path, "rb") as fh:
@@ -403,31 +454,26 @@ def load_reference(path):
                 continue
             if dtype.hasobject:
                 continue
-            arr = np.empty(shape, dtype=dtype, order="F" if fortran else "C")
+            nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
             head_len = fh.tell() - data_off
-            if head_len + arr.nbytes != info.file_size or data_off + info.file_size > fsize:
+            if head_len + nbytes != info.file_size or data_off + info.file_size > fsize:
                 raise IOError("{}: member {} is truncated or its sizes disagree ({} + {} bytes announced, "
-                              "{} stored, file of {} bytes)".format(path, info.filename, head_len, arr.nbytes,
+                              "{} stored, file of {} bytes)".format(path, info.filename, head_len, nbytes,
                                                                     info.file_size, fsize))
             fh.seek(data_off)
-            direct.append((key, arr, data_off + head_len, zlib.crc32(fh.read(head_len)), info.CRC))
-    with ThreadPoolExecutor(max_workers=_THREADS) as ex:
-        pending = []
-        for key, arr, off, head_crc, want in direct:
-            view = _raw_view(arr)
-            futs = [(b - a, ex.submit(_read_into, path, off + a, view[a:b], check_crc))
-                    for a, b in _crc_chunks(view, _THREADS)]
-            pending.append((key, futs, head_crc, want))
-            out[key] = arr
-        with np.load(path, encoding="latin1", allow_pickle=True) as npz:
-            for k in npz.files:
-                if k not in out:
-                    out[k] = npz[k]
-        for key, futs, crc, want in pending:
-            for n, f in futs:
-                c = f.result()
-                if check_crc:
-                    crc = crc32_combine(crc, c, n)
-            if check_crc and crc != want:
-                raise IOError("{}: CRC-32 mismatch in member {}.npy (corrupted file)".format(path, key))
+            head_crc = zlib.crc32(fh.read(head_len))
+            if any(key.endswith(sfx) for sfx in defer):
+                out.deferred[key] = (shape, dtype, fortran, data_off + head_len, head_crc, info.CRC)
+                continue
+            arr = np.empty(shape, dtype=dtype, order="F" if fortran else "C")
+            direct.append((key, arr, data_off + head_len, head_crc, info.CRC))
+    out.check_crc = check_crc
+    reader = _read_members(path, direct, check_crc, out)
+    next(reader)                                # workers started
+    with np.load(path, encoding="latin1", allow_pickle=True) as npz:
+        for k in npz.files:
+            if k not in out and k not in out.deferred:
+                out[k] = npz[k]
+    for _ in reader:                            # join + CRC
+        pass
     return out
