@@ -296,19 +296,38 @@ def _newref_body(args, contexts, rd):
     writer = npz_io.NpzWriter(args.outfile) if rank == 0 else None
     written = set()
 
-    def stream_out():
+    # The three tables of a pass (0.8 GB at 15 kb) are not kept until the end: once a pass's members are
+    # with the writer and its QC metrics taken (ref_qc.compute_metrics, on a worker thread), this dict
+    # lets go of them -- the writer frees them on its threads when they are on disk, beside the next
+    # pass's device work, instead of 2.5 GB being unmapped when the build returns.
+    will_f = genders.count("F") > 4
+    will_m = (not args.nipt) and genders.count("M") > 4
+    qc_metrics, qc_jobs = {}, []
+    from concurrent.futures import ThreadPoolExecutor as _Pool
+    qc_pool = _Pool(max_workers=1)
+
+    def stream_out(suf=None):
         if writer is not None:
-            for k_, v_ in final_ref.items():
+            for k_, v_ in list(final_ref.items()):
                 if k_ not in written and k_ not in ("has_female", "has_male"):
                     writer.add(k_, v_)
                     written.add(k_)
             writer.flush_async()
+            if suf is not None:
+                def take_metrics_and_release():
+                    from .ref_qc import compute_metrics
+                    if suf != "" or not (will_f or will_m):      # (ref_qc.py:11-20: the autosomal set only
+                        qc_metrics[suf] = compute_metrics(final_ref, suf)   #  gets a verdict on its own)
+                    for name in ("indexes", "distances", "null_ratios"):
+                        final_ref.pop(name + suf, None)
+                qc_jobs.append(qc_pool.submit(take_metrics_and_release))
     try:
         if len(genders) > 9:
             logging.info("Starting autosomal reference creation ...")
             sub = build_sub_reference(args, samples, "A", total_mask, bins_per_chr, contexts, dc, sel_of["A"], rd)
             final_ref.update({k: v for k, v in sub.items() if k != "gender"})
-            stream_out()
+            del sub
+            stream_out("")
         else:
             logging.critical("Provide at least 10 samples to enable the generation of a reference.")
             sys.exit()
@@ -318,7 +337,8 @@ def _newref_body(args, contexts, rd):
                                       sel_of["F"], rd)
             final_ref["has_female"] = True
             final_ref.update({k + ".F": v for k, v in sub.items() if k != "gender"})
-            stream_out()
+            del sub
+            stream_out(".F")
         else:
             logging.warning("Provide at least 5 female samples to enable normalization of female gonosomes.")
         if not args.nipt:
@@ -328,7 +348,8 @@ def _newref_body(args, contexts, rd):
                                           sel_of["M"], rd)
                 final_ref["has_male"] = True
                 final_ref.update({k + ".M": v for k, v in sub.items() if k != "gender"})
-                stream_out()
+                del sub
+                stream_out(".M")
             else:
                 logging.warning("Provide at least 5 male samples to enable normalization of male gonosomes.")
     except BaseException:
@@ -366,7 +387,10 @@ def _newref_body(args, contexts, rd):
         closing = ex.submit(writer.close)
         logging.info("Running QC on the newly created reference...")
         try:
-            qc_reference(final_ref)
+            for j_ in qc_jobs:
+                j_.result()
+            qc_pool.shutdown(wait=True)
+            qc_reference(final_ref, qc_metrics)
         finally:
             closing.result()
     logging.info("Finished creating reference")

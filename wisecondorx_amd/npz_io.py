@@ -18,6 +18,7 @@ CLI's wall-clock once the search runs on the GPU, so both go around `zipfile` fo
 import io
 import os
 import struct
+import threading
 import tempfile
 import zipfile
 import zlib
@@ -85,14 +86,18 @@ class NpzWriter:
     headers and the central directory, syncs and renames.  The file appears under its final name only
     after EVERY write has succeeded (a failed write -- disk full -- must not leave a plausible-looking
     archive behind); the temporary name is unique (two writers of one target, or somebody's stale
-    .tmp, must not trample each other).  Arrays handed to add() must stay unchanged until close()."""
+    .tmp, must not trample each other).  Arrays handed to add() must stay unchanged until their
+    payload is written; the writer lets go of a member's array as soon as that is the case
+    (flush_async), so a caller that drops its own reference gets gigabytes of tables freed on the
+    writer's threads beside its next work instead of at the end."""
 
     def __init__(self, path, compress_small=True):
         if not str(path).endswith(".npz"):
             path = str(path) + ".npz"
         self.final_path = str(path)
         self.compress_small = compress_small
-        self.members, self.jobs, self.keep, self.flushes = [], [], [], []
+        self.members, self.jobs, self.flushes = [], [], []
+        self.lock = threading.Lock()
         self.off = 0
         self.fd, self.tmp_path = tempfile.mkstemp(dir=os.path.dirname(os.path.abspath(self.final_path)) or ".",
                                                   prefix=os.path.basename(self.final_path) + ".", suffix=".tmp")
@@ -107,7 +112,6 @@ class NpzWriter:
                and (arr.flags.c_contiguous or arr.flags.f_contiguous))
         if big:
             m = {"name": fname, "head": _npy_header(arr), "raw": _raw_view(arr), "method": 0}
-            self.keep.append(arr)
         else:
             buf = io.BytesIO()
             np.lib.format.write_array(buf, arr, allow_pickle=True)
@@ -131,20 +135,43 @@ class NpzWriter:
         # every chunk of a stored member: CRC-32 and positional write on one worker (zlib and
         # os.pwrite release the GIL); the member's CRC is the chunks' combined in order
         if "crc" in m:
-            self.jobs.append((m, [self.ex.submit(_pwrite_all, self.fd, m["raw"], m["data_off"])]))
+            fs = [self.ex.submit(_pwrite_all, self.fd, m["raw"], m["data_off"])]
         else:
             base = m["data_off"] + len(m["head"])
-            self.jobs.append((m, [self.ex.submit(_crc_and_write, self.fd, m["raw"][a:b], base + a)
-                                  for a, b in _crc_chunks(m["raw"], 4 * _THREADS)]))
+            fs = [self.ex.submit(_crc_and_write, self.fd, m["raw"][a:b], base + a)
+                  for a, b in _crc_chunks(m["raw"], 4 * _THREADS)]
+        self.jobs.append({"m": m, "fs": fs, "arr": arr if big else None})
+
+    def _finish(self, job):
+        """A member whose payload writes are done: its CRC-32 (the chunks' combined in order), and the
+        writer's references to the payload dropped.  Raises what a failed write raised."""
+        with self.lock:
+            fs, m = job["fs"], job["m"]
+            if fs is None:
+                return
+            if "crc" in m:
+                fs[0].result()
+            else:
+                crc = zlib.crc32(m["head"])
+                for f in fs:
+                    c, n = f.result()
+                    crc = crc32_combine(crc, c, n)
+                m["crc"] = crc
+            m["raw"] = None
+            job["fs"] = job["arr"] = None
 
     def flush_async(self):
         """Start writing back what has been added so far (an fsync on a worker thread once those
-        members' payload writes are done): close()'s own fsync then finds little left to do."""
-        pending = [f for _, fs in self.jobs for f in fs]
+        members' payload writes are done): close()'s own fsync then finds little left to do, and the
+        arrays of those members are let go of."""
+        snapshot = [j for j in self.jobs if j["fs"] is not None]
 
         def sync():
-            for f in pending:
-                f.exception()           # (wait; a failed write is reported by close())
+            for j in snapshot:
+                for f in (j["fs"] or ()):
+                    f.exception()       # (wait)
+            for j in snapshot:
+                self._finish(j)         # (a failed write raises here: close() reports it)
             os.fsync(self.fd)
         self.flushes.append(self.ex.submit(sync))
 
@@ -163,17 +190,10 @@ class NpzWriter:
         ok = False
         fd, members = self.fd, self.members
         try:
-            for m, fs in self.jobs:
-                if "crc" in m:
-                    fs[0].result()
-                    continue
-                crc = zlib.crc32(m["head"])
-                for f in fs:
-                    c, n = f.result()
-                    crc = crc32_combine(crc, c, n)
-                m["crc"] = crc
             for f in self.flushes:
                 f.result()
+            for j in self.jobs:
+                self._finish(j)
             cd_off = self.off
             # ---- headers and central directory
             cd = b""
@@ -217,7 +237,7 @@ class NpzWriter:
             self.closed = True
             self.ex.shutdown(wait=True, cancel_futures=True)
             os.close(fd)
-            self.keep = []
+            self.jobs = []
             if ok:
                 os.replace(self.tmp_path, self.final_path)
             else:

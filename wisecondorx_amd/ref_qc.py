@@ -94,9 +94,11 @@ def verdict(m, male):
     return "PASS", ""
 
 
-def qc_reference(reference):
+def qc_reference(reference, precomputed=None):
     """QC of a reference .npz (path) or of the in-memory dict `newref` is about to write.
-    Returns the worst severity: 0 (PASS), 1 (WARN), 2 (FAIL) -- ref_qc.py:140-218."""
+    Returns the worst severity: 0 (PASS), 1 (WARN), 2 (FAIL) -- ref_qc.py:140-218.
+    precomputed: {suffix: compute_metrics(...)} of sub-references whose tables the caller has already
+    let go of (newref takes a pass's metrics right after the pass)."""
     if isinstance(reference, dict):
         ref, where = reference, "(in memory)"
     else:
@@ -119,7 +121,7 @@ def qc_reference(reference):
     loggers = {"PASS": logging.info, "WARN": logging.warning, "FAIL": logging.error}
     for suf in suffixes:
         label = _LABEL[suf]
-        m = compute_metrics(ref, suf)
+        m = precomputed[suf] if precomputed and suf in precomputed else compute_metrics(ref, suf)
         if m is None:
             logging.warning("[{}] no indexes/distances — skip".format(label))
             continue
