@@ -323,7 +323,12 @@ __global__ __launch_bounds__(NT) void k_normalize_mask_lanes(
         if (c < 0) c += len_cd;                       // NumPy negative index
         gv = (int)(c < cs ? c : c + own);             // chr_data index -> row
       }
-      unsigned long long w = sel[i * ipl + q];
+      // (the selection word is the same for every lane: in SGPRs the walk over its bits -- ctz, clear,
+      //  readlane index -- is scalar work; left in VGPRs it cost 11 of the loop's 24 vector instructions
+      //  per reference row)
+      const unsigned long long wv = sel[i * ipl + q];
+      unsigned long long w = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(wv >> 32)) << 32) |
+                             (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)wv);
       if (q == ipl - 1 && (k & 63)) w &= (1ull << (k & 63)) - 1ull;
       // the selected rows of this word, four at a time (their loads in flight together)
       while (w) {
