@@ -37,7 +37,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 vector == matrix (not in the guide)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA
 SPINUP_STEPS = int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "0"))   # extra untimed steps (0: only --warmup)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "screen_traffic.json")
+TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", r_, "screen_traffic.json") for r_ in ("r05", "r04")]
+SIMD_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: 2.4 GHz peak engine clock (1 024 SIMDs)
 
 
 def screen_source_sha():
@@ -150,10 +151,12 @@ def cpu_baseline(Xs, chr_cum, k, budget_s=10.0):
             "extrapolated_full_search_s": float(np.sum(mb * (B - mb))) / (pairs_py / dt_py)}
 
 
-def verify_rows(w, n_blocks=128, rows_per_block=16):
+def verify_rows(w, n_blocks=128, rows_per_block=16, gon_blocks=40):
     """Out of the timed region: the reference-bin tables of the LAST timed step against the C oracle
-    (oracle/wcx_oracle_tiled.c on the host's cores) on n_blocks x rows_per_block scattered target
-    rows, each against all its candidates -- indices and distances bit for bit."""
+    (oracle/wcx_oracle_tiled.c on the host's cores) -- indices and distances bit for bit, every row
+    against all its candidates: n_blocks x rows_per_block scattered target rows of the A pass, and
+    gon_blocks x rows_per_block scattered gonosomal target rows of the F pass (chrX) and of the M pass
+    (chrX + chrY, the chrY rows all included in the draw's range)."""
     from oracle import c_oracle as CO
     if w.last is None:
         return None
@@ -165,10 +168,40 @@ def verify_rows(w, n_blocks=128, rows_per_block=16):
     gi = w.last[0][sel].cpu().numpy()
     gd = w.last[1][sel].cpu().numpy()
     bad = int(np.count_nonzero((gi != oi).any(axis=1) | (gd != od).any(axis=1)))
-    return {"rows": int(len(rows)), "mismatches": bad, "seconds": time.perf_counter() - t0,
-            "what": "indices and distances of {} target rows ({} scattered blocks) of the last timed "
-                    "step, bit for bit against oracle/wcx_oracle_tiled.c on {} host threads (each row "
-                    "against all its candidates)".format(len(rows), n_blocks, CO.host_threads())}
+    out = {"rows": int(len(rows)), "mismatches": bad}
+    n_all, bad_all = int(len(rows)), bad
+    ref = getattr(w, "last_ref", None) or {}
+    if w.world == 1:
+        for tag in ("F", "M"):
+            if tag not in ref:
+                continue
+            P = w.P[tag]
+            cum, Bp = P["cum"], int(P["B"])
+            g0 = int(cum[21])                                  # first gonosomal row of this pass
+            if Bp - g0 < rows_per_block:
+                continue
+            Xs = np.ascontiguousarray(P["p"]["X"].T)           # [S][B] of this pass
+            n_b = min(gon_blocks, (Bp - g0) // rows_per_block)
+            st = g0 + np.sort(rng.choice(Bp - g0 - rows_per_block + 1, n_b, replace=False))
+            if tag == "M" and len(cum) > 23 and Bp - int(cum[22]) >= rows_per_block:
+                st[-1] = Bp - rows_per_block                   # the last chrY rows are always in
+                st = np.unique(st)
+            r_, oi, od = CO.topk_row_blocks_threaded(Xs, cum, st, rows_per_block, w.k)
+            sel = w.torch.from_numpy(r_).to(ref[tag]["idx"].device)
+            gi = ref[tag]["idx"][sel].cpu().numpy()
+            gd = ref[tag]["dist"][sel].cpu().numpy()
+            b_ = int(np.count_nonzero((gi != oi).any(axis=1) | (gd != od).any(axis=1)))
+            out[tag + "_pass"] = {"rows": int(len(r_)), "mismatches": b_,
+                                  "chrY_rows": int(np.count_nonzero(r_ >= int(cum[22]))) if len(cum) > 23 else 0}
+            n_all += int(len(r_))
+            bad_all += b_
+    out.update({"rows_all_passes": n_all, "mismatches_all_passes": bad_all,
+                "seconds": time.perf_counter() - t0,
+                "what": "indices and distances of {} target rows of the A pass ({} scattered blocks) and of "
+                        "scattered gonosomal rows of the F and M passes of the last timed step, bit for bit "
+                        "against oracle/wcx_oracle_tiled.c on {} host threads (each row against all its "
+                        "candidates)".format(len(rows), n_blocks, CO.host_threads())})
+    return out
 
 
 class Workload:
@@ -305,8 +338,10 @@ class Workload:
         if record:
             self.ms["predict_full"].append(1e3 * (time.perf_counter() - t0))
             self.ms["normalize"].append(ctx.kernel_ms("aut:normalize") + max(0.0, ctx.kernel_ms("normalize")))
-            for name in ("cbs", "segment_z", "cutoff", "weights"):
+            for name in ("cbs", "segment_z", "cutoff"):
                 self.ms[name].append(ctx.kernel_ms(name))
+            # two calls (autosomal + gonosomal reference), each with its own timer
+            self.ms["weights"].append(ctx.kernel_ms("weights") + max(0.0, ctx.kernel_ms("gon:weights")))
             for tag in ("A", "F", "M"):
                 cx_ = self.side[tag][1] if tag in self.side else ctx
                 for n_ in self.names:
@@ -403,7 +438,8 @@ def hbm_kernels(w, rf):
                               "{:.0f} GB through L2)".format(int(rf.get("refined_pairs", 0)) * S * 8 / 1e9)),
         "k_cut_partial (cut-off, 5 repeats x 2 sweeps)": (w.mean_ms("cutoff"), 10 * B * k * 8,
                                                           "10 sweeps of the autosomal distances"),
-        "k_weights": (w.mean_ms("weights"), (B + int(w.P["F"]["B"])) * k * 8, "one sweep of distances (A + gonosomal reference)"),
+        "k_weights": (w.mean_ms("weights"), (B + int(w.P["F"]["B"])) * k * 8,
+                      "one sweep of distances: the autosomal + the gonosomal reference (two calls, both timed)"),
         "k_normalize_pass x3 (1 sample, A + gonosomes)": (w.mean_ms("normalize"), 3 * (B + BG) * (k * 4 + k // 8 + 32),
                                                           "per pass and bin: k indexes + selection bits + in / out values"),
     }
@@ -637,20 +673,38 @@ def main():
 
     # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (bench.py cannot read
     # counters itself); only valid for the kernel sources it was recorded with
-    def add_traffic(rf, S):
-        if not (world == 1 and os.path.exists(TRAFFIC_JSON)):
+    def add_traffic(rf, S, B):
+        # what `frac` is: ALGORITHMIC flop (2 S per ordered pair) over the sweep's time -- the symmetric
+        # sweep executes about half of them, so frac is a speed-up-adjusted figure, not the matrix
+        # pipe's utilisation; frac_executed and (with the PMC file) mfma_busy_frac are the hardware's
+        rf["frac_note"] = "algorithmic flop (2 S P) / sweep time / dense f16 peak; the hardware-side figures " \
+                          "are frac_executed (MFMA flop really issued) and mfma_busy_frac (PMC)"
+        rf["frac_executed"] = rf["executed_tflops"] / F16_MFMA_PEAK_TFLOPS
+        algo_bytes = B * S * 8 + B * args.refsize * 12       # X once + idx / dist out
+        rf["algorithmic_bytes"] = int(algo_bytes)
+        if world != 1:
             return
-        tj = json.load(open(TRAFFIC_JSON))
-        key = "S{}".format(S)
-        if tj.get("kernel_sha") == screen_source_sha() and key in tj.get("workloads", {}) \
-                and (args.binsize, args.refsize) == (15000, 300):
-            e = tj["workloads"][key]
-            rf["traffic"] = e["fetch_bytes_per_sweep_corrected_x2"] + e["write_bytes_per_sweep"]
-            rf["traffic_source"] = "profiles/r04/screen_traffic.json (rocprofv3 --pmc FETCH_SIZE, " \
-                                   "WRITE_SIZE; bytes per screen sweep; kernel_sha {})".format(
-                                       tj["kernel_sha"])
+        for path in TRAFFIC_JSONS:
+            if not os.path.exists(path):
+                continue
+            tj = json.load(open(path))
+            key = "S{}".format(S)
+            if tj.get("kernel_sha") == screen_source_sha() and key in tj.get("workloads", {}) \
+                    and (args.binsize, args.refsize) == (15000, 300):
+                e = tj["workloads"][key]
+                rf["traffic"] = e["fetch_bytes_per_sweep_corrected_x2"] + e["write_bytes_per_sweep"]
+                rf["traffic_over_algorithmic"] = rf["traffic"] / algo_bytes
+                if e.get("mfma_busy_cycles_per_sweep"):
+                    rf["mfma_busy_frac"] = e["mfma_busy_cycles_per_sweep"] / (
+                        1024 * rf["kernel_ms"] * 1e-3 * SIMD_CLOCK_HZ)
+                    rf["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES per sweep / (1 024 SIMDs x kernel_ms x " \
+                                           "2.4 GHz)"
+                rf["traffic_source"] = "{} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES; " \
+                                       "per screen sweep; kernel_sha {})".format(
+                                           os.path.relpath(path, ROOT), tj["kernel_sha"])
+                return
     if screen_ms >= 0:
-        add_traffic(roofline, w.S)
+        add_traffic(roofline, w.S, w.B)
 
     out = {
         "metric": "newref+predict throughput @{}kb bins (bins x refs per second)".format(
@@ -690,7 +744,7 @@ def main():
         sequential_kernel_times(w2)
         r2, sm2 = w2.roofline()
         if sm2 >= 0:
-            add_traffic(r2, w2.S)
+            add_traffic(r2, w2.S, w2.B)
         out["secondary"] = {"workload": "BASELINE configs[2]: 15 kb x 100 samples, same step",
                             "ms_per_step": dt2 / args.steps * 1e3,
                             "value": w2.pairs_total / (dt2 / args.steps),

@@ -220,8 +220,23 @@ def test_cbs_batch_dev_equals_the_host_api(pt, with_inf):
                                              1e-4, 500000, 3, _lib.ptr(seg), cap, _lib.ptr(cnt)))
         return [seg[i, :cnt[i]].copy() for i in range(ns)]
 
+    # the device call FIRST, on a context of its own whose host staging area is poisoned (debug flag
+    # 64): the host-side decisions (short-arc bound, edge statistics) read a series' x | w only where
+    # ensure_resident exported them -- a missing export reads NaN here instead of the values an earlier
+    # host call left in the same staging area
+    fresh = _lib.Context(0)
+    fresh.lib.wcx_debug_flags(fresh.h, 64)
+    main_ctx, ctx = ctx, fresh
+    try:
+        got_fresh = device()
+    finally:
+        ctx = main_ctx
+        fresh.close()
     want, got = host(), device()
     assert sum(len(x) for x in want) > ns * 22               # (change-points and NA splits were found)
+    for a, b in zip(want, got_fresh):
+        assert a.shape == b.shape
+        assert np.array_equal(a, b, equal_nan=True)
     for a, b in zip(want, got):
         assert a.shape == b.shape
         assert np.array_equal(a, b, equal_nan=True)

@@ -305,3 +305,33 @@ def test_shipped_dnacopy_segments_do_not_depend_on_the_seed_or_alpha(bdry):
     assert not moved, "segments differ from DNAcopy's for seeds {}".format(moved)
     got = predict_tools.run_cbs(res, "F", 1e-3, binsize, 1, ctx)
     assert [tuple(s[:3]) for s in got] == want3
+
+
+def test_shipped_dnacopy_segments_under_random_weights(bdry):
+    """The one DNAcopy pin (docs/include/example.bed) was produced with per-bin weights that the
+    reference does not ship; the oracle and the device reproduce its 50 segments with UNIT weights.
+    How much hangs on that assumption?  The same run under 32 random weight vectors drawn from the
+    range WisecondorX's weights take (get_weights-like, uniform 0.5 ... 2, predict_tools.py:152-155;
+    CBS.R:41-42,70-73 pass them to segment()): every change-point of the shipped segmentation must be
+    found again within +-1 bin, and no extra one may appear."""
+    from test_oracle_cbs import example_case
+    from wisecondorx_amd import _lib, predict_tools
+    results_r, results_w, binsize, want = example_case()
+    want3 = [tuple(int(v) for v in s[:3]) for s in want]
+    ctx = _lib.default_context(0)
+    rng = np.random.default_rng(2024)
+    worst, moved = 0, []
+    for trial in range(32):
+        ws = [rng.uniform(0.5, 2.0, len(v)) for v in results_w]
+        res = {"results_r": [v.tolist() for v in results_r], "results_w": [w_.tolist() for w_ in ws]}
+        got = [tuple(s[:3]) for s in predict_tools.run_cbs(res, "F", 1e-4, binsize, 1, ctx)]
+        if len(got) != len(want3):
+            moved.append((trial, "{} segments instead of {}".format(len(got), len(want3))))
+            continue
+        for a, b in zip(got, want3):
+            d = max(abs(a[1] - b[1]), abs(a[2] - b[2]))
+            worst = max(worst, d)
+            if a[0] != b[0] or d > 1:
+                moved.append((trial, a, b))
+    assert not moved, "change-points moved under random weights: {}".format(moved[:5])
+    print("largest shift of a change-point under 32 random weight vectors: {} bin(s)".format(worst))

@@ -247,10 +247,18 @@ def test_mask_skew_default_is_upstream_and_aligned_masks_is_opt_in(tmp_path):
     npz_io.save_sample(sp, sample_from_counts(g["test_counts"], bpc), 4000000)
     n_aut = int(np.sum(bpc[:22]))
     common = ["--binsize", "4000000", "--refsize", "40", "--yfrac", "0.004"]
-    # default: upstream's masks, skew included
+    # default: upstream's masks; the skew makes the reference unusable, so newref stops with an error
+    # and leaves no file (nor a temporary one) behind
+    out0 = str(tmp_path / "ref_default.npz")
+    random.seed(5)
+    with pytest.raises(SystemExit) as e0:
+        main.main(["newref"] + infiles + [out0] + common)
+    assert e0.value.code == 1
+    assert [f for f in os.listdir(str(tmp_path)) if f.startswith("ref_default")] == []
+    # --reference-mask-skew (deprecated alias): upstream's file as it is, skew included
     out = str(tmp_path / "ref.npz")
     random.seed(5)
-    main.main(["newref"] + infiles + [out] + common)
+    main.main(["newref"] + infiles + [out, "--reference-mask-skew"] + common)
     mine = np.load(out, allow_pickle=True)
     assert np.array_equal(mine["mask"], g["mask"])
     assert np.array_equal(mine["mask.F"], g["mask_F"])

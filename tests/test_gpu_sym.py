@@ -140,14 +140,20 @@ def test_symmetric_sweep_wide_norm_spread(nt, monkeypatch):
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
 
 
-def test_symmetric_sweep_all_rows_of_the_bench_cohort(nt):
+@pytest.fixture(scope="module")
+def bench_cohort_500():
+    """bench.py's default workload (15 kb x 500 samples): the prepared A / F / M passes."""
+    import bench
+    return bench.make_full_workload(15000, 500)[1]
+
+
+def test_symmetric_sweep_all_rows_of_the_bench_cohort(nt, bench_cohort_500):
     """The autosomal pass of bench.py's default workload -- the PCA-CORRECTED matrix of the 500-sample
     synthetic cohort at 15 kb, not a synthetic corrected matrix -- through the default path (symmetric
     sweep): EVERY one of the 182 k rows, indices and distances, bit for bit against the tiled C oracle;
     no row may need the exact kernel."""
-    import bench
     from wisecondorx_amd import _lib
-    co, passes, _ = bench.make_full_workload(15000, 500)
+    passes = bench_cohort_500
     p = passes["A"]
     X = p["X"]
     cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
@@ -155,6 +161,47 @@ def test_symmetric_sweep_all_rows_of_the_bench_cohort(nt):
     idx, dist = nt.get_ref_for_rows(X, cum, k, 0, B, mode=0)
     st = _lib.default_context().topk_stats()
     assert st["sym_gates"] > 0 and st["fallback_rows"] == 0 and st["rows"] == B
+    oi, od = _oracle(X, cum, k)
+    bad = np.flatnonzero((idx != oi).any(axis=1) | (dist != od).any(axis=1))
+    assert bad.size == 0, "{} of {} rows differ (first {})".format(bad.size, B, bad[:5])
+
+
+@pytest.mark.parametrize("tag", ["F", "M"])
+def test_gonosomal_passes_all_rows_of_the_bench_cohort(nt, bench_cohort_500, tag):
+    """The F and M passes of bench.py's default workload at full size (the female / male halves of the
+    cohort, ~192 k / ~195 k candidate rows x 250 samples): EVERY gonosomal target row -- chrX, and chrY
+    in the M pass -- through the default path of a row shard (one-directional sweep in candidate
+    segments), indices and distances bit for bit against the tiled C oracle."""
+    from wisecondorx_amd import _lib
+    p = bench_cohort_500[tag]
+    X = p["X"]
+    cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
+    B, g0, k = cum[-1], cum[21], 300
+    assert B - g0 > 5000
+    if tag == "M":
+        assert cum[23] - cum[22] > 100, "the M pass of the bench cohort has chrY target rows"
+    idx, dist = nt.get_ref_for_rows(X, cum, k, g0, B, mode=0)
+    st = _lib.default_context().topk_stats()
+    assert st["rows"] == B - g0 and st["fallback_rows"] == 0
+    Xs = np.ascontiguousarray(np.asarray(X).T)
+    oi, od = CO.get_reference_rows_threaded(Xs, cum, g0, B, k)
+    bad = np.flatnonzero((idx != oi).any(axis=1) | (dist != od).any(axis=1))
+    assert bad.size == 0, "{} of {} gonosomal rows differ (first {})".format(bad.size, B - g0, bad[:5])
+
+
+def test_default_sweep_all_rows_of_the_100_sample_cohort(nt):
+    """BASELINE configs[2] as bench.py's `secondary` block runs it: the PCA-corrected matrix of the
+    100-sample cohort at 15 kb through the DEFAULT policy (K = 112), every row against the tiled C
+    oracle, bit for bit."""
+    import bench
+    from wisecondorx_amd import _lib
+    p = bench.make_full_workload(15000, 100)[1]["A"]
+    X = p["X"]
+    cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
+    B, k = cum[-1], 300
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, B, mode=0)
+    st = _lib.default_context().topk_stats()
+    assert st["rows"] == B and st["fallback_rows"] == 0
     oi, od = _oracle(X, cum, k)
     bad = np.flatnonzero((idx != oi).any(axis=1) | (dist != od).any(axis=1))
     assert bad.size == 0, "{} of {} rows differ (first {})".format(bad.size, B, bad[:5])

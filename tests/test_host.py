@@ -497,7 +497,10 @@ def test_newref_mask_skew_default_follows_upstream():
     from wisecondorx_amd import main
     a = main.build_parser().parse_args(["newref", "a.npz", "out.npz"])
     assert a.aligned_masks is False
+    assert a.reference_mask_skew is False
     assert main.build_parser().parse_args(["newref", "a.npz", "out.npz", "--aligned-masks"]).aligned_masks
+    assert main.build_parser().parse_args(["newref", "a.npz", "out.npz",
+                                           "--reference-mask-skew"]).reference_mask_skew    # deprecated alias
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_skew.npz"))
     n_aut = int(np.sum(g["cohort_bpc"][:22]))
     assert g["mask"][:n_aut].sum() == g["mask_F"][:n_aut].sum() + 1
@@ -622,6 +625,12 @@ def test_reference_npz_deferred_members(tmp_path):
             fh.seek(off + 4096)
             fh.write(bytes([c[0] ^ 1]))
     ref2 = npz_io.load_reference(path, defer=(".M",))                    # (the other members are intact)
+    with pytest.raises(IOError, match="CRC-32 mismatch"):
+        npz_io.ensure_loaded(ref2, ".M")
+    # ... and leaves nothing behind: no half-read table in the dict (the intact "indexes.M" of the same
+    # call included), the plans still there, so a later access raises and a retry fails the same way
+    assert "distances.M" not in ref2 and "indexes.M" not in ref2
+    assert sorted(ref2.deferred) == ["distances.M", "indexes.M"]
     with pytest.raises(IOError, match="CRC-32 mismatch"):
         npz_io.ensure_loaded(ref2, ".M")
 

@@ -1450,6 +1450,13 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
   }
   double *hx = reinterpret_cast<double *>(hstage), *hw = hx + totp;
   int *hpos = reinterpret_cast<int *>(hw + totp);
+  if (d_r && (ctx->debug_flags & 64)) {
+    // (tests: on the device path the host copies exist only where ensure_resident put them; poisoned,
+    //  a host read of a series nobody exported cannot go unnoticed -- the staging area is reused
+    //  between calls and would otherwise still hold an earlier call's values)
+    const double poison = __builtin_nan("");
+    for (int64_t i = 0; i < 2 * totp; ++i) hx[i] = poison;
+  }
   if (!d_r)
     for_samples([&](int s) {
       for (int c = 0; c < n_chr; ++c) {

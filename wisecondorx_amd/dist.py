@@ -390,7 +390,11 @@ def predict_batch_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False)
         if G is not None:
             _lib.check(lib.wcx_ref_wrap_dev(ctx.h, G["idx"].data_ptr(), G["dist"].data_ptr(), BG_all, k,
                                             cumG_p, len(cumG), _lib.C.byref(hG)))
-            _lib.check(lib.wcx_weights_dev(ctx.h, hG, cache["wg"].data_ptr()))
+            ctx.timer_tag("gon:")             # (its own timer: "weights" alone would keep only this call)
+            try:
+                _lib.check(lib.wcx_weights_dev(ctx.h, hG, cache["wg"].data_ptr()))
+            finally:
+                ctx.timer_tag("")
             _lib.check(lib.wcx_predict_normalize_dev(ctx.h, hG, d_xG.data_ptr(), ns, cutoff.value, ct, 22,
                                                      g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
                                                      med[2].data_ptr(), med[3].data_ptr()))

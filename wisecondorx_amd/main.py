@@ -364,35 +364,59 @@ def _newref_body(args, contexts, rd):
             contexts[0].lib.wcx_pca_end(contexts[0].h)
             contexts[0].release_buffers()
     if rank != 0:
+        qc_pool.shutdown(wait=False)
         return                      # rank 0 holds the gathered tables and writes the file
-    final_ref["is_nipt"] = args.nipt
-    final_ref["trained_cutoff"] = trained_cutoff
-    n_aut = int(np.sum(final_ref["bins_per_chr"]))
-    for ap in (".F", ".M"):
-        if "mask" + ap in final_ref and not np.array_equal(final_ref["mask" + ap][:n_aut],
-                                                           final_ref["mask"]):
-            # the reference has the same latent skew (newref_control.py:51-54 mutates the shared
-            # mask after the A pass kept its copy) and misaligns silently at predict time
-            logging.warning("The PCA-distance filter of the {} pass dropped {} autosomal bin(s) "
-                            "the autosomal reference still holds (upstream behaviour): predict cannot "
-                            "align the two -- rebuild with --aligned-masks".format(
-                                ap[1:], int(np.sum(final_ref["mask"]) -
-                                            np.sum(final_ref["mask" + ap][:n_aut]))))
-    for k_ in ("has_female", "has_male", "is_nipt", "trained_cutoff"):
-        writer.add(k_, final_ref[k_])
-    # the last writes and the sync run beside the QC of the tables (main.py:134-135)
-    from concurrent.futures import ThreadPoolExecutor
-    from .ref_qc import qc_reference
-    with ThreadPoolExecutor(max_workers=1) as ex:
-        closing = ex.submit(writer.close)
-        logging.info("Running QC on the newly created reference...")
-        try:
-            for j_ in qc_jobs:
-                j_.result()
-            qc_pool.shutdown(wait=True)
-            qc_reference(final_ref, qc_metrics)
-        finally:
-            closing.result()
+    closing = None
+    try:
+        final_ref["is_nipt"] = args.nipt
+        final_ref["trained_cutoff"] = trained_cutoff
+        n_aut = int(np.sum(final_ref["bins_per_chr"]))
+        skewed = []
+        for ap in (".F", ".M"):
+            if "mask" + ap in final_ref and not np.array_equal(final_ref["mask" + ap][:n_aut],
+                                                               final_ref["mask"]):
+                # the reference has the same latent skew as upstream's (newref_control.py:51-54 mutates
+                # the shared mask after the A pass kept its copy) and cannot be aligned at predict time
+                skewed.append("the PCA-distance filter of the {} pass dropped {} autosomal bin(s) the "
+                              "autosomal reference still holds".format(
+                                  ap[1:], int(np.sum(final_ref["mask"]) -
+                                              np.sum(final_ref["mask" + ap][:n_aut]))))
+        if skewed and getattr(args, "reference_mask_skew", False):
+            logging.warning("{} (upstream behaviour, kept on request): predict cannot use this "
+                            "reference -- rebuild with --aligned-masks".format("; ".join(skewed)))
+        elif skewed:
+            # upstream writes such a reference and its predict then dies with an IndexError
+            # (predict_control.py:50, tests/golden/mask_skew.npz); an unusable file is not written here
+            logging.critical("{}: no predict can use such a reference (upstream's raises IndexError at "
+                             "predict_control.py:50), so it is NOT written.  Rebuild with --aligned-masks "
+                             "(keeps the autosomal masks of the three passes equal), or with "
+                             "--reference-mask-skew to write upstream's file as it is".format(
+                                 "; ".join(skewed)))
+            writer.abort()
+            qc_pool.shutdown(wait=False)
+            sys.exit(1)
+        for k_ in ("has_female", "has_male", "is_nipt", "trained_cutoff"):
+            writer.add(k_, final_ref[k_])
+        # the last writes and the sync run beside the QC of the tables (main.py:134-135)
+        from concurrent.futures import ThreadPoolExecutor
+        from .ref_qc import qc_reference
+        with ThreadPoolExecutor(max_workers=1) as ex:
+            closing = ex.submit(writer.close)
+            logging.info("Running QC on the newly created reference...")
+            try:
+                for j_ in qc_jobs:
+                    j_.result()
+                qc_pool.shutdown(wait=True)
+                qc_reference(final_ref, qc_metrics)
+            finally:
+                closing.result()
+    except BaseException:
+        # anything between the passes and the close (the skew check, a missing key, a failing QC
+        # job): no open descriptor, no writer threads, no multi-GB temporary file left behind
+        if closing is None:
+            writer.abort()
+        qc_pool.shutdown(wait=False)
+        raise
     logging.info("Finished creating reference")
 
 
@@ -671,7 +695,11 @@ def build_parser():
     p.add_argument("--aligned-masks", action="store_true",
                    help="Keep the autosomal part of the mask fixed in the gonosomal passes. Default "
                         "(like upstream WisecondorX): their PCA-distance filter may drop autosomal bins "
-                        "the autosomal reference still holds -- predict cannot use such a reference")
+                        "the autosomal reference still holds -- no predict can use such a reference, so "
+                        "newref then stops with an error instead of writing it")
+    p.add_argument("--reference-mask-skew", action="store_true",
+                   help="(deprecated) write the reference even when the gonosomal passes dropped "
+                        "autosomal bins, exactly as upstream does; predict will refuse it")
     p.set_defaults(func=tool_newref)
 
     p = sub.add_parser("gender", description="Returns the gender of a .npz resulting from convert",

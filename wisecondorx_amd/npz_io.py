@@ -408,37 +408,45 @@ class Reference(dict):
 
 def _read_members(path, plans, check_crc, out):
     """plans: [(key, arr, data offset, CRC of the header bytes, CRC of the directory)] -> out[key] = arr,
-    read by worker threads, CRC-32 checked."""
+    read by worker threads, CRC-32 checked.  A member enters `out` only when ALL of the plans have been
+    read and verified: another thread using `out` meanwhile never sees a half-filled table, and after an
+    I/O or CRC failure nothing of this call is in it."""
+    done = {}
     with ThreadPoolExecutor(max_workers=_THREADS) as ex:
         pending = []
         for key, arr, off, head_crc, want in plans:
             view = _raw_view(arr)
             futs = [(b - a, ex.submit(_read_into, path, off + a, view[a:b], check_crc))
                     for a, b in _crc_chunks(view, _THREADS)]
-            pending.append((key, futs, head_crc, want))
-            out[key] = arr
+            pending.append((key, arr, futs, head_crc, want))
         yield                                   # (the caller's own reading runs beside the workers)
-        for key, futs, crc, want in pending:
+        for key, arr, futs, crc, want in pending:
             for n, f in futs:
                 c = f.result()
                 if check_crc:
                     crc = crc32_combine(crc, c, n)
             if check_crc and crc != want:
                 raise IOError("{}: CRC-32 mismatch in member {}.npy (corrupted file)".format(path, key))
+            done[key] = arr
+    out.update(done)
 
 
 def ensure_loaded(ref, suffix):
-    """Read the deferred big members of `ref` whose key ends with `suffix` ("" = all of them)."""
+    """Read the deferred big members of `ref` whose key ends with `suffix` ("" = all of them).  The
+    read plans leave `ref.deferred` only once their tables are in `ref`: after a failure the call can
+    be repeated, and a later access raises instead of finding garbage."""
     deferred = getattr(ref, "deferred", None)
     if not deferred:
         return ref
-    keys = [k for k in deferred if k.endswith(suffix)]
+    keys = [k for k in list(deferred) if k.endswith(suffix)]
     plans = []
     for k in keys:
-        shape, dtype, fortran, off, head_crc, want = deferred.pop(k)
+        shape, dtype, fortran, off, head_crc, want = deferred[k]
         plans.append((k, np.empty(shape, dtype=dtype, order="F" if fortran else "C"), off, head_crc, want))
     for _ in _read_members(ref.path, plans, ref.check_crc, ref):
         pass
+    for k in keys:
+        deferred.pop(k, None)
     return ref
 
 
@@ -490,9 +498,10 @@ def load_reference(path, defer=()):
     out.check_crc = check_crc
     reader = _read_members(path, direct, check_crc, out)
     next(reader)                                # workers started
+    planned = {p_[0] for p_ in direct}
     with np.load(path, encoding="latin1", allow_pickle=True) as npz:
         for k in npz.files:
-            if k not in out and k not in out.deferred:
+            if k not in planned and k not in out.deferred:
                 out[k] = npz[k]
     for _ in reader:                            # join + CRC
         pass
