@@ -364,7 +364,7 @@ class Workload:
             # MFMA screen: algorithmic work = the -2 X^T X Gram GEMM, 2*S flop per candidate pair
             # (SURVEY.md §8d).  The kernel executes one fp16 product over K = 16*NK >= S + 4 (four
             # augmented columns carry the norm and the threshold), reported as executed_tflops.
-            nk_list = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32]
+            nk_list = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64]
             nk = next(v for v in nk_list if 16 * v >= S + 4)   # same rule as wcx_topk_screen_launch
             flops = 2.0 * S * pairs_A
             achieved = flops / (screen_ms * 1e-3) / 1e12

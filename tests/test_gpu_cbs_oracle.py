@@ -307,31 +307,53 @@ def test_shipped_dnacopy_segments_do_not_depend_on_the_seed_or_alpha(bdry):
     assert [tuple(s[:3]) for s in got] == want3
 
 
+def weight_robustness(segment_runs, want3):
+    """Shared by the CPU (oracle) and GPU statement of the weight-robustness check: per trial the list
+    of (chromosome, start, end) segments.  Returns (exact, moved, bad): trials identical to the shipped
+    segmentation; trials where ONLY the chr21 13.1 Mb change-point moved or vanished (the two-bin stub
+    [129, 131) before the NA gap of the centromere: the change-point may slide up to bin 140, the end of
+    that gap, or merge away); anything else."""
+    others = [s_ for s_ in want3 if s_[0] != 20]
+    exact, moved, bad = 0, 0, []
+    for trial, got in enumerate(segment_runs):
+        if got == want3:
+            exact += 1
+            continue
+        g21 = [s_ for s_ in got if s_[0] == 20]
+        ok = [s_ for s_ in got if s_[0] != 20] == others and g21[0] == (20, 63, 94) and g21[-1][2] == 467
+        if ok and len(g21) == 3:
+            ok = g21[1][1] == 129 and 131 <= g21[1][2] <= 140 and 131 <= g21[2][1] <= 140
+        elif ok:
+            ok = g21[1:] == [(20, 129, 467)]
+        if ok:
+            moved += 1
+        else:
+            bad.append((trial, g21))
+    return exact, moved, bad
+
+
 def test_shipped_dnacopy_segments_under_random_weights(bdry):
     """The one DNAcopy pin (docs/include/example.bed) was produced with per-bin weights that the
     reference does not ship; the oracle and the device reproduce its 50 segments with UNIT weights.
     How much hangs on that assumption?  The same run under 32 random weight vectors drawn from the
     range WisecondorX's weights take (get_weights-like, uniform 0.5 ... 2, predict_tools.py:152-155;
-    CBS.R:41-42,70-73 pass them to segment()): every change-point of the shipped segmentation must be
-    found again within +-1 bin, and no extra one may appear."""
+    CBS.R:41-42,70-73 pass them to segment()).  Measured: 49 of the 50 segments never
+    move; ONE change-point is weight-sensitive -- the start of the chr21 gain, a two-bin stub next to
+    the centromere's NA gap -- and slides to the other end of the gap (<= 9 bins) or merges away in
+    about four trials of ten.  Everything else within 0 bins."""
     from test_oracle_cbs import example_case
     from wisecondorx_amd import _lib, predict_tools
     results_r, results_w, binsize, want = example_case()
     want3 = [tuple(int(v) for v in s[:3]) for s in want]
     ctx = _lib.default_context(0)
     rng = np.random.default_rng(2024)
-    worst, moved = 0, []
+    runs = []
     for trial in range(32):
         ws = [rng.uniform(0.5, 2.0, len(v)) for v in results_w]
         res = {"results_r": [v.tolist() for v in results_r], "results_w": [w_.tolist() for w_ in ws]}
-        got = [tuple(s[:3]) for s in predict_tools.run_cbs(res, "F", 1e-4, binsize, 1, ctx)]
-        if len(got) != len(want3):
-            moved.append((trial, "{} segments instead of {}".format(len(got), len(want3))))
-            continue
-        for a, b in zip(got, want3):
-            d = max(abs(a[1] - b[1]), abs(a[2] - b[2]))
-            worst = max(worst, d)
-            if a[0] != b[0] or d > 1:
-                moved.append((trial, a, b))
-    assert not moved, "change-points moved under random weights: {}".format(moved[:5])
-    print("largest shift of a change-point under 32 random weight vectors: {} bin(s)".format(worst))
+        runs.append([tuple(s[:3]) for s in predict_tools.run_cbs(res, "F", 1e-4, binsize, 1, ctx)])
+    exact, moved, bad = weight_robustness(runs, want3)
+    assert not bad, "segments other than the chr21 stub moved under random weights: {}".format(bad[:3])
+    assert exact >= 12, "only {} of 32 weight vectors reproduce DNAcopy's 50 segments".format(exact)
+    print("32 random weight vectors: {} reproduce all 50 segments, {} move only the chr21 stub".format(
+        exact, moved))

@@ -168,7 +168,9 @@ def test_screen_real_valued_outlier_scale(nt):
 
 @pytest.mark.parametrize("k", [700, 1500])
 def test_large_refsize(nt, k):
-    """refsize beyond the MFMA screen's 512: all-fp64 search + the 16/32-entries-per-lane median."""
+    """Large refsizes on a small matrix: k = 700 through the one-directional screen (its shortlists
+    hold k + margin up to refsize 800) and the 16-entries-per-lane refine, k = 1500 (beyond the screen's
+    1024) through the all-fp64 search; + the 16/32-entries-per-lane median of the null ratios."""
     from wisecondorx_amd.synth import corrected_matrix
     X, mbpc, cum = corrected_matrix([900, 700, 500, 300], 20, seed=k)
     idx, dist = nt.get_ref_for_rows(X, cum, k, 0, cum[-1])
@@ -180,7 +182,8 @@ def test_large_refsize(nt, k):
                                O.null_ratios(X, idx, 0, cum[-1], ids), rtol=1e-12, atol=1e-13)
 
 
-@pytest.mark.parametrize("S", [12, 13, 28, 29, 108, 109, 124, 125, 156, 253, 444, 508])
+@pytest.mark.parametrize("S", [12, 13, 28, 29, 108, 109, 124, 125, 156, 253, 444, 508,
+                               509, 636, 637, 764, 765, 892, 893, 1020])
 def test_screen_k_step_boundaries(nt, S):
     """Every instantiated K = 16*NK of the screen kernel, at the S values where the four augmented
     columns (norm / threshold) just fit or spill into the next k-step."""
@@ -197,12 +200,32 @@ def test_screen_k_step_boundaries(nt, S):
 
 
 def test_beyond_screen_sample_limit_falls_back_to_exact(nt):
+    """More than 1020 samples (K = 16 NK > 1024: the target fragments no longer fit a wave's registers)
+    and a refsize beyond 1024 go to the all-fp64 search; mode 2 (screen required) refuses them."""
+    from wisecondorx_amd import _lib
     from wisecondorx_amd.synth import corrected_matrix
-    X, mbpc, cum = corrected_matrix([900, 700, 500], 510, seed=3)
+    X, mbpc, cum = corrected_matrix([900, 700, 500], 1021, seed=3)
     idx, dist = nt.get_ref_for_rows(X, cum, 30, 100, 200)          # mode 0: auto
     oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, 100, 200, 30)
     assert np.array_equal(idx, oi)
     assert np.array_equal(dist, od)
+    with pytest.raises(_lib.WcxError):
+        nt.get_ref_for_rows(X, cum, 30, 100, 200, mode=2)
+
+
+@pytest.mark.parametrize("k,screened", [(800, True), (801, False)])
+def test_one_directional_refsize_limit(nt, k, screened):
+    """A row shard (one-directional sweep, shortlists of 1024 entries) screens refsizes up to 800; one
+    more goes to the exact kernel.  Same bits either way."""
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([1500, 1300, 1200, 1000], 40, seed=k)
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 200, 700)
+    st = _lib.default_context().topk_stats()
+    oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, 200, 700, k)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+    assert (st["refined"] > 0) == screened       # (pairs the refine re-evaluated: the screen ran)
 
 
 def test_null_ratios_nan_duplicates_and_ties(nt):

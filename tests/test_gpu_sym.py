@@ -42,6 +42,14 @@ SHAPES = [
     ([1600, 1500, 1400, 1200, 1100, 900, 500], 260, 150, 8),      # K = 320 (NK 20)
     ([1700, 1500, 1300, 1200, 1000, 0, 700, 650], 150, 100, 8),   # K = 160 (NK 10), an empty chromosome
     ([2100, 1900, 1600, 1400, 1300, 1100], 250, 200, 8),           # K = 256 (NK 16): where the default policy starts
+    # more than 508 samples: NK = 40 .. 64, one wave per SIMD (round 5; the all-fp64 search before)
+    ([2300, 2000, 1800, 1500, 1300, 1000], 509, 300, 8),           # K = 640 (NK 40)
+    ([2200, 2000, 1700, 1500, 1200, 900], 640, 300, 8),            # K = 768 (NK 48)
+    ([2000, 1800, 1700, 1400, 1100, 900], 800, 100, 8),            # K = 896 (NK 56)
+    ([2400, 2100, 1800, 1500, 1300, 1000], 1000, 300, 8),          # K = 1024 (NK 64)
+    # refsize beyond 448: lists of 4096 entries, 16 / 32 entries per lane in the refine
+    ([5200, 4700, 4100, 3600, 3300, 2900, 2500, 2200], 60, 600, 4),
+    ([5600, 5100, 4500, 4000, 3500, 3000, 2600, 2300], 100, 1000, 4),
 ]
 
 
@@ -56,6 +64,9 @@ def test_symmetric_sweep_vs_c_oracle(nt, mb, S, k, sf, monkeypatch):
     assert np.array_equal(idx, oi), "indices differ"
     assert np.array_equal(dist, od), "distances differ"
     assert st["fallback_rows"] <= 2
+    if S > 508 or k > 512:
+        assert st["fallback_rows"] == 0
+        return
     # the one-directional sweep on the same input: same bits
     monkeypatch.setenv("WCX_SCREEN_SYM", "0")
     idx1, dist1, st1 = _run(nt, X, cum, k)

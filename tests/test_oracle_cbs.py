@@ -196,3 +196,23 @@ def test_oracle_reproduces_the_references_shipped_dnacopy_segments(bdry):
     # the outcome does not hinge on the permutation stream
     again = O.cbs_r_wrapper(results_r, results_w, "F", 1e-4, binsize, 77, CO.cbs_segment)
     assert [s[:3] for s in again] == [s[:3] for s in got]
+
+
+def test_oracle_shipped_segments_under_random_weights(bdry):
+    """The DNAcopy pin under weights: the shipped run's weights are unknown (unit weights reproduce its
+    50 segments).  Eight random get_weights-like weight vectors (uniform 0.5 ... 2): 49 of the 50
+    segments never move; only the chr21 stub's change-point (two bins before the centromere's NA gap)
+    slides or merges away.  (The device runs the same check with 32 vectors:
+    tests/test_gpu_cbs_oracle.py.)"""
+    from oracle import wcx_oracle as O
+    from test_gpu_cbs_oracle import weight_robustness
+    CO.load_boundary_table(bdry)
+    results_r, results_w, binsize, want = example_case()
+    want3 = [tuple(int(v) for v in s[:3]) for s in want]
+    rng = np.random.default_rng(2024)
+    runs = []
+    for _ in range(8):
+        ws = [rng.uniform(0.5, 2.0, len(v)) for v in results_w]
+        runs.append([tuple(s[:3]) for s in O.cbs_r_wrapper(results_r, ws, "F", 1e-4, binsize, 1, CO.cbs_segment)])
+    exact, moved, bad = weight_robustness(runs, want3)
+    assert not bad and exact >= 3 and exact + moved == 8

@@ -397,7 +397,7 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   wcx_aux_cancel_if_few_rows(ctx, B, searched);   // few target rows: no ranking of the null samples
   const bool can_screen = wcx_screen_supported(B, S, k);
   if (mode == 2 && !can_screen) {
-    wcx_set_error("mode 2 (MFMA screen) needs S <= 508, refsize <= 512, B >= 2048 "
+    wcx_set_error("mode 2 (MFMA screen) needs S <= 1020, refsize <= 1024, B >= 2048 "
                   "(got B=%lld S=%d k=%d)", (long long)B, S, k);
     return WCX_ERR_UNSUPPORTED;
   }

@@ -187,7 +187,9 @@ __device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S,
   sort_emit<IPL>(d, ix, k, oi, od);
 }
 
-// Rows whose shortlist fits 512 entries (8 per lane): the common case.
+// Rows whose shortlist fits 64 IPL entries (IPL per lane; 8 -> 512: the common case, refsize <= 448;
+// 16 / 32 for larger refsizes).
+template <int IPL>
 __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, int S, int Sp,
                                                ChrTab chr, int64_t row_begin, int64_t n_rows,
                                                const unsigned char *__restrict__ searched,
@@ -215,16 +217,17 @@ __global__ __launch_bounds__(NT) void k_refine(const double *__restrict__ Xr, in
     }
     const int n = cnt_out[r] & 0x3fffffff;
     if (wcx::lane_id() == 0) atomicAdd(&stats[5], (unsigned long long)n);   // pairs re-evaluated exactly
-    if (n > 512) continue;     // k_refine_big
+    if (n > 64 * IPL) continue;     // k_refine_big
     const int64_t row = row_begin + r;
     int64_t cs = 0, ce = chr.cum[0];
     for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
-    refine_row<8>(Xr, S, Sp, row, cs, ce - cs, sl + r * (int64_t)sls, perm, n, k,
+    refine_row<IPL>(Xr, S, Sp, row, cs, ce - cs, sl + r * (int64_t)sls, perm, n, k,
                   out_idx + r * (int64_t)k, out_dist + r * (int64_t)k, tile, xt_s, g_s);
   }
 }
 
-// Rare rows with 512 < n <= CAP shortlisted entries: one workgroup per row, LDS bitonic sort.
+// Rare rows with more entries than the wave kernel takes (n_small < n <= REFINE_MAX): one workgroup per
+// row, LDS bitonic sort.
 __global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr, int S, int Sp,
                                                    ChrTab chr, int64_t row_begin, int64_t n_rows,
                                                    const unsigned char *__restrict__ searched,
@@ -233,13 +236,14 @@ __global__ __launch_bounds__(NT) void k_refine_big(const double *__restrict__ Xr
                                                    const unsigned int *__restrict__ flags,
                                                    const int *__restrict__ perm, int k,
                                                    int32_t *__restrict__ out_idx,
-                                                   double *__restrict__ out_dist, int sls) {
+                                                   double *__restrict__ out_dist, int sls, int n_small) {
+  constexpr int CAP = REFINE_MAX;
   __shared__ double sd[CAP];
   __shared__ int si[CAP];
   for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
     if (!searched[r] || flags[r]) continue;
     const int n = cnt_out[r] & 0x3fffffff;
-    if (n <= 512) continue;
+    if (n <= n_small) continue;
     const int64_t row = row_begin + r;
     int64_t cs = 0, ce = chr.cum[0];
     for (int c = 1; c < chr.n_chr && row >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
@@ -298,13 +302,22 @@ int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTa
                       ScreenGlobals *glob, int sl_stride) {
   const unsigned gref = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
   const size_t rlds = (NT / 64) * ((size_t)(64 * RPITCH + Sp) * 8 + 64 * 4);
-  WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_refine),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-  k_refine<<<gref, NT, rlds, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl, cnt_out,
-                                         flags, perm, k, d_out_idx, d_out_dist, glob, ctx->d_stats, sl_stride);
+  // entries per lane of the wave kernel: a final shortlist holds ~1.13 k entries
+  const int ipl = k <= 448 ? 8 : (k <= 900 ? 16 : 32);
+#define WCX_REFINE(I)                                                                              \
+  {                                                                                                \
+    WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_refine<I>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));           \
+    k_refine<I><<<gref, NT, rlds, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl,  \
+                                                 cnt_out, flags, perm, k, d_out_idx, d_out_dist,   \
+                                                 glob, ctx->d_stats, sl_stride);                   \
+  }
+  if (ipl == 8) WCX_REFINE(8) else if (ipl == 16) WCX_REFINE(16) else WCX_REFINE(32)
+#undef WCX_REFINE
   const unsigned gbig = (unsigned)(n_rows < 2048 ? n_rows : 2048);
   k_refine_big<<<gbig, NT, 0, ctx->stream>>>(Xr, S, Sp, tab, row_begin, n_rows, searched, sl,
-                                             cnt_out, flags, perm, k, d_out_idx, d_out_dist, sl_stride);
+                                             cnt_out, flags, perm, k, d_out_idx, d_out_dist, sl_stride,
+                                             64 * ipl);
   WCX_HIP(hipGetLastError());
   return WCX_OK;
 }

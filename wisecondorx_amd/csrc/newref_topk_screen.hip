@@ -260,13 +260,14 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
   if (b >= Bpad) return;
   const int64_t row = perm[b];
   // scale 2^p so that the largest |a| lands in [1024, 2048): |a~|^2 <= 508 * 2^22 < 2^31.1 keeps
-  // nb/65536 and any threshold/65536 inside the fp16 range
+  // nb/65536 and any threshold/65536 inside the fp16 range; with more than 508 samples (NK > 32) one
+  // binade lower: |a~|^2 <= 1020 * 2^20 < 2^30
   const double amax = __longlong_as_double((long long)glob->amax_bits);
   int ex = 0;
   double scale = 1.0;
   if (amax > 0.0) {
     frexp(amax, &ex);            // amax = m 2^ex, m in [0.5,1)
-    scale = ldexp(1.0, 11 - ex);
+    scale = ldexp(1.0, (NK > 32 ? 10 : 11) - ex);
   }
   const int64_t tile = b >> 5;
   const int rl = (int)(b & 31);
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(NT) void k_sym_regroup(const uint4 *__restrict__ po
                                                     const unsigned int *__restrict__ pool_ovf,
                                                     unsigned int pool_cap, int64_t n_rows,
                                                     uint2 *__restrict__ sl, int *__restrict__ cnt,
-                                                    unsigned int *__restrict__ flags) {
+                                                    unsigned int *__restrict__ flags, int cap2) {
   if (*pool_ovf) {                           // records were lost: every row goes to the exact kernel
     for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * NT)
       flags[r] = 1u;
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(NT) void k_sym_regroup(const uint4 *__restrict__ po
   for (unsigned int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
     const uint4 rec = pool[i];
     const int slot = atomicAdd(&cnt[rec.x], 1);
-    if (slot < CAP2) sl[(int64_t)rec.x * CAP2 + slot] = make_uint2(rec.z, rec.y);
+    if (slot < cap2) sl[(int64_t)rec.x * cap2 + slot] = make_uint2(rec.z, rec.y);
     else flags[rec.x] = 1u;
   }
 }
@@ -602,24 +603,28 @@ __global__ __launch_bounds__(NT) void k_sym_regroup(const uint4 *__restrict__ po
 // list bounds the true k-th distance; its filter bound F must not exceed the estimate the list was
 // collected under (everything with d~ <= D is in the list) -- then the entries with d~ <= F are
 // exactly the ones the refine needs; else the row is flagged for the exact kernel.
+// IPL = list slots per lane: the lists hold 64 IPL entries (SymArgs::cap2); max_keep = most entries the
+// refine accepts.
+template <int IPL>
 __global__ __launch_bounds__(NT) void k_sym_final(const RowInfo *__restrict__ info,
                                                   const ScreenGlobals *__restrict__ glob,
                                                   const int *__restrict__ rowpos, int64_t n_rows,
                                                   uint2 *__restrict__ sl, int *__restrict__ cnt,
                                                   unsigned int *__restrict__ flags,
-                                                  const float *__restrict__ Dest, int k, float gamma) {
+                                                  const float *__restrict__ Dest, int k, float gamma,
+                                                  int max_keep) {
   const int lane = wcx::lane_id();
   const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
   const float e_max = __uint_as_float(glob->e_max), N_max = __uint_as_float(glob->N_max);
-  constexpr int IPL = CAP2 / 64;
+  constexpr int CAPL = 64 * IPL;
   for (int64_t r = w0; r < n_rows; r += nw) {
     const int c = cnt[r];
-    if (flags[r] || c > CAP2 || c < k) {
+    if (flags[r] || c > CAPL || c < k) {
       if (lane == 0) { flags[r] = 1u; cnt[r] = 0; }
       continue;
     }
-    uint2 *row = sl + r * (int64_t)CAP2;
+    uint2 *row = sl + r * (int64_t)CAPL;
     unsigned int key[IPL], idx[IPL];
     const int nq = (c + 63) >> 6;             // (wave-uniform: only the slices that hold entries are read)
 #pragma unroll
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(NT) void k_sym_final(const RowInfo *__restrict__ in
       base += __popcll(m);
     }
     if (lane == 0) {
-      if (base > CAP) { flags[r] = 1u; cnt[r] = 0; }
+      if (base > max_keep) { flags[r] = 1u; cnt[r] = 0; }
       else cnt[r] = base;
     }
   }
@@ -683,7 +688,7 @@ int wcx_transpose_launch(wcx_ctx *ctx, const double *src, int64_t rows, int64_t 
 }
 
 bool wcx_screen_supported(int64_t B, int S, int k) {
-  return S <= 508 && k <= 512 && k <= LIM && B >= 2048;
+  return S <= SMAX_SCREEN && k <= KMAX_SCREEN && B >= 2048;
 }
 
 static int env_int(const char *name, int dflt);
@@ -710,6 +715,8 @@ static int screen_dispatch(const ScreenCfg &c, const ScreenArgs &a, unsigned gri
   if (rc < 0) rc = wcx_screen_launch_k4(c, a, grid, lds, st);
   if (rc < 0) rc = wcx_screen_launch_k5(c, a, grid, lds, st);
   if (rc < 0) rc = wcx_screen_launch_k6(c, a, grid, lds, st);
+  if (rc < 0) rc = wcx_screen_launch_k7(c, a, grid, lds, st);
+  if (rc < 0) rc = wcx_screen_launch_k8(c, a, grid, lds, st);
   return rc;
 }
 
@@ -718,6 +725,8 @@ static int sym_dispatch(int nk, int ctg, int lb, int ring, const SymArgs &a, uns
   int rc = wcx_sym_launch_k1(nk, ctg, lb, ring, a, grid, lds, st);
   if (rc < 0) rc = wcx_sym_launch_k2(nk, ctg, lb, ring, a, grid, lds, st);
   if (rc < 0) rc = wcx_sym_launch_k3(nk, ctg, lb, ring, a, grid, lds, st);
+  if (rc < 0) rc = wcx_sym_launch_k4(nk, ctg, lb, ring, a, grid, lds, st);
+  if (rc < 0) rc = wcx_sym_launch_k5(nk, ctg, lb, ring, a, grid, lds, st);
   return rc;
 }
 
@@ -735,6 +744,8 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   const int NK = cfg.nk, CTG = cfg.ctg, GRr = CTG * 32;
   const int Sp = row_pitch(S);
   const int64_t n_rows = B;
+  // list capacity per row: the estimates admit ~4 k entries at k = 300, ~2.7 k at k = 1000
+  const int cap2 = k <= 448 ? CAP2 : CAP2_BIG;
   const int64_t n_s = (B + SF - 1) / SF;
   const int64_t P_s = (n_s + CT - 1) / CT * CT;
   const int64_t Bpad2 = P_s + ((B - n_s) + CT - 1) / CT * CT;       // positions of the two-region order
@@ -770,7 +781,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   const size_t o_phead = carve(256);      // pool head | pool overflow | queue head
   const size_t o_desc = carve(256 * sizeof(SymDesc));
   const size_t o_seq = carve((size_t)(NTb / 4 + 1) * 4);
-  const size_t o_sl = carve((size_t)n_rows * CAP2 * 8);
+  const size_t o_sl = carve((size_t)n_rows * cap2 * 8);
   const size_t o_cnt = carve((size_t)n_rows * 4);
   const size_t o_gst = carve((size_t)n_rows * 4);
   const size_t o_flag = carve((size_t)n_rows * 4);
@@ -873,6 +884,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     WCX_PREP_CASE(1) WCX_PREP_CASE(2) WCX_PREP_CASE(3) WCX_PREP_CASE(4) WCX_PREP_CASE(5)
     WCX_PREP_CASE(6) WCX_PREP_CASE(7) WCX_PREP_CASE(8) WCX_PREP_CASE(10) WCX_PREP_CASE(12)
     WCX_PREP_CASE(14) WCX_PREP_CASE(16) WCX_PREP_CASE(20) WCX_PREP_CASE(24) WCX_PREP_CASE(28)
+    WCX_PREP_CASE(40) WCX_PREP_CASE(48) WCX_PREP_CASE(56) WCX_PREP_CASE(64)
     default:
       k_screen_prep<32><<<gprep, NT, 0, st>>>(Xr, PB, S, Sp, cmean, perm, glob, F, info);
       k_screen_prep<32><<<gprep_s, NT, 0, st>>>(Xr, P_s, S, Sp, cmean, perm2, glob, Fs, infs);
@@ -974,7 +986,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     WCX_HIP(hipMemsetAsync(d_seq, 0, (size_t)(NQb + 1) * 4, st));
     SymArgs a;
     a.F = F; a.tinfo = tinfo; a.tmin = tmin; a.tchr = tchr; a.glob = glob; a.sl = sl; a.cnt = cnt_out;
-    a.flags = flags; a.stats = ctx->d_stats; a.dbg = ctx->debug_flags;
+    a.flags = flags; a.stats = ctx->d_stats; a.dbg = ctx->debug_flags; a.cap2 = cap2;
     a.pool = pool; a.pool_head = pool_head; a.pool_ovf = pool_head + 1; a.pool_cap = pool_cap;
     a.queue_head = pool_head + 2;
     a.desc = d_desc; a.n_desc = (int)descs.size(); a.total_items = total; a.seq = d_seq;
@@ -990,12 +1002,18 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
       wcx_set_error("symmetric screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
       return (int)WCX_ERR_HIP;
     }
-    k_sym_regroup<<<2048, NT, 0, st>>>(pool, pool_head, pool_head + 1, pool_cap, n_rows, sl, cnt_out, flags);
+    k_sym_regroup<<<2048, NT, 0, st>>>(pool, pool_head, pool_head + 1, pool_cap, n_rows, sl, cnt_out, flags,
+                                       cap2);
   }
   {
     const float gamma = (float)(16 * NK + 12) * 1.1920929e-7f;
     const unsigned gf = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
-    k_sym_final<<<gf, NT, 0, st>>>(info, glob, rowpos, n_rows, sl, cnt_out, flags, Dest, k, gamma);
+    if (cap2 == CAP2)
+      k_sym_final<CAP2 / 64><<<gf, NT, 0, st>>>(info, glob, rowpos, n_rows, sl, cnt_out, flags, Dest, k, gamma,
+                                                CAP);
+    else
+      k_sym_final<CAP2_BIG / 64><<<gf, NT, 0, st>>>(info, glob, rowpos, n_rows, sl, cnt_out, flags, Dest, k,
+                                                    gamma, REFINE_MAX);
   }
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_screen");
@@ -1008,7 +1026,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   rc = wcx_timer_begin(ctx, "topk_refine");
   if (rc) return rc;
   rc = wcx_refine_launch(ctx, Xr, S, Sp, tab, 0, n_rows, searched, sl, cnt_out, flags, perm, k, d_out_idx,
-                         d_out_dist, glob, CAP2);
+                         d_out_dist, glob, cap2);
   if (rc) return rc;
   rc = wcx_timer_end(ctx, "topk_refine");
   if (rc) return rc;
@@ -1033,8 +1051,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // entries; a hi+lo three-product form was measured 35 % slower end to end).  K = 16 NK holds the
   // S data columns + 4 augmented columns (see k_screen_prep); NK is rounded up to an instantiated
   // value.
-  static const int nk_list[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32};
-  int NK = 32;
+  static const int nk_list[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+  int NK = 64;
   for (int v : nk_list)
     if (16 * v >= S + 4) { NK = v; break; }
   // Kernel configuration: small K keeps TWO target tiles per wave in registers (every candidate
@@ -1046,8 +1064,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // Kernel configuration (measured on MI355X): 128 targets per workgroup; small K:
   // 64 candidates per iteration, 3 waves per SIMD, LDS-DMA ring of 3; large K: 2 waves per SIMD
   // (the targets' fragments alone take 4 NK registers), LDS-DMA double buffer.
+  // More than 508 samples (NK = 40 .. 64): the fragments of a wave's 32 targets alone take 160 .. 256
+  // registers -- one wave per SIMD on the unified VGPR + AGPR file, one workgroup per CU, a double
+  // buffer of 40 .. 64 KB groups in LDS.
   if (NK <= 8) { cfg.ctg = 2; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 3; cfg.ring = 3; }
-  else { cfg.ctg = NK <= 16 ? 2 : 1; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 2; cfg.ring = 2; }
+  else if (NK <= 32) { cfg.ctg = NK <= 16 ? 2 : 1; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 2; cfg.ring = 2; }
+  else { cfg.ctg = 1; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 1; cfg.ring = 2; }
   if (const char *e = getenv("WCX_SCREEN_TILE")) {     // testing / tuning: "ctg,tt,wpb,lb,ring"
     int a = 0, b = 0, c = 0, d = 0, r = 0;
     if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &r) == 5) {
@@ -1151,6 +1173,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       return screen_sym_path(ctx, dXs, B, S, chr_cum, n_chr, blocks, cfg, SF, cut_r1, slots, k, d_out_idx,
                              d_out_dist);
   }
+  // the one-directional sweep keeps k + its filter margin inside shortlists of CAP entries: a larger
+  // refsize of a row shard / gonosomal pass goes to the exact kernel
+  if (k > KMAX_ONE_DIR)
+    return wcx_topk_exact_launch(ctx, dXs, B, S, exact_blocks, row_begin, n_rows, k, d_out_idx, d_out_dist);
   // scratch layout
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
@@ -1251,6 +1277,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     WCX_PREP_CASE(1) WCX_PREP_CASE(2) WCX_PREP_CASE(3) WCX_PREP_CASE(4) WCX_PREP_CASE(5)
     WCX_PREP_CASE(6) WCX_PREP_CASE(7) WCX_PREP_CASE(8) WCX_PREP_CASE(10) WCX_PREP_CASE(12)
     WCX_PREP_CASE(14) WCX_PREP_CASE(16) WCX_PREP_CASE(20) WCX_PREP_CASE(24) WCX_PREP_CASE(28)
+    WCX_PREP_CASE(40) WCX_PREP_CASE(48) WCX_PREP_CASE(56) WCX_PREP_CASE(64)
     default: k_screen_prep<32><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info); break;
 #undef WCX_PREP_CASE
   }

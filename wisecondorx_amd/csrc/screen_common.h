@@ -11,7 +11,11 @@ constexpr int NT = 256;      // threads of the helper kernels (prep, merge, refi
 constexpr int CT = 64;       // sweep positions are padded to a multiple of this (gmask granule)
 constexpr int CAP = 1024;    // shortlist capacity per target
 constexpr int LIM = CAP - CT;
-constexpr int CAP2 = 2048;   // list capacity per row in the symmetric sweep (fixed thresholds, no cuts)
+constexpr int CAP2 = 2048;   // list capacity per row in the symmetric sweep (fixed thresholds, no cuts);
+constexpr int CAP2_BIG = 4096;   // ... for refsize > 448 (SymArgs::cap2 carries the one in use)
+constexpr int KMAX_SCREEN = 1024;    // largest refsize of the MFMA paths (symmetric sweep)
+constexpr int KMAX_ONE_DIR = 800;    // ... of the one-directional sweep: k + filter margin must stay below LIM
+constexpr int SMAX_SCREEN = 1020;    // most samples: K = 16 NK >= S + 4, NK <= 64 (target fragments in registers)
 
 struct RowInfo {
   float nb;  // |a~|^2
@@ -77,7 +81,8 @@ struct SymArgs {
   const float *tmin;          // [tile] min theta over the tile's rows
   const unsigned char *tchr;  // [tile] chromosome of the (pure) tile; 255 = no rows
   const ScreenGlobals *glob;  // n_tiles
-  uint2 *sl;                  // [row][CAP2]
+  uint2 *sl;                  // [row][cap2]
+  int cap2;                   // list capacity per row: CAP2 or CAP2_BIG
   int *cnt;                   // [row] entries appended (device-scope atomic)
   unsigned int *flags;        // [row] 1 = redo exactly
   unsigned long long *stats;
@@ -94,6 +99,8 @@ struct SymArgs {
 int wcx_sym_launch_k1(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_sym_launch_k2(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_sym_launch_k3(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_sym_launch_k4(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_sym_launch_k5(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
 
 // Screen kernel configuration: K = 16 nk, ctg candidate sub-tiles per iteration, tt target tiles
 // per wave, wpb waves per workgroup (targets per workgroup = 32 tt wpb), lb = waves per SIMD the
@@ -108,6 +115,8 @@ int wcx_screen_launch_k3(const ScreenCfg &c, const ScreenArgs &a, unsigned grid,
 int wcx_screen_launch_k4(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_screen_launch_k5(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_screen_launch_k6(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_screen_launch_k7(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_screen_launch_k8(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
 
 struct ChrTab {
   int n_chr;
@@ -120,3 +129,5 @@ int wcx_refine_launch(wcx_ctx *ctx, const double *Xr, int S, int Sp, const ChrTa
                       const uint2 *sl, const int *cnt_out, const unsigned int *flags,
                       const int *perm, int k, int32_t *d_out_idx, double *d_out_dist,
                       ScreenGlobals *glob, int sl_stride = CAP);
+// most shortlist entries per row the refine accepts (above: the row is flagged for the exact kernel)
+constexpr int REFINE_MAX = 2048;

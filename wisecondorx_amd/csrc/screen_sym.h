@@ -115,7 +115,7 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
   const unsigned int posj = (unsigned int)(t * 32 + l32);
   
   // column-direction list of my row (exclusive launches: register counter, see below)
-  uint2 *mine = A.sl + (int64_t)(rowj >= 0 ? rowj : 0) * CAP2;
+  uint2 *mine = A.sl + (int64_t)(rowj >= 0 ? rowj : 0) * A.cap2;
   // (device-scope accesses: the previous item of this quad may have run on another XCD)
   int cntr = (excl && rowj >= 0) ? __hip_atomic_load(&A.cnt[rowj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
   // Records (row, partner position, d~ bits): hits that may not touch a row's counter directly
@@ -324,7 +324,7 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
             if (anym & (0x8000u >> r)) {
               asm volatile("" ::: "memory");               // (keeps the two tests separate)
               if (pm & (0x8000u >> r)) {
-                if (ofs < CAP2)
+                if (ofs < A.cap2)
                   mine[ofs] = make_uint2(__float_as_uint(-2.f * acc[s][r]),
                                          cposb + (unsigned int)(8 * (r >> 2) + (r & 3)));
                 ++ofs;
@@ -391,7 +391,7 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
   flush();
   if (excl && hf == 0 && rowj >= 0) {
     __hip_atomic_store(&A.cnt[rowj], cntr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cntr > CAP2) A.flags[rowj] = 1u;
+    if (cntr > A.cap2) A.flags[rowj] = 1u;
   }
 }
 
