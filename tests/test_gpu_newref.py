@@ -168,9 +168,8 @@ def test_screen_real_valued_outlier_scale(nt):
 
 @pytest.mark.parametrize("k", [700, 1500])
 def test_large_refsize(nt, k):
-    """Large refsizes on a small matrix: k = 700 through the one-directional screen (its shortlists
-    hold k + margin up to refsize 800) and the 16-entries-per-lane refine, k = 1500 (beyond the screen's
-    1024) through the all-fp64 search; + the 16/32-entries-per-lane median of the null ratios."""
+    """Large refsizes on a small matrix (beyond the one-directional screen's 512, and beyond the
+    symmetric sweep's 1024): the all-fp64 search; + the 16/32-entries-per-lane median of the null ratios."""
     from wisecondorx_amd.synth import corrected_matrix
     X, mbpc, cum = corrected_matrix([900, 700, 500, 300], 20, seed=k)
     idx, dist = nt.get_ref_for_rows(X, cum, k, 0, cum[-1])
@@ -213,10 +212,11 @@ def test_beyond_screen_sample_limit_falls_back_to_exact(nt):
         nt.get_ref_for_rows(X, cum, 30, 100, 200, mode=2)
 
 
-@pytest.mark.parametrize("k,screened", [(800, True), (801, False)])
+@pytest.mark.parametrize("k,screened", [(300, True), (512, None), (513, False)])
 def test_one_directional_refsize_limit(nt, k, screened):
-    """A row shard (one-directional sweep, shortlists of 1024 entries) screens refsizes up to 800; one
-    more goes to the exact kernel.  Same bits either way."""
+    """A row shard (one-directional sweep, shortlists of 1024 entries) screens refsizes up to 512 (where
+    the lists of a small, noisy problem may overflow: those rows are redone exactly); one more goes to
+    the exact kernel as a whole.  Same bits either way."""
     from wisecondorx_amd import _lib
     from wisecondorx_amd.synth import corrected_matrix
     X, mbpc, cum = corrected_matrix([1500, 1300, 1200, 1000], 40, seed=k)
@@ -225,7 +225,10 @@ def test_one_directional_refsize_limit(nt, k, screened):
     oi, od = CO.get_reference_rows(np.ascontiguousarray(np.asarray(X).T), cum, 200, 700, k)
     assert np.array_equal(idx, oi)
     assert np.array_equal(dist, od)
-    assert (st["refined"] > 0) == screened       # (pairs the refine re-evaluated: the screen ran)
+    if screened is not None:
+        assert (st["refined"] > 0) == screened       # (pairs the refine re-evaluated: the screen ran)
+    if screened:
+        assert st["fallback_rows"] <= 5
 
 
 def test_null_ratios_nan_duplicates_and_ties(nt):

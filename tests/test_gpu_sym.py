@@ -43,10 +43,10 @@ SHAPES = [
     ([1700, 1500, 1300, 1200, 1000, 0, 700, 650], 150, 100, 8),   # K = 160 (NK 10), an empty chromosome
     ([2100, 1900, 1600, 1400, 1300, 1100], 250, 200, 8),           # K = 256 (NK 16): where the default policy starts
     # more than 508 samples: NK = 40 .. 64, one wave per SIMD (round 5; the all-fp64 search before)
-    ([2300, 2000, 1800, 1500, 1300, 1000], 509, 300, 8),           # K = 640 (NK 40)
-    ([2200, 2000, 1700, 1500, 1200, 900], 640, 300, 8),            # K = 768 (NK 48)
+    ([2900, 2600, 2300, 2000, 1700, 1400], 509, 300, 8),           # K = 640 (NK 40)
+    ([3000, 2600, 2300, 1900, 1600, 1300], 640, 300, 8),           # K = 768 (NK 48)
     ([2000, 1800, 1700, 1400, 1100, 900], 800, 100, 8),            # K = 896 (NK 56)
-    ([2400, 2100, 1800, 1500, 1300, 1000], 1000, 300, 8),          # K = 1024 (NK 64)
+    ([3000, 2700, 2300, 2000, 1700, 1300], 1000, 300, 8),          # K = 1024 (NK 64)
     # refsize beyond 448: lists of 4096 entries, 16 / 32 entries per lane in the refine
     ([5200, 4700, 4100, 3600, 3300, 2900, 2500, 2200], 60, 600, 4),
     ([5600, 5100, 4500, 4000, 3500, 3000, 2600, 2300], 100, 1000, 4),

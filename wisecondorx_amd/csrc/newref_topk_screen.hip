@@ -38,6 +38,7 @@
 #include <cstdlib>
 
 #include "screen_kernel.h"
+#include "screen_common.h"
 
 namespace {
 
@@ -129,11 +130,14 @@ __global__ void k_transpose(const double *__restrict__ Xs, int64_t B, int S, int
 constexpr int NBUCKET = 128;            // norm buckets: float bits >> 20 (12.5 % steps)
 constexpr int NCELL = NBUCKET * 32;     // (bucket, chromosome) cells
 
+constexpr int HUB_BINS = 65536;          // histogram of (float bits of |a|^2) >> 16: 0.8 % steps in norm
 __global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xs, int64_t B, int S,
                                                  int Sp, const double *__restrict__ cmean,
                                                  ChrTab chr, ScreenGlobals *__restrict__ glob,
                                                  unsigned int *__restrict__ rbits,
-                                                 int *__restrict__ rchr) {
+                                                 int *__restrict__ rchr,
+                                                 unsigned int *__restrict__ rfine = nullptr,
+                                                 int *__restrict__ hubhist = nullptr) {
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
   if (b >= B) return;
   float s = 0.f;
@@ -150,6 +154,39 @@ __global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xs, 
     atomicMax(&glob->uinv, 0xffffffffu - u);
   }
   rbits[b] = u;
+  if (rfine) {
+    const unsigned int f = s < HUGE_VALF ? __float_as_uint(s) >> 16 : 0xffffffffu;
+    rfine[b] = f;
+    if (f < (unsigned int)HUB_BINS) atomicAdd(&hubhist[f], 1);
+  }
+}
+
+// Hub region = the rows below a norm quantile: the smallest key q with at least `want` rows at or below
+// it (the whole last histogram bin is taken: a few rows more than asked for).
+__global__ __launch_bounds__(1024) void k_hub_cut(const int *__restrict__ hubhist, int want,
+                                                  ScreenGlobals *__restrict__ glob) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  constexpr int PER = HUB_BINS / 1024;
+  int s = 0;
+  for (int i = 0; i < PER; ++i) s += hubhist[t * PER + i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  const int before = part[t] - s;
+  if (before < want && part[t] >= want) {           // the quantile lies in this thread's bins
+    int run = before;
+    for (int i = 0; i < PER; ++i) {
+      run += hubhist[t * PER + i];
+      if (run >= want) { glob->hub_key = (unsigned int)(t * PER + i); break; }
+    }
+  }
+  if (t == 1023 && part[t] < want) glob->hub_key = (unsigned int)(HUB_BINS - 1);   // (fewer finite rows)
 }
 
 // Cell histogram with workgroup-private LDS counters (the rows pile into a few dozen cells: global
@@ -161,8 +198,10 @@ __global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict_
                                                  const int *__restrict__ rchr, int64_t B, int SF,
                                                  int fair_sample,
                                                  const ScreenGlobals *__restrict__ glob,
-                                                 int *__restrict__ rkey, int *__restrict__ cellcnt) {
+                                                 int *__restrict__ rkey, int *__restrict__ cellcnt,
+                                                 const unsigned int *__restrict__ gate = nullptr) {
   __shared__ int lh[2 * NCELL];
+  if (gate && !*gate) return;
   for (int i = threadIdx.x; i < 2 * NCELL; i += NT) lh[i] = 0;
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
@@ -189,8 +228,10 @@ __global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict_
 // Exclusive scan of the cell counts -> first sweep position of every cell; the main region starts
 // `pad` positions later so that the sample region ends on a group boundary.
 __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cellcnt,
-                                                     int *__restrict__ cursor, int pad) {
+                                                     int *__restrict__ cursor, int pad,
+                                                     const unsigned int *__restrict__ gate = nullptr) {
   __shared__ int part[1024];
+  if (gate && !*gate) return;
   const int t = threadIdx.x;
   constexpr int PER = 2 * NCELL / 1024;
   int loc[PER], s = 0;
@@ -212,8 +253,10 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cel
 // Rows -> sweep positions: each workgroup reserves one range per cell it touches.
 __global__ __launch_bounds__(NT) void k_scatter(const int *__restrict__ rkey, int64_t B,
                                                 int *__restrict__ cursor, int *__restrict__ perm,
-                                                int *__restrict__ rowpos) {
+                                                int *__restrict__ rowpos,
+                                                const unsigned int *__restrict__ gate = nullptr) {
   __shared__ int lh[2 * NCELL];
+  if (gate && !*gate) return;
   for (int i = threadIdx.x; i < 2 * NCELL; i += NT) lh[i] = 0;
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
@@ -232,9 +275,10 @@ __global__ __launch_bounds__(NT) void k_scatter(const int *__restrict__ rkey, in
 
 __global__ __launch_bounds__(NT) void k_group_mask(const int *__restrict__ perm,
                                                    const int *__restrict__ rchr, int64_t n_groups,
-                                                   unsigned int *__restrict__ gmask) {
+                                                   unsigned int *__restrict__ gmask,
+                                                   const unsigned int *__restrict__ gate = nullptr) {
   const int64_t g = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (g >= n_groups) return;
+  if (g >= n_groups || (gate && !*gate)) return;
   unsigned int m = 0;
   for (int i = 0; i < CT; ++i) {
     const int row = perm[g * CT + i];
@@ -255,9 +299,10 @@ template <int NK>
 __global__ __launch_bounds__(NT) void k_screen_prep(
     const double *__restrict__ Xr, int64_t Bpad, int S, int Sp,
     const double *__restrict__ cmean, const int *__restrict__ perm,
-    ScreenGlobals *__restrict__ glob, half8 *__restrict__ F, RowInfo *__restrict__ info) {
+    ScreenGlobals *__restrict__ glob, half8 *__restrict__ F, RowInfo *__restrict__ info,
+    const unsigned int *__restrict__ gate = nullptr) {
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (b >= Bpad) return;
+  if (b >= Bpad || (gate && !*gate)) return;
   const int64_t row = perm[b];
   // scale 2^p so that the largest |a| lands in [1024, 2048): |a~|^2 <= 508 * 2^22 < 2^31.1 keeps
   // nb/65536 and any threshold/65536 inside the fp16 range; with more than 508 samples (NK > 32) one
@@ -482,13 +527,15 @@ constexpr float SYM_DMAX = 4.0e9f;         // thresholds at or above this: the r
 
 constexpr int SYM_NSUB = 4;                // norm sub-steps inside a class (order only: no padding)
 
+// rfine != nullptr: the rows at or below the hub key form the HUB region, the head of the order (their
+// own (class, chromosome) cells, in front of everybody else's): cells [0, SYM_NCELL) hubs, the rest after.
 __global__ __launch_bounds__(NT) void k_sym_hist(const unsigned int *__restrict__ rbits,
                                                  const int *__restrict__ rchr, int64_t B,
                                                  const ScreenGlobals *__restrict__ glob,
                                                  int *__restrict__ rkey, int *__restrict__ cellcnt,
-                                                 int suborder) {
-  __shared__ int lh[SYM_NCELL * SYM_NSUB];
-  for (int i = threadIdx.x; i < SYM_NCELL * SYM_NSUB; i += NT) lh[i] = 0;
+                                                 int suborder, const unsigned int *__restrict__ rfine) {
+  __shared__ int lh[2 * SYM_NCELL * SYM_NSUB];
+  for (int i = threadIdx.x; i < 2 * SYM_NCELL * SYM_NSUB; i += NT) lh[i] = 0;
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
   if (b < B) {
@@ -503,28 +550,34 @@ __global__ __launch_bounds__(NT) void k_sym_hist(const unsigned int *__restrict_
     // inside a (class, chromosome) cell the rows are ordered by the finer norm steps: the rows of a
     // tile then have similar norms -- and similar thresholds, which is what the row-direction gate
     // of the symmetric sweep (one threshold per streamed tile) wants
-    const int key = ((int)cls * 32 + rchr[b]) * SYM_NSUB + (int)sub;
+    const bool hub = rfine && rfine[b] <= glob->hub_key;
+    const int key = (((hub ? 0 : SYM_NCLS) + (int)cls) * 32 + rchr[b]) * SYM_NSUB + (int)sub;
     rkey[b] = key;
     atomicAdd(&lh[key], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < SYM_NCELL * SYM_NSUB; i += NT)
+  for (int i = threadIdx.x; i < 2 * SYM_NCELL * SYM_NSUB; i += NT)
     if (lh[i]) atomicAdd(&cellcnt[i], lh[i]);
 }
 
 // First sweep position of every cell (cells padded to whole tiles), the chromosome of every tile,
-// the number of tiles in use (rounded up to whole quads).  tchr was preset to 255.
+// the number of tiles in use (rounded up to whole quads) and of the hub region (cells [0, SYM_NCELL)).
+// tchr was preset to 255.  Thread t owns the cells 2 t and 2 t + 1.
 __global__ __launch_bounds__(SYM_NCELL) void k_sym_scan(const int *__restrict__ cellcnt,
                                                         int *__restrict__ cursor,
                                                         unsigned char *__restrict__ tchr,
                                                         ScreenGlobals *__restrict__ glob) {
   __shared__ int part[SYM_NCELL];
   const int t = threadIdx.x;
-  int sub[SYM_NSUB], total = 0;
+  int sub[2][SYM_NSUB], padded[2];
 #pragma unroll
-  for (int j = 0; j < SYM_NSUB; ++j) { sub[j] = cellcnt[t * SYM_NSUB + j]; total += sub[j]; }
-  const int padded = (total + 31) & ~31;
-  part[t] = padded;
+  for (int c = 0; c < 2; ++c) {
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < SYM_NSUB; ++j) { sub[c][j] = cellcnt[(2 * t + c) * SYM_NSUB + j]; total += sub[c][j]; }
+    padded[c] = (total + 31) & ~31;
+  }
+  part[t] = padded[0] + padded[1];
   __syncthreads();
   for (int off = 1; off < SYM_NCELL; off <<= 1) {
     const int v = t >= off ? part[t - off] : 0;
@@ -532,12 +585,17 @@ __global__ __launch_bounds__(SYM_NCELL) void k_sym_scan(const int *__restrict__ 
     part[t] += v;
     __syncthreads();
   }
-  const int start = part[t] - padded;
-  int run = start;
+  int start = part[t] - padded[0] - padded[1];
+  if (2 * t == SYM_NCELL) glob->n_hub_tiles = (unsigned int)(start >> 5);
 #pragma unroll
-  for (int j = 0; j < SYM_NSUB; ++j) { cursor[t * SYM_NSUB + j] = run; run += sub[j]; }
-  for (int i = start >> 5; i < (start + padded) >> 5; ++i) tchr[i] = (unsigned char)(t & 31);
-  if (t == SYM_NCELL - 1) glob->n_tiles = (unsigned int)((((start + padded) >> 5) + 3) & ~3);
+  for (int c = 0; c < 2; ++c) {
+    int run = start;
+#pragma unroll
+    for (int j = 0; j < SYM_NSUB; ++j) { cursor[(2 * t + c) * SYM_NSUB + j] = run; run += sub[c][j]; }
+    for (int i = start >> 5; i < (start + padded[c]) >> 5; ++i) tchr[i] = (unsigned char)((2 * t + c) & 31);
+    start += padded[c];
+  }
+  if (t == SYM_NCELL - 1) glob->n_tiles = (unsigned int)(((start >> 5) + 3) & ~3);
 }
 
 // After the sampled pre-pass: the estimated threshold of every row, in screen-distance space
@@ -551,10 +609,11 @@ __global__ __launch_bounds__(NT) void k_sym_setup(const int *__restrict__ perm,
                                                   int *__restrict__ cnt, unsigned int *__restrict__ flags,
                                                   float *__restrict__ Dest,
                                                   unsigned int *__restrict__ tinfo,
-                                                  float *__restrict__ tmin) {
+                                                  float *__restrict__ tmin,
+                                                  const unsigned int *__restrict__ gate = nullptr) {
   const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
   const int64_t tile = p >> 5;
-  if (tile >= (int64_t)glob->n_tiles) return;
+  if (tile >= (int64_t)glob->n_tiles || (gate && !*gate)) return;
   const int l = (int)(p & 31);
   const int row = perm[p];
   float theta = HUGE_VALF;
@@ -583,7 +642,9 @@ __global__ __launch_bounds__(NT) void k_sym_regroup(const uint4 *__restrict__ po
                                                     const unsigned int *__restrict__ pool_ovf,
                                                     unsigned int pool_cap, int64_t n_rows,
                                                     uint2 *__restrict__ sl, int *__restrict__ cnt,
-                                                    unsigned int *__restrict__ flags, int cap2) {
+                                                    unsigned int *__restrict__ flags, int cap2,
+                                                    const unsigned int *__restrict__ gate = nullptr) {
+  if (gate && !*gate) return;
   if (*pool_ovf) {                           // records were lost: every row goes to the exact kernel
     for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * NT)
       flags[r] = 1u;
@@ -612,7 +673,8 @@ __global__ __launch_bounds__(NT) void k_sym_final(const RowInfo *__restrict__ in
                                                   uint2 *__restrict__ sl, int *__restrict__ cnt,
                                                   unsigned int *__restrict__ flags,
                                                   const float *__restrict__ Dest, int k, float gamma,
-                                                  int max_keep) {
+                                                  int max_keep, const unsigned int *__restrict__ gate) {
+  if (gate && !*gate) return;
   const int lane = wcx::lane_id();
   const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
@@ -675,6 +737,40 @@ __global__ __launch_bounds__(NT) void k_sym_final(const RowInfo *__restrict__ in
   }
 }
 
+// After the first attempt (thresholds from the hub counts): rows the final cut could not finish.  More
+// than the device-wide redo takes -- data whose neighbours are not its low-norm rows, lists overflowed --
+// opens the gate of the second attempt (sampled pre-pass, distribution-free, + another sweep).
+constexpr unsigned int HUB_FAIL_MAX = 96;
+__global__ __launch_bounds__(NT) void k_hub_count_failed(const unsigned int *__restrict__ flags, int64_t n_rows,
+                                                         unsigned int *__restrict__ n_failed) {
+  int c = 0;
+  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * NT)
+    c += flags[r] ? 1 : 0;
+  c = wcx::wave_sum_i(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_failed, (unsigned int)c);
+}
+__global__ void k_hub_verdict(const unsigned int *__restrict__ n_failed, unsigned int *__restrict__ gate,
+                              unsigned long long *__restrict__ stats) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const unsigned int bad = *n_failed > HUB_FAIL_MAX ? 1u : 0u;
+    *gate = bad;
+    if (stats) stats[14] = bad ? *n_failed : 0ull;       // (diagnostics: rows that sent the sweep round again)
+  }
+}
+// Second attempt only: lists, flags, record pool, work queue and sequence counters back to empty.
+__global__ __launch_bounds__(NT) void k_gate_reset(const unsigned int *__restrict__ gate, int64_t n_rows,
+                                                   int *__restrict__ cnt, unsigned int *__restrict__ flags,
+                                                   unsigned int *__restrict__ heads, int *__restrict__ seq,
+                                                   int n_seq) {
+  if (!*gate) return;
+  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * NT) {
+    cnt[r] = 0;
+    flags[r] = 0u;
+    if (r < n_seq) seq[r] = 0;
+    if (r < 3) heads[r] = 0u;                      // pool head | pool overflow | queue head
+  }
+}
+
 }  // namespace
 
 // Host side --------------------------------------------------------------------------------
@@ -730,26 +826,48 @@ static int sym_dispatch(int nk, int ctg, int lb, int ring, const SymArgs &a, uns
   return rc;
 }
 
+static int count_dispatch(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds,
+                          hipStream_t st) {
+  int rc = wcx_count_launch_k1(nk, ctg, lb, ring, a, grid, lds, st);
+  if (rc < 0) rc = wcx_count_launch_k2(nk, ctg, lb, ring, a, grid, lds, st);
+  if (rc < 0) rc = wcx_count_launch_k3(nk, ctg, lb, ring, a, grid, lds, st);
+  return rc;
+}
+
 // The search of ALL rows against all rows with the symmetric sweep (screen_sym.h):
-//   order A   the sample rows (b = 0 mod SF) best-first, own small fragment array F_s
-//   order B   all rows by (norm class, chromosome), cells padded to tiles: fragment array F
-//   pre-pass  one-directional kernel, targets = all rows (fragments from F), candidates = F_s:
-//             streaming top-r -> an estimated threshold per row (its list entries are dropped)
-//   sweep     k_screen_sym over all tile pairs {a < b}, fixed thresholds, atomic appends
-//   final cut proves the estimate per row or flags it; refine; exact redo of flagged rows
+//   order B   all rows by (hub region first, norm class, chromosome), cells padded to tiles: fragments F
+//   attempt 1 (K >= 256, B >= 32768): thresholds from the hub counts (screen_count.h: every row against
+//             the low-norm 1/32 of the rows, no lists), k_screen_sym over all tile pairs {a < b} with
+//             those FIXED thresholds, final cut: proves the threshold per row or flags it
+//   verdict   more than HUB_FAIL_MAX rows flagged (data without hubs): the gate of attempt 2 opens
+//   attempt 2 (always launched, returns at once behind a closed gate; the only attempt for small K):
+//     order A   the sample rows (b = 0 mod SF) best-first, own small fragment array F_s
+//     pre-pass  one-directional kernel, targets = all rows (fragments from F), candidates = F_s:
+//               streaming top-r -> an estimated threshold per row (its list entries are dropped)
+//     sweep + final cut as above
+//   refine; exact redo of flagged rows
 static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const int64_t *chr_cum,
                            int n_chr, const std::vector<ScreenBlock> &blocks, const ScreenCfg &cfg,
-                           int SF, int cut_r, int slots, int k, int32_t *d_out_idx,
+                           int SF, int cut_r, int raw_est, int slots, int k, int32_t *d_out_idx,
                            double *d_out_dist) {
   const int NK = cfg.nk, CTG = cfg.ctg, GRr = CTG * 32;
   const int Sp = row_pitch(S);
   const int64_t n_rows = B;
   // list capacity per row: the estimates admit ~4 k entries at k = 300, ~2.7 k at k = 1000
   const int cap2 = k <= 448 ? CAP2 : CAP2_BIG;
+  // hub-count estimates (attempt 1): WCX_SYM_HUB=0 turns them off; the region is 1 / WCX_HUB_FRAC of the
+  // rows, at least 6 x the entries wanted below an estimate (1.18 k: the k-th neighbour's filter bound
+  // ranks ~1.14 k)
+  const int need = (int)(1.18 * k) + 8;
+  const int hub_frac = env_int("WCX_HUB_FRAC", 32);
+  int64_t hub_rows = hub_frac > 1 ? B / hub_frac : 0;
+  if (hub_rows < 6 * (int64_t)need) hub_rows = 6 * (int64_t)need;
+  const bool use_hub = env_int("WCX_SYM_HUB", 1) != 0 && NK >= 16 && hub_frac > 1 && hub_rows * 6 <= B;
+  const int n1_tiles = env_int("WCX_HUB_N1", 16);
   const int64_t n_s = (B + SF - 1) / SF;
   const int64_t P_s = (n_s + CT - 1) / CT * CT;
   const int64_t Bpad2 = P_s + ((B - n_s) + CT - 1) / CT * CT;       // positions of the two-region order
-  const int64_t NTb = (((B + 31) / 32 + (int64_t)SYM_NCLS * n_chr + 4) + 7) / 8 * 8;   // tile bound
+  const int64_t NTb = (((B + 31) / 32 + (int64_t)2 * SYM_NCLS * n_chr + 4) + 7) / 8 * 8;   // tile bound
   const int64_t PB = NTb * 32;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
@@ -765,6 +883,8 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   const size_t o_rpos = carve((size_t)B * 4);
   const size_t o_rpos2 = carve((size_t)B * 4);
   const size_t o_rbit = carve((size_t)B * 4);
+  const size_t o_rfin = carve((size_t)B * 4);
+  const size_t o_hubh = carve((size_t)HUB_BINS * 4);
   const size_t o_rchr = carve((size_t)B * 4);
   const size_t o_rkey = carve((size_t)B * 4);
   const size_t o_cell = carve((size_t)2 * NCELL * 4);
@@ -776,9 +896,11 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   const size_t o_dest = carve((size_t)n_rows * 4);
   // records: row-direction hits (a few per cent of all) + everything from launches that split a
   // target quad over several work items (the high, hub-free tiles)
-  const unsigned int pool_cap = (unsigned int)(n_rows * 1024 < 200000000ll ? n_rows * 1024 : 200000000ll);
+  // (a small matrix splits most of its chunks: nearly every hit is a record then -- half a list per row)
+  const int64_t pool_want = n_rows * (int64_t)(cap2 / 2);
+  const unsigned int pool_cap = (unsigned int)(pool_want < 200000000ll ? pool_want : 200000000ll);
   const size_t o_pool = carve((size_t)pool_cap * 16);
-  const size_t o_phead = carve(256);      // pool head | pool overflow | queue head
+  const size_t o_phead = carve(256);      // pool head | pool overflow | queue head | gate | failed rows
   const size_t o_desc = carve(256 * sizeof(SymDesc));
   const size_t o_seq = carve((size_t)(NTb / 4 + 1) * 4);
   const size_t o_sl = carve((size_t)n_rows * cap2 * 8);
@@ -808,6 +930,8 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   int *rowpos = reinterpret_cast<int *>(base + o_rpos);
   int *rowpos2 = reinterpret_cast<int *>(base + o_rpos2);
   unsigned int *rbits = reinterpret_cast<unsigned int *>(base + o_rbit);
+  unsigned int *rfine = reinterpret_cast<unsigned int *>(base + o_rfin);
+  int *hubhist = reinterpret_cast<int *>(base + o_hubh);
   int *rchr = reinterpret_cast<int *>(base + o_rchr);
   int *rkey = reinterpret_cast<int *>(base + o_rkey);
   int *cellcnt = reinterpret_cast<int *>(base + o_cell);
@@ -819,6 +943,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   float *Dest = reinterpret_cast<float *>(base + o_dest);
   uint4 *pool = reinterpret_cast<uint4 *>(base + o_pool);
   unsigned int *pool_head = reinterpret_cast<unsigned int *>(base + o_phead);
+  unsigned int *d_gate = pool_head + 3, *d_failed = pool_head + 4;
   SymDesc *d_desc = reinterpret_cast<SymDesc *>(base + o_desc);
   int *d_seq = reinterpret_cast<int *>(base + o_seq);
   uint2 *sl = reinterpret_cast<uint2 *>(base + o_sl);
@@ -831,6 +956,9 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   unsigned int *d_nredo = reinterpret_cast<unsigned int *>(base + o_nredo);
   TopkBlock *d_rtile = reinterpret_cast<TopkBlock *>(base + o_rtile);
   int32_t *d_rlist = reinterpret_cast<int32_t *>(base + o_rlist);
+  // the gate of the second attempt: closed until the verdict opens it; without a first attempt the
+  // second one is the only one and runs ungated
+  const unsigned int *gate2 = use_hub ? d_gate : nullptr;
 
   hipStream_t st = ctx->stream;
   WCX_HIP(hipMemsetAsync(glob, 0, sizeof(ScreenGlobals), st));
@@ -860,37 +988,38 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   tab.n_chr = n_chr;
   for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
   const unsigned gb = (unsigned)((B + NT - 1) / NT);
-  k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
-  // order A: the two-region best-first order; only its sample region [0, P_s) is used
-  WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
-  WCX_HIP(hipMemsetAsync(perm2, 0xff, (size_t)Bpad2 * 4, st));
-  k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, SF, 0, glob, rkey, cellcnt);
-  k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, (int)(P_s - n_s));
-  k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm2, rowpos2);
-  k_group_mask<<<(unsigned)((P_s / CT + NT - 1) / NT), NT, 0, st>>>(perm2, rchr, P_s / CT, gmask);
-  // order B: (norm class, chromosome) cells padded to tiles
+  if (use_hub) {
+    WCX_HIP(hipMemsetAsync(hubhist, 0, (size_t)HUB_BINS * 4, st));
+    k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr, rfine, hubhist);
+    k_hub_cut<<<1, 1024, 0, st>>>(hubhist, (int)hub_rows, glob);
+  } else {
+    k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
+  }
+  // order B: (hub region | the rest) x (norm class, chromosome) cells padded to tiles
   WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
   WCX_HIP(hipMemsetAsync(cursor, 0, (size_t)2 * NCELL * 4, st));
   WCX_HIP(hipMemsetAsync(perm, 0xff, (size_t)PB * 4, st));
   WCX_HIP(hipMemsetAsync(tchr, 0xff, (size_t)NTb, st));
-  k_sym_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt, env_int("WCX_SYM_SUBORDER", 1));
+  static_assert(2 * SYM_NCELL * SYM_NSUB <= 2 * NCELL, "cell tables");
+  k_sym_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt, env_int("WCX_SYM_SUBORDER", 1),
+                                use_hub ? rfine : nullptr);
   k_sym_scan<<<1, SYM_NCELL, 0, st>>>(cellcnt, cursor, tchr, glob);
   k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
   const unsigned gprep = (unsigned)((PB + NT - 1) / NT), gprep_s = (unsigned)((P_s + NT - 1) / NT);
-  switch (NK) {
-#define WCX_PREP_CASE(N) case N: \
-    k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, PB, S, Sp, cmean, perm, glob, F, info); \
-    k_screen_prep<N><<<gprep_s, NT, 0, st>>>(Xr, P_s, S, Sp, cmean, perm2, glob, Fs, infs); break;
-    WCX_PREP_CASE(1) WCX_PREP_CASE(2) WCX_PREP_CASE(3) WCX_PREP_CASE(4) WCX_PREP_CASE(5)
-    WCX_PREP_CASE(6) WCX_PREP_CASE(7) WCX_PREP_CASE(8) WCX_PREP_CASE(10) WCX_PREP_CASE(12)
-    WCX_PREP_CASE(14) WCX_PREP_CASE(16) WCX_PREP_CASE(20) WCX_PREP_CASE(24) WCX_PREP_CASE(28)
-    WCX_PREP_CASE(40) WCX_PREP_CASE(48) WCX_PREP_CASE(56) WCX_PREP_CASE(64)
-    default:
-      k_screen_prep<32><<<gprep, NT, 0, st>>>(Xr, PB, S, Sp, cmean, perm, glob, F, info);
-      k_screen_prep<32><<<gprep_s, NT, 0, st>>>(Xr, P_s, S, Sp, cmean, perm2, glob, Fs, infs);
-      break;
+  auto prep_frag = [&](int64_t n_pos, const int *pm, half8 *Fo, RowInfo *io, const unsigned int *gate) {
+    const unsigned g = (unsigned)((n_pos + NT - 1) / NT);
+    switch (NK) {
+#define WCX_PREP_CASE(N) case N: k_screen_prep<N><<<g, NT, 0, st>>>(Xr, n_pos, S, Sp, cmean, pm, glob, Fo, io, gate); break;
+      WCX_PREP_CASE(1) WCX_PREP_CASE(2) WCX_PREP_CASE(3) WCX_PREP_CASE(4) WCX_PREP_CASE(5)
+      WCX_PREP_CASE(6) WCX_PREP_CASE(7) WCX_PREP_CASE(8) WCX_PREP_CASE(10) WCX_PREP_CASE(12)
+      WCX_PREP_CASE(14) WCX_PREP_CASE(16) WCX_PREP_CASE(20) WCX_PREP_CASE(24) WCX_PREP_CASE(28)
+      WCX_PREP_CASE(40) WCX_PREP_CASE(48) WCX_PREP_CASE(56) WCX_PREP_CASE(64)
+      default: k_screen_prep<32><<<g, NT, 0, st>>>(Xr, n_pos, S, Sp, cmean, pm, glob, Fo, io, gate); break;
 #undef WCX_PREP_CASE
-  }
+    }
+  };
+  (void)gprep_s;
+  prep_frag(PB, perm, F, info, nullptr);
   WCX_HIP(hipGetLastError());
   rc = wcx_timer_end(ctx, "topk_prep");
   if (rc) return rc;
@@ -901,63 +1030,24 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   }
   rc = wcx_timer_begin(ctx, "topk_screen");
   if (rc) return rc;
-  rc = wcx_timer_begin(ctx, "topk_pre");
-  if (rc) return rc;
 
-  // ---- sampled pre-pass (one-directional kernel; candidates = the sample's fragments)
-  {
-    const int64_t group_bytes = (int64_t)GRr * NK * 32;
-    int64_t chunk_groups = ((int64_t)env_int("WCX_SCREEN_CHUNK_KB", NK > 16 ? 16384 : 3072) << 10) / group_bytes;
-    if (chunk_groups < 16) chunk_groups = 16;
-    if (chunk_groups > 4096) chunk_groups = 4096;
-    const size_t lds = (size_t)(cfg.ring >= 2 ? cfg.ring : 2) * (size_t)(CTG * NK * 64) * 16 +
-                       (size_t)(chunk_groups + 64) * 4;
-    ScreenArgs a;
-    a.F = Fs; a.Ft = F; a.info = info; a.glob = glob; a.perm = perm2; a.rowpos = rowpos; a.gmask = gmask;
-    a.blocks = d_blocks; a.sl = sl; a.cnt = cnt_out; a.flags = flags; a.g_state = g_state;
-    a.stats = ctx->d_stats; a.row_begin = 0; a.n_rows_all = n_rows;
-    a.k = k; a.dbg = (ctx->debug_flags & ~3) | env_int("WCX_PRE_DBG", 0); a.n_seg = 1; a.n_blocks = (int)blocks.size();
-    int trig_a = 4 * cut_r + 64;
-    if (trig_a > LIM) trig_a = LIM;
-    const int64_t g_end = P_s / GRr;
-    bool first = true;
-    for (int64_t g0 = 0; g0 < g_end; g0 += chunk_groups) {
-      const int64_t g1 = g0 + chunk_groups < g_end ? g0 + chunk_groups : g_end;
-      a.g_start = g0; a.g_count = (int)(g1 - g0);
-      a.cut_k = cut_r; a.cut_mode = 1; a.trig = trig_a; a.end_cut = g1 == g_end ? 1 : 0;
-      a.first = first ? 1 : 0;
-      first = false;
-      const int e = screen_dispatch(cfg, a, (unsigned)blocks.size(), lds, st);
-      if (e < 0) {
-        wcx_set_error("screen kernel configuration nk=%d ctg=%d is not instantiated", cfg.nk, cfg.ctg);
-        return (int)WCX_ERR_UNSUPPORTED;
-      }
-      if (e != 0) {
-        wcx_set_error("screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-        return (int)WCX_ERR_HIP;
-      }
-    }
-  }
-  k_sym_setup<<<gprep, NT, 0, st>>>(perm, info, glob, g_state, cnt_out, flags, Dest, tinfo, tmin);
-  WCX_HIP(hipGetLastError());
-  rc = wcx_timer_end(ctx, "topk_pre");
-  if (rc) return rc;
-
-  // ---- symmetric sweep: ONE persistent launch; the workgroups pull (chunk, quad) work items from a
+  // ---- the symmetric sweep: ONE persistent launch; the workgroups pull (chunk, quad) work items from a
   // device-side queue in chunk-major order (k_screen_sym).  As long as a chunk has at least `fill`
   // quads above it, a quad is one work item per chunk and its column-direction hits go straight to
   // the lists (exclusive items, ordered per quad); the chunks high in the order, which few quads
   // still stream, split a quad over several items that write records instead.
+  int64_t Cz = ((int64_t)env_int("WCX_SYM_CHUNK_KB", NK > 16 ? 8192 : 3072) << 10) / ((int64_t)NK * 1024);
+  Cz = Cz / 8 * 8;
+  if (Cz < 32) Cz = 32;
+  if (Cz > 8192) Cz = 8192;
+  while ((NTb + Cz - 1) / Cz > 256) Cz *= 2;                   // descriptor table: <= 256 chunks
+  const int glist_cap = (int)((Cz / CTG + 64 + 3) / 4 * 4);
+  const size_t lds_sym = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)cfg.ring * CTG * 256 +
+                         (size_t)glist_cap * 4 + (size_t)4 * 64 * 16;   // visit list, staged records
+  const int NQb = (int)(NTb / 4);
+  SymArgs sa;
+  int sym_grid = 0;
   {
-    int64_t Cz = ((int64_t)env_int("WCX_SYM_CHUNK_KB", NK > 16 ? 8192 : 3072) << 10) / ((int64_t)NK * 1024);
-    Cz = Cz / 8 * 8;
-    if (Cz < 32) Cz = 32;
-    if (Cz > 8192) Cz = 8192;
-    while ((NTb + Cz - 1) / Cz > 256) Cz *= 2;                   // descriptor table: <= 256 chunks
-    const int glist_cap = (int)((Cz / CTG + 64 + 3) / 4 * 4);
-    const size_t lds = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)cfg.ring * CTG * 256 +
-                       (size_t)glist_cap * 4 + (size_t)4 * 64 * 16;   // visit list, staged records
-    const int NQb = (int)(NTb / 4);
     const int split_env = env_int("WCX_SYM_SPLIT", 0);
     const int fill = env_int("WCX_SYM_FILL", 1) * slots;        // work items a chunk should offer
     std::vector<SymDesc> descs;
@@ -984,15 +1074,20 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     rc = wcx_upload_small(ctx, d_desc, descs.data(), descs.size() * sizeof(SymDesc));
     if (rc) return rc;
     WCX_HIP(hipMemsetAsync(d_seq, 0, (size_t)(NQb + 1) * 4, st));
-    SymArgs a;
-    a.F = F; a.tinfo = tinfo; a.tmin = tmin; a.tchr = tchr; a.glob = glob; a.sl = sl; a.cnt = cnt_out;
-    a.flags = flags; a.stats = ctx->d_stats; a.dbg = ctx->debug_flags; a.cap2 = cap2;
-    a.pool = pool; a.pool_head = pool_head; a.pool_ovf = pool_head + 1; a.pool_cap = pool_cap;
-    a.queue_head = pool_head + 2;
-    a.desc = d_desc; a.n_desc = (int)descs.size(); a.total_items = total; a.seq = d_seq;
-    a.glist_cap = glist_cap;
-    const int grid = total < slots ? total : slots;
-    const int e = sym_dispatch(NK, CTG, cfg.lb, cfg.ring, a, (unsigned)grid, lds, st);
+    sa.F = F; sa.tinfo = tinfo; sa.tmin = tmin; sa.tchr = tchr; sa.glob = glob; sa.sl = sl; sa.cnt = cnt_out;
+    sa.flags = flags; sa.stats = ctx->d_stats; sa.dbg = ctx->debug_flags; sa.cap2 = cap2;
+    sa.pool = pool; sa.pool_head = pool_head; sa.pool_ovf = pool_head + 1; sa.pool_cap = pool_cap;
+    sa.queue_head = pool_head + 2;
+    sa.desc = d_desc; sa.n_desc = (int)descs.size(); sa.total_items = total; sa.seq = d_seq;
+    sa.glist_cap = glist_cap;
+    sa.gate = nullptr;
+    sym_grid = total < slots ? total : slots;
+  }
+  const float gamma = (float)(16 * NK + 12) * 1.1920929e-7f;
+  const unsigned gf = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
+  auto sweep_and_cut = [&](const unsigned int *gate) -> int {
+    sa.gate = gate;
+    const int e = sym_dispatch(NK, CTG, cfg.lb, cfg.ring, sa, (unsigned)sym_grid, lds_sym, st);
     if (e < 0) {
       wcx_set_error("symmetric screen kernel nk=%d ctg=%d lb=%d ring=%d is not instantiated", NK, CTG, cfg.lb,
                     cfg.ring);
@@ -1003,19 +1098,110 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
       return (int)WCX_ERR_HIP;
     }
     k_sym_regroup<<<2048, NT, 0, st>>>(pool, pool_head, pool_head + 1, pool_cap, n_rows, sl, cnt_out, flags,
-                                       cap2);
-  }
-  {
-    const float gamma = (float)(16 * NK + 12) * 1.1920929e-7f;
-    const unsigned gf = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
+                                       cap2, gate);
     if (cap2 == CAP2)
       k_sym_final<CAP2 / 64><<<gf, NT, 0, st>>>(info, glob, rowpos, n_rows, sl, cnt_out, flags, Dest, k, gamma,
-                                                CAP);
+                                                CAP, gate);
     else
       k_sym_final<CAP2_BIG / 64><<<gf, NT, 0, st>>>(info, glob, rowpos, n_rows, sl, cnt_out, flags, Dest, k,
-                                                    gamma, REFINE_MAX);
+                                                    gamma, REFINE_MAX, gate);
+    WCX_HIP(hipGetLastError());
+    return (int)WCX_OK;
+  };
+
+  // ---- attempt 1: thresholds from the hub counts
+  if (use_hub) {
+    rc = wcx_timer_begin(ctx, "topk_pre");
+    if (rc) return rc;
+    CountArgs ca;
+    ca.F = F; ca.tchr = tchr; ca.glob = glob; ca.perm = perm; ca.tinfo = tinfo; ca.tmin = tmin;
+    ca.Dest = Dest; ca.cnt = cnt_out; ca.flags = flags; ca.stats = ctx->d_stats;
+    ca.need = need; ca.n1 = n1_tiles; ca.gate = nullptr;
+    // the visit list holds the hub groups only: room for twice the rows asked for (the quantile takes a
+    // whole histogram bin) + one padding tile per cell; a bigger region is cut off there by the kernel
+    const int64_t hub_t = (hub_rows * 2 + 31) / 32 + (int64_t)SYM_NCLS * n_chr + 8;
+    const int64_t cap_t = hub_t < NTb ? hub_t : NTb;
+    ca.glist_cap = (int)(cap_t / CTG + 64);
+    const size_t lds_cnt = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)ca.glist_cap * 4;
+    const int e = count_dispatch(NK, CTG, cfg.lb, cfg.ring, ca, (unsigned)NQb, lds_cnt, st);
+    if (e < 0) {
+      wcx_set_error("hub-count kernel nk=%d ctg=%d lb=%d ring=%d is not instantiated", NK, CTG, cfg.lb, cfg.ring);
+      return (int)WCX_ERR_UNSUPPORTED;
+    }
+    if (e != 0) {
+      wcx_set_error("hub-count kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+      return (int)WCX_ERR_HIP;
+    }
+    rc = wcx_timer_end(ctx, "topk_pre");
+    if (rc) return rc;
+    rc = sweep_and_cut(nullptr);
+    if (rc) return rc;
+    if (!(ctx->debug_flags & 59)) {      // (the ablations leave every row unfinished: one sweep is what they time)
+      k_hub_count_failed<<<512, NT, 0, st>>>(flags, n_rows, d_failed);
+      k_hub_verdict<<<1, 64, 0, st>>>(d_failed, d_gate, ctx->d_stats);
+    }
+    k_gate_reset<<<1024, NT, 0, st>>>(d_gate, n_rows, cnt_out, flags, pool_head, d_seq, NQb + 1);
+  } else {
+    rc = wcx_timer_begin(ctx, "topk_pre");
+    if (rc) return rc;
   }
-  WCX_HIP(hipGetLastError());
+
+  // ---- attempt 2 (behind the gate when attempt 1 ran): sampled pre-pass + sweep
+  {
+    // order A: the two-region best-first order; only its sample region [0, P_s) is used
+    WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
+    WCX_HIP(hipMemsetAsync(perm2, 0xff, (size_t)Bpad2 * 4, st));
+    k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, SF, 0, glob, rkey, cellcnt, gate2);
+    k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, (int)(P_s - n_s), gate2);
+    k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm2, rowpos2, gate2);
+    k_group_mask<<<(unsigned)((P_s / CT + NT - 1) / NT), NT, 0, st>>>(perm2, rchr, P_s / CT, gmask, gate2);
+    prep_frag(P_s, perm2, Fs, infs, gate2);
+    WCX_HIP(hipGetLastError());
+    const int64_t group_bytes = (int64_t)GRr * NK * 32;
+    int64_t chunk_groups = ((int64_t)env_int("WCX_SCREEN_CHUNK_KB", NK > 16 ? 16384 : 3072) << 10) / group_bytes;
+    if (chunk_groups < 16) chunk_groups = 16;
+    if (chunk_groups > 4096) chunk_groups = 4096;
+    const size_t lds = (size_t)(cfg.ring >= 2 ? cfg.ring : 2) * (size_t)(CTG * NK * 64) * 16 +
+                       (size_t)(chunk_groups + 64) * 4;
+    ScreenArgs a;
+    a.F = Fs; a.Ft = F; a.info = info; a.glob = glob; a.perm = perm2; a.rowpos = rowpos; a.gmask = gmask;
+    a.blocks = d_blocks; a.sl = sl; a.cnt = cnt_out; a.flags = flags; a.g_state = g_state;
+    a.stats = ctx->d_stats; a.row_begin = 0; a.n_rows_all = n_rows;
+    a.k = k; a.dbg = (ctx->debug_flags & ~3) | env_int("WCX_PRE_DBG", 0); a.n_seg = 1; a.n_blocks = (int)blocks.size();
+    a.raw_est = raw_est;
+    a.gate = gate2;
+    // (lists of at most 5 x 64 entries -- trigger + one group's appends -- take the short cut path of
+    //  k_screen: five slices to load, select and write back instead of sixteen)
+    int trig_a = 4 * cut_r + 64;
+    if (trig_a > 256 && 2 * cut_r + 32 <= 256) trig_a = 256;
+    if (trig_a > LIM) trig_a = LIM;
+    const int64_t g_end = P_s / GRr;
+    bool first = true;
+    for (int64_t g0 = 0; g0 < g_end; g0 += chunk_groups) {
+      const int64_t g1 = g0 + chunk_groups < g_end ? g0 + chunk_groups : g_end;
+      a.g_start = g0; a.g_count = (int)(g1 - g0);
+      a.cut_k = cut_r; a.cut_mode = 1; a.trig = trig_a; a.end_cut = g1 == g_end ? 1 : 0;
+      a.first = first ? 1 : 0;
+      first = false;
+      const int e = screen_dispatch(cfg, a, (unsigned)blocks.size(), lds, st);
+      if (e < 0) {
+        wcx_set_error("screen kernel configuration nk=%d ctg=%d is not instantiated", cfg.nk, cfg.ctg);
+        return (int)WCX_ERR_UNSUPPORTED;
+      }
+      if (e != 0) {
+        wcx_set_error("screen kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        return (int)WCX_ERR_HIP;
+      }
+    }
+    k_sym_setup<<<gprep, NT, 0, st>>>(perm, info, glob, g_state, cnt_out, flags, Dest, tinfo, tmin, gate2);
+    WCX_HIP(hipGetLastError());
+    if (!use_hub) {
+      rc = wcx_timer_end(ctx, "topk_pre");
+      if (rc) return rc;
+    }
+    rc = sweep_and_cut(gate2);
+    if (rc) return rc;
+  }
   rc = wcx_timer_end(ctx, "topk_screen");
   if (rc) return rc;
   if (ctx->ev_after_sweep) WCX_HIP(hipEventRecord(ctx->ev_after_sweep, st));   // (wcx_sweep_event)
@@ -1135,10 +1321,15 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // overwhelming probability (mean k/SF of the k nearest fall into the sample; + 10 % for the
   // uneven share of the own chromosome, Poisson tail 1e-6 per row): the estimate admits ~r SF
   // candidates; a row whose estimate fails costs ~0.1 ms in the device-wide redo.
+  // WCX_EST_MARGIN=1: the estimate carries the filter margin like a proven threshold (round 2-4).
+  // Default: the raw r-th sample value, r chosen for the rank the final cut needs below the estimate --
+  // that of the k-th neighbour's filter bound: 1.135 k entries survive the final cut at 15 kb (S = 100
+  // and 500), allowed for with 1.18 k.
+  const int raw_est = env_int("WCX_EST_MARGIN", 0) ? 0 : 1;
   auto sample_rank = [&](int nseg) {
     if (!SF) return 0;
     // smallest r with P(Poisson(lambda) >= r) <= 1e-6 / n_seg,  lambda = 1.1 k / (SF n_seg)
-    const double lambda = 1.1 * (double)k / ((double)SF * nseg);
+    const double lambda = 1.1 * (raw_est ? 1.18 : 1.0) * (double)k / ((double)SF * nseg);
     const double target = 1e-6 / nseg;
     double term = exp(-lambda), cdf = 0.0;   // term = P(X = i)
     int i = 0;
@@ -1170,8 +1361,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     const int sym_mode = env_int("WCX_SCREEN_SYM", 1);
     if (cut_r1 && row_begin == 0 && n_rows == B && covered == B && cfg.tt == 1 && cfg.wpb == 4 &&
         cfg.ring >= 2 && (sym_mode == 2 || (sym_mode == 1 && NK >= 16)))
-      return screen_sym_path(ctx, dXs, B, S, chr_cum, n_chr, blocks, cfg, SF, cut_r1, slots, k, d_out_idx,
-                             d_out_dist);
+      return screen_sym_path(ctx, dXs, B, S, chr_cum, n_chr, blocks, cfg, SF, cut_r1, raw_est, slots, k,
+                             d_out_idx, d_out_dist);
   }
   // the one-directional sweep keeps k + its filter margin inside shortlists of CAP entries: a larger
   // refsize of a row shard / gonosomal pass goes to the exact kernel
@@ -1321,6 +1512,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   a.blocks = d_blocks; a.sl = sl; a.cnt = cnt_out; a.flags = flags; a.g_state = g_state;
   a.stats = ctx->d_stats; a.row_begin = row_begin; a.n_rows_all = n_rows;
   a.k = k; a.dbg = ctx->debug_flags; a.n_seg = n_seg; a.n_blocks = (int)blocks.size();
+  a.raw_est = raw_est;
   // Every chunk launch ends with a partly filled last round of workgroups (1423 blocks on 512
   // slots = 2.78 rounds at 15 kb).  With more than one round of blocks the target blocks are split
   // in two halves that sweep the same chunks on two streams: when one half's launch drains, the

@@ -14,7 +14,8 @@ constexpr int LIM = CAP - CT;
 constexpr int CAP2 = 2048;   // list capacity per row in the symmetric sweep (fixed thresholds, no cuts);
 constexpr int CAP2_BIG = 4096;   // ... for refsize > 448 (SymArgs::cap2 carries the one in use)
 constexpr int KMAX_SCREEN = 1024;    // largest refsize of the MFMA paths (symmetric sweep)
-constexpr int KMAX_ONE_DIR = 800;    // ... of the one-directional sweep: k + filter margin must stay below LIM
+constexpr int KMAX_ONE_DIR = 512;    // ... of the one-directional sweep: k + its filter margin (14 % at 15 kb, more
+                                     // than 50 % on small noisy problems) must fit shortlists of LIM = 960 entries
 constexpr int SMAX_SCREEN = 1020;    // most samples: K = 16 NK >= S + 4, NK <= 64 (target fragments in registers)
 
 struct RowInfo {
@@ -30,6 +31,8 @@ struct ScreenGlobals {
   unsigned int n_overflow;
   unsigned int uinv;             // 0xffffffff - min(norm float bits >> 20) over finite rows
   unsigned int n_tiles;          // symmetric sweep: tiles in use (multiple of 4)
+  unsigned int hub_key;          // rows with (float bits of |a|^2) >> 16 <= hub_key form the hub region
+  unsigned int n_hub_tiles;      // tiles of the hub region (the head of the symmetric sweep order)
 };
 
 
@@ -64,6 +67,8 @@ struct ScreenArgs {
   int end_cut;              // cut of every target at the end of the launch: 0 none, 1 = end of the
                             // sampled pre-pass (estimate from rank cut_k), 2 = final (exact k-th)
   int first, dbg, n_seg, n_blocks;
+  int raw_est = 0;          // sampled pre-pass: the estimate is the r-th sample value itself (no filter margin)
+  const unsigned int *gate = nullptr;   // not null: the launch does nothing unless *gate != 0 (second-attempt kernels)
 };
 
 // One chunk of streamed tiles of the symmetric sweep: work items = (quads q_first .. q_first + n_q - 1)
@@ -95,7 +100,28 @@ struct SymArgs {
   int *seq;                   // [quad] exclusive items of the quad that have finished
   int glist_cap;              // ints reserved for the visit list in LDS
   int dbg;
+  const unsigned int *gate = nullptr;   // not null: the launch does nothing unless *gate != 0
 };
+// Arguments of the hub-count estimator (screen_count.h).
+struct CountArgs {
+  const half8 *F;
+  const unsigned char *tchr;
+  const ScreenGlobals *glob;  // n_tiles, n_hub_tiles
+  const int *perm;            // sweep position -> row (-1 = padding)
+  unsigned int *tinfo;        // out: [tile][64] theta | row id
+  float *tmin;                // out: [tile]
+  float *Dest;                // out: [row] threshold in screen-distance space
+  int *cnt;                   // out: [row] = 0
+  unsigned int *flags;        // out: rows without an estimate
+  unsigned long long *stats;
+  int need;                   // hub candidates wanted below the estimate
+  int n1;                     // hub tiles of the moment phase
+  int glist_cap;              // hub groups the visit list in LDS has room for
+  const unsigned int *gate = nullptr;   // not null: the launch does nothing if *gate != 0
+};
+int wcx_count_launch_k1(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_count_launch_k2(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_count_launch_k3(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_sym_launch_k1(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_sym_launch_k2(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_sym_launch_k3(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);

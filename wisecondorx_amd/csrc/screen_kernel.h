@@ -89,7 +89,7 @@ __device__ __forceinline__ float compact_loaded(const uint2 (&raw)[NSL], int n,
                                                 uint2 *__restrict__ sl_row, int kk, float na, float E,
                                                 float Q, float G_old, int est_old, int mode,
                                                 bool fail_if_est, unsigned int *overflow_flag,
-                                                int &n_out, int &est_out) {
+                                                int &n_out, int &est_out, bool raw_est = false) {
   const int lane = wcx::lane_id();
   unsigned int key[NSL], idx[NSL];
 #pragma unroll
@@ -127,7 +127,14 @@ __device__ __forceinline__ float compact_loaded(const uint2 (&raw)[NSL], int n,
     dk = dk > 0.f ? dk : 0.f;
     const float rt = sqrtf(up(dk + Q)) * 1.0000005f + 2.f * E;
     const float Fb = up(up(rt * rt) + Q);
-    const float Gn = (Fb - na) + 4e-7f * (Fb + na);
+    float Gn = (Fb - na) + 4e-7f * (Fb + na);
+    // An ESTIMATE needs no filter margin: nothing is proven with it -- the final cut proves (k entries
+    // whose own filter bound lies below the estimate) or flags the row.  Taking the r-th sample value as
+    // it is admits a third fewer pairs than its filter bound (the distances of a row's nearest few
+    // hundred candidates differ by a few per cent only: a 2 % wider threshold admits 1.5 x as many);
+    // the sample rank r allows for the margin instead (sample_rank: the estimate must cover the rank of
+    // the k-th neighbour's FILTER BOUND, ~1.14 k, not k).
+    if (mode == 1 && raw_est) Gn = tk + 4e-7f * (fabsf(tk) + na);
     if (tk < HUGE_VALF) {        // (NaN / inf bound: keep the old threshold)
       if (mode == 1) { if (Gn < G_old) { G = Gn; est = 1; } }
       else if (Gn <= G_old) { G = Gn; est = 0; }
@@ -203,7 +210,7 @@ __device__ __forceinline__ void cut_targets(const ScreenArgs &A, unsigned int ne
     int n_new, e_new;
     const float Gn = compact_loaded(raw, n_c, A.sl + (w_srow + c) * (int64_t)CAP, kk, na_c, E_c,
                                     Q_c, G_c, e_c, mode, fail_if_est, &A.flags[w_srow + c], n_new,
-                                    e_new);
+                                    e_new, A.raw_est != 0);
     if (l32 == c) { G = Gn; cntr = n_new; est = e_new; }
     ++n_compact;
     if (cn < 0) break;
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(64 * WPB, LBW) void k_screen(
   half8 *sbuf = reinterpret_cast<half8 *>(smem);                       // [NSLOT][TILE_H8]
   int *glist = reinterpret_cast<int *>(smem + NSLOT * TILE_H8 * 16);   // [groups of the chunk]
   __shared__ int s_nlist;
+  if (A.gate && !*A.gate) return;                   // (a second-attempt launch nobody asked for)
 
   // Candidate segments: with few target blocks (a row shard of a multi-GPU build) every block is
   // issued n_seg times; copy `seg` sweeps every n_seg-th group of the visit list into its own

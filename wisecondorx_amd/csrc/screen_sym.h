@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_nlist, s_item, s_desc;
   const int tid = threadIdx.x;
+  if (A.gate && !*A.gate) return;                      // (a second attempt nobody asked for)
   const int n_tiles = (int)A.glob->n_tiles;
   SymCounters C = {0, 0, 0, 0, 0, 0, 0};
   for (;;) {
