@@ -301,8 +301,13 @@ class Workload:
             if tag == "A":
                 # ONE exchange (all-gather of the row shards of X over RCCL/xGMI), the search + null
                 # ratios of this rank's target rows, then every rank gets the whole tables
-                idx_l, dist_l, nr_l, _ = wd.newref_sharded(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
-                                                           self.backend, self.rank, self.world, out=P["bufs"])
+                # (N > 1: the tile pairs of the symmetric sweep dealt out to the ranks + ONE all-to-all of
+                #  the hit records, dist.newref_sym_sharded; WCX_BENCH_SYM_SHARD=0: every rank sweeps its
+                #  target rows against all candidates, the round-1..4 form)
+                shard_fn = wd.newref_sym_sharded if (self.world > 1 and os.environ.get("WCX_BENCH_SYM_SHARD", "1") != "0") \
+                    else wd.newref_sharded
+                idx_l, dist_l, nr_l, _ = shard_fn(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
+                                                  self.backend, self.rank, self.world, out=P["bufs"])
                 if self.args.debug_flags & 59:           # (ablations leave garbage neighbour tables)
                     ctx.timer_tag("")
                     ctx.sync()

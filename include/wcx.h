@@ -164,6 +164,29 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
                         int64_t row_end, int k, int mode, int32_t *d_out_idx,
                         double *d_out_dist);
 
+/* Row-sharded search of an autosomal pass WITH the symmetric sweep (multi-GPU; the parts of
+ * newref_control.py:90-109 / newref_tools.py:244-247, one per rank).  Every rank holds all of X (one
+ * all-gather) and builds the same sweep order and thresholds; the tile PAIRS are dealt out to the ranks,
+ * each pair computed once for both directions, and every hit becomes a 16-byte record
+ * (row, partner sweep position, screen distance bits, 0) for the rank that owns the row:
+ *   wcx_newref_sym_sweep_dev    rank `part` of `n_parts` (<= 32); row_bounds int64[n_parts + 1]: rank r owns
+ *                               rows [row_bounds[r], row_bounds[r + 1]).  counts_out int64[n_parts] (host):
+ *                               records for each destination rank.  Synchronises.
+ *                               WCX_ERR_UNSUPPORTED where the symmetric sweep does not apply (K < 256,
+ *                               B < 32768, a gonosomal pass): use wcx_newref_topk_dev on the row range.
+ *   wcx_newref_sym_records_dev  the records, grouped by destination rank in rank order, into d_send
+ *                               (device, sum(counts) x 16 bytes)
+ *   -- the caller exchanges them: ONE all-to-all --
+ *   wcx_newref_sym_finish_dev   d_recv: the n_recv records received for this rank's rows: lists, final
+ *                               cut, exact fp64 refine, exact redo -> out_idx int32[own rows][k],
+ *                               out_dist double[own rows][k], identical to wcx_newref_topk_dev's. */
+int wcx_newref_sym_sweep_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const int64_t *chr_cum,
+                             int n_chr, int k, int part, int n_parts, const int64_t *row_bounds,
+                             int64_t *counts_out);
+int wcx_newref_sym_records_dev(wcx_ctx *ctx, void *d_send);
+int wcx_newref_sym_finish_dev(wcx_ctx *ctx, const void *d_recv, int64_t n_recv, int32_t *d_out_idx,
+                              double *d_out_dist);
+
 /* Replaces the null-ratio loop newref_tools.py:210-223: out[r][m] =
  * log2(X[row_begin+r][sid[m]] / median_k X[idx[r][k]][sid[m]]), the index row applied to the
  * FULL bin vector without re-offsetting (reference quirk, newref_tools.py:219-221; index -1

@@ -118,3 +118,71 @@ def test_bench_two_ranks_smoke(mode):
     assert d["roofline"]["frac"] > 0
     assert d["scaling"] == ("weak" if mode == "replicas" else "strong")
     assert d["verified"]["mismatches"] == 0 and d["verified"]["rows"] > 100
+
+
+def _worker_sym(rank, world, port, X, cum, k, ids, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd import dist as wd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    be = wd.GpuBackend(ctx)
+    B = X.shape[0]
+    b, e = wd.row_shard(rank, world, B)
+    pad = wd.max_shard_rows(world, B)
+    local = torch.zeros((pad, X.shape[1]), dtype=torch.float64, device=dev)
+    local[:e - b] = torch.from_numpy(np.ascontiguousarray(X[b:e])).to(dev)
+    wd.newref_sym_sharded.last_records = None
+    idx, dd, nr, Xs = wd.newref_sym_sharded(local, B, cum, k, ids, be, rank, world)
+    ctx.sync()
+    st = ctx.topk_stats()
+    q.put((rank, idx.cpu().numpy().copy(), dd.cpu().numpy().copy(), nr.cpu().numpy().copy(),
+           wd.newref_sym_sharded.last_records, st["fallback_rows"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_row_sharded_symmetric_sweep(world):
+    """dist.newref_sym_sharded with the real kernels, all ranks on one device over gloo: the tile pairs of
+    the symmetric sweep dealt out to the ranks (each pair once, both directions), the hit records routed
+    to the rows' owners by ONE all-to-all -- every rank's row block bit-identical to the oracle's (and so
+    to the one-process build); the symmetric path must really have run on every rank."""
+    import torch.multiprocessing as mp
+    from oracle import c_oracle as CO
+    from oracle import wcx_oracle as O
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([7100, 6600, 6100, 5400, 4700, 3901], 256, seed=29)    # 33 801 rows
+    X = np.asfortranarray(X)
+    B, k, ids = cum[-1], 64, [3, 1, 7, 0, 22, 39, 255, 100]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker_sym, args=(r, world, port, X, cum, k, ids, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[4] is not None and r[4][0] > 0 and r[4][1] > 0, "rank {}: the symmetric sweep did not run".format(r[0])
+    assert sum(r[4][0] for r in res) == sum(r[4][1] for r in res)          # every record arrived somewhere
+    ei, ed = CO.get_reference_rows_threaded(np.ascontiguousarray(X.T), cum, 0, B, k)
+    gi, gd = np.concatenate([r[1] for r in res]), np.concatenate([r[2] for r in res])
+    bad = np.flatnonzero((gi != ei).any(axis=1) | (gd != ed).any(axis=1))
+    assert bad.size == 0, "{} of {} rows differ (first {})".format(bad.size, B, bad[:5])
+    gnr = np.concatenate([r[3] for r in res])
+    for lo in (0, B // 2 - 500, B - 1000):            # (the NumPy oracle walks the rows one by one)
+        with np.errstate(all="ignore"):
+            enr = O.null_ratios(X, ei[lo:lo + 1000], lo, lo + 1000, ids)
+        np.testing.assert_allclose(gnr[lo:lo + 1000], enr, rtol=1e-12, atol=1e-13)
+    assert max(r[5] for r in res) <= 64              # rows the exact kernel had to redo, per rank

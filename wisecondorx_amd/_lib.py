@@ -57,6 +57,10 @@ SIGNATURES = {
     "wcx_null_ratios_dev": (C.c_int, [vp, vp, c_i64, C.c_int, vp, c_i64, c_i64, C.c_int,
                                       c_i32p, C.c_int, vp]),
     "wcx_ref_upload": (C.c_int, [vp, vp, vp, c_i64, C.c_int, c_i64p, C.c_int, C.POINTER(vp)]),
+    "wcx_newref_sym_sweep_dev": (C.c_int, [vp, vp, c_i64, C.c_int, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          c_i64p, c_i64p]),
+    "wcx_newref_sym_records_dev": (C.c_int, [vp, vp]),
+    "wcx_newref_sym_finish_dev": (C.c_int, [vp, vp, c_i64, vp, vp]),
     "wcx_ref_wrap_dev": (C.c_int, [vp, vp, vp, c_i64, C.c_int, c_i64p, C.c_int, C.POINTER(vp)]),
     "wcx_ref_free": (C.c_int, [vp, vp]),
     "wcx_cutoff": (C.c_int, [vp, vp, C.c_int, c_f64p]),
@@ -91,6 +95,9 @@ SIGNATURES = {
     "wcx_set_null_matrix_dev": (C.c_int, [vp, vp, c_i64, C.c_int, vp, c_i64]),
     "wcx_segment_z": (C.c_int, [vp, vp, vp, vp, C.c_int, c_i64p, C.c_int, vp, C.c_int, vp, vp]),
 }
+
+
+WCX_ERR_UNSUPPORTED = 4        # include/wcx.h
 
 
 class WcxError(RuntimeError):

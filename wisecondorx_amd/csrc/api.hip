@@ -227,6 +227,7 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
     if (kv.second.start) hipEventDestroy(kv.second.start);
     if (kv.second.stop) hipEventDestroy(kv.second.stop);
   }
+  wcx_sym_state_free(ctx);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->host_scratch) hipHostFree(ctx->host_scratch);
   for (auto &sl : ctx->sel_pool)
@@ -335,6 +336,48 @@ int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[16]) {
   out[3] = (int64_t)h[3];
   for (int i = 4; i < 16; ++i) out[i] = (int64_t)h[i];
   return WCX_OK;
+}
+
+// ------------------------------------------------------------------ row-sharded symmetric search
+int wcx_newref_sym_sweep_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const int64_t *chr_cum,
+                             int n_chr, int k, int part, int n_parts, const int64_t *row_bounds,
+                             int64_t *counts_out) {
+  WCX_ARG(ctx && dXs && chr_cum && row_bounds && counts_out, "NULL argument");
+  WCX_ARG(B > 0 && S > 0 && n_chr > 0 && k > 0, "B, S, n_chr, k must be positive");
+  WCX_ARG(chr_cum[n_chr - 1] == B, "chr_cum[n_chr-1] must equal B");
+  WCX_ARG(n_parts >= 1 && part >= 0 && part < n_parts, "bad part");
+  WCX_ARG(B < (int64_t)0x7fffffff, "B must fit in int32 (indices are int32)");
+  if (n_chr > 22) {
+    wcx_set_error("the sharded symmetric sweep searches every row: not a gonosomal pass (n_chr = %d)", n_chr);
+    return WCX_ERR_UNSUPPORTED;
+  }
+  WCX_HIP(hipSetDevice(ctx->device));
+  if (ctx->rank_X && !ctx->rank_pending) ctx->rank_X = nullptr;
+  const int64_t r0 = row_bounds[part], r1 = row_bounds[part + 1];
+  WCX_ARG(0 <= r0 && r0 <= r1 && r1 <= B, "bad row bounds");
+  int64_t pairs = 0;
+  for (int c = 0; c < n_chr; ++c) {
+    const int64_t cs = c ? chr_cum[c - 1] : 0, ce = chr_cum[c];
+    const int64_t lo = cs > r0 ? cs : r0, hi = ce < r1 ? ce : r1;
+    if (lo < hi) pairs += (hi - lo) * (B - (ce - cs));
+  }
+  ctx->topk_stats[0] = r1 - r0;
+  ctx->topk_stats[1] = pairs;
+  wcx_aux_cancel_if_few_rows(ctx, B, r1 - r0);
+  return wcx_sym_shard_sweep(ctx, dXs, B, S, chr_cum, n_chr, k, part, n_parts, row_bounds, counts_out);
+}
+
+int wcx_newref_sym_records_dev(wcx_ctx *ctx, void *d_send) {
+  WCX_ARG(ctx, "NULL argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  return wcx_sym_shard_records(ctx, d_send);
+}
+
+int wcx_newref_sym_finish_dev(wcx_ctx *ctx, const void *d_recv, int64_t n_recv, int32_t *d_out_idx,
+                              double *d_out_dist) {
+  WCX_ARG(ctx && d_out_idx && d_out_dist && n_recv >= 0 && (d_recv || n_recv == 0), "bad argument");
+  WCX_HIP(hipSetDevice(ctx->device));
+  return wcx_sym_shard_finish(ctx, d_recv, n_recv, d_out_idx, d_out_dist);
 }
 
 // ------------------------------------------------------------------ newref search (a4-a6)

@@ -598,6 +598,58 @@ __global__ __launch_bounds__(SYM_NCELL) void k_sym_scan(const int *__restrict__ 
   if (t == SYM_NCELL - 1) glob->n_tiles = (unsigned int)(((start >> 5) + 3) & ~3);
 }
 
+// ---- Deterministic order B (the row-sharded symmetric sweep: every rank must build the SAME tiles, the
+// records they exchange name sweep positions).  k_scatter hands out the positions inside a cell in the
+// order the workgroups' atomics arrive; here a row's position is  start[cell] + the number of rows
+// before it with the same key  -- a stable counting sort:
+//   k_det_local   per workgroup of 256 consecutive rows: rank among the workgroup's rows of the same key
+//                 (compare loop in LDS) and, by the last such row, the workgroup's count -> table[key][wg]
+//   k_det_scan    one wave per key: exclusive scan of its workgroup counts (+ the cell's start)
+//   k_det_place   position = table[key][wg] + local rank
+constexpr int DET_KEYS = 2 * SYM_NCELL * SYM_NSUB;
+__global__ __launch_bounds__(NT) void k_det_local(const int *__restrict__ rkey, int64_t B, int n_wg,
+                                                  int *__restrict__ table, unsigned short *__restrict__ lrank) {
+  __shared__ int sk[NT];
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  const int key = b < B ? rkey[b] : -1;
+  sk[threadIdx.x] = key;
+  __syncthreads();
+  if (key < 0) return;
+  int before = 0, after = 0;
+  for (int j = 0; j < NT; ++j) {
+    const bool same = sk[j] == key;
+    before += (same && j < (int)threadIdx.x) ? 1 : 0;
+    after += (same && j > (int)threadIdx.x) ? 1 : 0;
+  }
+  lrank[b] = (unsigned short)before;
+  if (after == 0) table[(int64_t)key * n_wg + blockIdx.x] = before + 1;
+}
+__global__ __launch_bounds__(NT) void k_det_scan(int *__restrict__ table, int n_wg,
+                                                 const int *__restrict__ cursor) {
+  const int lane = wcx::lane_id();
+  const int key = (int)(((int64_t)blockIdx.x * NT + threadIdx.x) >> 6);
+  if (key >= DET_KEYS) return;
+  int *row = table + (int64_t)key * n_wg;
+  int run = cursor[key];
+  for (int w0 = 0; w0 < n_wg; w0 += 64) {
+    const int w = w0 + lane;
+    const int c = w < n_wg ? row[w] : 0;
+    const int incl = wcx::wave_incl_scan_i(c);
+    if (w < n_wg) row[w] = run + incl - c;
+    run += __builtin_amdgcn_readlane(incl, 63);
+  }
+}
+__global__ __launch_bounds__(NT) void k_det_place(const int *__restrict__ rkey, int64_t B, int n_wg,
+                                                  const int *__restrict__ table,
+                                                  const unsigned short *__restrict__ lrank,
+                                                  int *__restrict__ perm, int *__restrict__ rowpos) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (b >= B) return;
+  const int pos = table[(int64_t)rkey[b] * n_wg + blockIdx.x] + (int)lrank[b];
+  perm[pos] = (int)b;
+  rowpos[b] = pos;
+}
+
 // After the sampled pre-pass: the estimated threshold of every row, in screen-distance space
 // (D = G + nb': the pre-pass admits t = nb'_c - 2 g~ <= G), as theta = -D/2 per sweep position;
 // per-tile minimum; list counters reset (the pre-pass's entries are dropped: the symmetric sweep
@@ -771,6 +823,56 @@ __global__ __launch_bounds__(NT) void k_gate_reset(const unsigned int *__restric
   }
 }
 
+// ---- Row-sharded symmetric sweep: the records of this rank's tile pairs, by the rank that owns the row.
+struct RowBounds { int n; int64_t b[33]; };       // rank r owns rows [b[r], b[r + 1])
+__device__ __forceinline__ int owner_of(const RowBounds &rb, unsigned int row) {
+  int o = 0;
+  while (o + 1 < rb.n && (int64_t)row >= rb.b[o + 1]) ++o;
+  return o;
+}
+__global__ __launch_bounds__(NT) void k_rec_hist(const uint4 *__restrict__ pool,
+                                                 const unsigned int *__restrict__ pool_head,
+                                                 unsigned int pool_cap, RowBounds rb,
+                                                 unsigned long long *__restrict__ counts) {
+  __shared__ unsigned int h[32];
+  if (threadIdx.x < 32) h[threadIdx.x] = 0u;
+  __syncthreads();
+  unsigned int n = *pool_head;
+  if (n > pool_cap) n = pool_cap;
+  for (unsigned int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT)
+    atomicAdd(&h[owner_of(rb, pool[i].x)], 1u);
+  __syncthreads();
+  if (threadIdx.x < 32 && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+// cursor[r] = first slot of destination r in the send buffer (advanced by the records placed)
+__global__ __launch_bounds__(NT) void k_rec_bucket(const uint4 *__restrict__ pool,
+                                                   const unsigned int *__restrict__ pool_head,
+                                                   unsigned int pool_cap, RowBounds rb,
+                                                   unsigned long long *__restrict__ cursor,
+                                                   uint4 *__restrict__ send) {
+  unsigned int n = *pool_head;
+  if (n > pool_cap) n = pool_cap;
+  for (unsigned int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    const uint4 rec = pool[i];
+    const unsigned long long slot = atomicAdd(&cursor[owner_of(rb, rec.x)], 1ull);
+    send[slot] = rec;
+  }
+}
+// records received for the rows [row0, row0 + n_own): into the rows' lists (list index = row - row0)
+__global__ __launch_bounds__(NT) void k_rec_regroup(const uint4 *__restrict__ recv, int64_t n_recv,
+                                                    int64_t row0, int64_t n_own, uint2 *__restrict__ sl,
+                                                    int *__restrict__ cnt, unsigned int *__restrict__ flags,
+                                                    int cap2) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n_recv; i += (int64_t)gridDim.x * NT) {
+    const uint4 rec = recv[i];
+    const int64_t r = (int64_t)rec.x - row0;
+    if (r < 0 || r >= n_own) continue;               // (not ours: a routing error would show as missing rows)
+    const int slot = atomicAdd(&cnt[r], 1);
+    if (slot < cap2) sl[r * cap2 + slot] = make_uint2(rec.z, rec.y);
+    else flags[r] = 1u;
+  }
+}
+
 }  // namespace
 
 // Host side --------------------------------------------------------------------------------
@@ -826,6 +928,33 @@ static int sym_dispatch(int nk, int ctg, int lb, int ring, const SymArgs &a, uns
   return rc;
 }
 
+// Row-sharded symmetric sweep: what phase 1 (wcx_newref_sym_sweep_dev) leaves for the record copy and
+// for phase 2 (wcx_newref_sym_finish_dev); lives in the context (wcx_ctx::sym_state).
+struct SymShardState {
+  bool valid = false;
+  int64_t B = 0, row_begin = 0, row_end = 0;
+  int S = 0, Sp = 0, NK = 0, k = 0, cap2 = 0, n_parts = 0, part = 0;
+  ChrTab tab;
+  RowBounds rb;
+  const double *dXs = nullptr;
+  double *Xr = nullptr;
+  RowInfo *info = nullptr;
+  ScreenGlobals *glob = nullptr;
+  int *rowpos = nullptr, *perm = nullptr, *cnt = nullptr;
+  float *Dest = nullptr;
+  unsigned int *flags = nullptr, *pool_head = nullptr, *d_nredo = nullptr;
+  unsigned char *searched = nullptr;
+  uint2 *sl = nullptr;
+  uint4 *pool = nullptr;
+  unsigned int pool_cap = 0;
+  unsigned long long *d_counts = nullptr;       // [32] records per destination | [32] bucket cursors
+  TopkBlock *d_redo = nullptr, *d_rtile = nullptr;
+  int32_t *d_rlist = nullptr;
+  void *rscr = nullptr;
+  unsigned long long counts[32] = {0};
+};
+struct SymShardCall { int part, n_parts; RowBounds rb; SymShardState *state; };
+
 static int count_dispatch(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds,
                           hipStream_t st) {
   int rc = wcx_count_launch_k1(nk, ctg, lb, ring, a, grid, lds, st);
@@ -849,10 +978,11 @@ static int count_dispatch(int nk, int ctg, int lb, int ring, const CountArgs &a,
 static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const int64_t *chr_cum,
                            int n_chr, const std::vector<ScreenBlock> &blocks, const ScreenCfg &cfg,
                            int SF, int cut_r, int raw_est, int slots, int k, int32_t *d_out_idx,
-                           double *d_out_dist) {
+                           double *d_out_dist, SymShardCall *sh = nullptr) {
   const int NK = cfg.nk, CTG = cfg.ctg, GRr = CTG * 32;
   const int Sp = row_pitch(S);
   const int64_t n_rows = B;
+  const int64_t n_own = sh ? sh->rb.b[sh->part + 1] - sh->rb.b[sh->part] : B;   // rows whose lists live here
   // list capacity per row: the estimates admit ~4 k entries at k = 300, ~2.7 k at k = 1000
   const int cap2 = k <= 448 ? CAP2 : CAP2_BIG;
   // hub-count estimates (attempt 1): WCX_SYM_HUB=0 turns them off; the region is 1 / WCX_HUB_FRAC of the
@@ -863,6 +993,11 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   int64_t hub_rows = hub_frac > 1 ? B / hub_frac : 0;
   if (hub_rows < 6 * (int64_t)need) hub_rows = 6 * (int64_t)need;
   const bool use_hub = env_int("WCX_SYM_HUB", 1) != 0 && NK >= 16 && hub_frac > 1 && hub_rows * 6 <= B;
+  if (sh && !use_hub) {
+    wcx_set_error("the row-sharded symmetric sweep needs the hub-count thresholds (K >= 256, B >= %lld)",
+                  (long long)(36 * (int64_t)need));
+    return (int)WCX_ERR_UNSUPPORTED;
+  }
   const int n1_tiles = env_int("WCX_HUB_N1", 16);
   const int64_t n_s = (B + SF - 1) / SF;
   const int64_t P_s = (n_s + CT - 1) / CT * CT;
@@ -897,13 +1032,17 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   // records: row-direction hits (a few per cent of all) + everything from launches that split a
   // target quad over several work items (the high, hub-free tiles)
   // (a small matrix splits most of its chunks: nearly every hit is a record then -- half a list per row)
-  const int64_t pool_want = n_rows * (int64_t)(cap2 / 2);
+  const int64_t pool_want = sh ? n_rows * (int64_t)(cap2 / 2) / sh->n_parts * 2 : n_rows * (int64_t)(cap2 / 2);
   const unsigned int pool_cap = (unsigned int)(pool_want < 200000000ll ? pool_want : 200000000ll);
   const size_t o_pool = carve((size_t)pool_cap * 16);
   const size_t o_phead = carve(256);      // pool head | pool overflow | queue head | gate | failed rows
   const size_t o_desc = carve(256 * sizeof(SymDesc));
   const size_t o_seq = carve((size_t)(NTb / 4 + 1) * 4);
-  const size_t o_sl = carve((size_t)n_rows * cap2 * 8);
+  const size_t o_sl = carve((size_t)n_own * cap2 * 8);
+  const int n_wg_det = (int)((B + NT - 1) / NT);
+  const size_t o_dett = carve(sh ? (size_t)DET_KEYS * n_wg_det * 4 : 0);
+  const size_t o_detl = carve(sh ? (size_t)B * 2 : 0);
+  const size_t o_cnts = carve(64 * 8);
   const size_t o_cnt = carve((size_t)n_rows * 4);
   const size_t o_gst = carve((size_t)n_rows * 4);
   const size_t o_flag = carve((size_t)n_rows * 4);
@@ -1004,7 +1143,16 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   k_sym_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, glob, rkey, cellcnt, env_int("WCX_SYM_SUBORDER", 1),
                                 use_hub ? rfine : nullptr);
   k_sym_scan<<<1, SYM_NCELL, 0, st>>>(cellcnt, cursor, tchr, glob);
-  k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
+  if (sh) {      // the same order on every rank
+    int *dett = reinterpret_cast<int *>(base + o_dett);
+    unsigned short *detl = reinterpret_cast<unsigned short *>(base + o_detl);
+    WCX_HIP(hipMemsetAsync(dett, 0, (size_t)DET_KEYS * n_wg_det * 4, st));
+    k_det_local<<<gb, NT, 0, st>>>(rkey, B, n_wg_det, dett, detl);
+    k_det_scan<<<(unsigned)((DET_KEYS * 64 + NT - 1) / NT), NT, 0, st>>>(dett, n_wg_det, cursor);
+    k_det_place<<<gb, NT, 0, st>>>(rkey, B, n_wg_det, dett, detl, perm, rowpos);
+  } else {
+    k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
+  }
   const unsigned gprep = (unsigned)((PB + NT - 1) / NT), gprep_s = (unsigned)((P_s + NT - 1) / NT);
   auto prep_frag = [&](int64_t n_pos, const int *pm, half8 *Fo, RowInfo *io, const unsigned int *gate) {
     const unsigned g = (unsigned)((n_pos + NT - 1) / NT);
@@ -1081,6 +1229,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     sa.desc = d_desc; sa.n_desc = (int)descs.size(); sa.total_items = total; sa.seq = d_seq;
     sa.glist_cap = glist_cap;
     sa.gate = nullptr;
+    if (sh) { sa.force_records = 1; sa.part = sh->part; sa.n_parts = sh->n_parts; }
     sym_grid = total < slots ? total : slots;
   }
   const float gamma = (float)(16 * NK + 12) * 1.1920929e-7f;
@@ -1117,13 +1266,20 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     ca.F = F; ca.tchr = tchr; ca.glob = glob; ca.perm = perm; ca.tinfo = tinfo; ca.tmin = tmin;
     ca.Dest = Dest; ca.cnt = cnt_out; ca.flags = flags; ca.stats = ctx->d_stats;
     ca.need = need; ca.n1 = n1_tiles; ca.gate = nullptr;
+    const bool hub_pass = env_int("WCX_HUB_APPEND", 0) != 0 && !(ctx->debug_flags & 59) && !sh;
+    ca.sl = hub_pass ? sl : nullptr; ca.cap2 = cap2;
+    sa.hub_appended = hub_pass ? 1 : 0;
     // the visit list holds the hub groups only: room for twice the rows asked for (the quantile takes a
     // whole histogram bin) + one padding tile per cell; a bigger region is cut off there by the kernel
     const int64_t hub_t = (hub_rows * 2 + 31) / 32 + (int64_t)SYM_NCLS * n_chr + 8;
     const int64_t cap_t = hub_t < NTb ? hub_t : NTb;
     ca.glist_cap = (int)(cap_t / CTG + 64);
     const size_t lds_cnt = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)ca.glist_cap * 4;
-    const int e = count_dispatch(NK, CTG, cfg.lb, cfg.ring, ca, (unsigned)NQb, lds_cnt, st);
+    int e = count_dispatch(NK, CTG, cfg.lb, cfg.ring, ca, (unsigned)NQb, lds_cnt, st);
+    if (e == 0 && hub_pass) {
+      ca.append_pass = 1;
+      e = count_dispatch(NK, CTG, cfg.lb, cfg.ring, ca, (unsigned)NQb, lds_cnt, st);
+    }
     if (e < 0) {
       wcx_set_error("hub-count kernel nk=%d ctg=%d lb=%d ring=%d is not instantiated", NK, CTG, cfg.lb, cfg.ring);
       return (int)WCX_ERR_UNSUPPORTED;
@@ -1134,6 +1290,38 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     }
     rc = wcx_timer_end(ctx, "topk_pre");
     if (rc) return rc;
+    if (sh) {
+      // this rank's tile pairs -> records; how many go to which rank (the call synchronises here)
+      const int e2 = sym_dispatch(NK, CTG, cfg.lb, cfg.ring, sa, (unsigned)sym_grid, lds_sym, st);
+      if (e2 != 0) {
+        wcx_set_error("symmetric screen kernel nk=%d ctg=%d: launch failed (%d)", NK, CTG, e2);
+        return e2 < 0 ? (int)WCX_ERR_UNSUPPORTED : (int)WCX_ERR_HIP;
+      }
+      unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(base + o_cnts);
+      WCX_HIP(hipMemsetAsync(d_counts, 0, 64 * 8, st));
+      k_rec_hist<<<1024, NT, 0, st>>>(pool, pool_head, pool_cap, sh->rb, d_counts);
+      WCX_HIP(hipGetLastError());
+      rc = wcx_timer_end(ctx, "topk_screen");
+      if (rc) return rc;
+      SymShardState &Z = *sh->state;
+      unsigned int head2[2] = {0, 0};
+      WCX_HIP(hipMemcpyAsync(Z.counts, d_counts, 32 * 8, hipMemcpyDeviceToHost, st));
+      WCX_HIP(hipMemcpyAsync(head2, pool_head, 8, hipMemcpyDeviceToHost, st));
+      WCX_HIP(hipStreamSynchronize(st));
+      if (head2[1] || head2[0] > pool_cap) {
+        wcx_set_error("record pool of the sharded sweep overflowed (%u records, room for %u)", head2[0], pool_cap);
+        return (int)WCX_ERR_NOMEM;
+      }
+      Z.valid = true;
+      Z.B = B; Z.row_begin = sh->rb.b[sh->part]; Z.row_end = sh->rb.b[sh->part + 1];
+      Z.S = S; Z.Sp = Sp; Z.NK = NK; Z.k = k; Z.cap2 = cap2; Z.n_parts = sh->n_parts; Z.part = sh->part;
+      Z.tab = tab; Z.rb = sh->rb; Z.dXs = dXs; Z.Xr = Xr; Z.info = info; Z.glob = glob; Z.rowpos = rowpos;
+      Z.perm = perm; Z.cnt = cnt_out; Z.Dest = Dest; Z.flags = flags; Z.pool_head = pool_head;
+      Z.d_nredo = d_nredo; Z.searched = searched; Z.sl = sl; Z.pool = pool; Z.pool_cap = pool_cap;
+      Z.d_counts = d_counts; Z.d_redo = d_redo; Z.d_rtile = d_rtile; Z.d_rlist = d_rlist;
+      Z.rscr = base + o_rscr;
+      return (int)WCX_OK;
+    }
     rc = sweep_and_cut(nullptr);
     if (rc) return rc;
     if (!(ctx->debug_flags & 59)) {      // (the ablations leave every row unfinished: one sweep is what they time)
@@ -1199,6 +1387,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
       rc = wcx_timer_end(ctx, "topk_pre");
       if (rc) return rc;
     }
+    sa.hub_appended = 0;
     rc = sweep_and_cut(gate2);
     if (rc) return rc;
   }
@@ -1613,6 +1802,131 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipGetLastError());
   rc = wcx_topk_exact_redo_launch(ctx, dXs, B, S, d_redo, d_nredo, d_rtile, d_nredo + 1, d_rlist,
                                   base + o_rscr, row_begin, k, d_out_idx, d_out_dist);
+  if (rc) return rc;
+  return wcx_timer_end(ctx, "topk");
+}
+
+// ------------------------------------------------------------------------------------------
+// Row-sharded reference-bin search WITH the symmetric sweep (multi-GPU).  Every rank holds all
+// of X (one all-gather) and builds the SAME sweep order (deterministic counting sort) and the same
+// thresholds (hub counts of all rows: 1.4 ms, not sharded); the tile PAIRS of the sweep are dealt out to
+// the ranks item by item, each computed once for both directions, and every hit travels as a 16-byte
+// record (row, partner position, screen distance) to the rank that owns the row's list: ONE all-to-all.
+void wcx_sym_state_free(wcx_ctx *ctx) {
+  delete reinterpret_cast<SymShardState *>(ctx->sym_state);
+  ctx->sym_state = nullptr;
+}
+
+int wcx_sym_shard_sweep(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const int64_t *chr_cum, int n_chr,
+                        int k, int part, int n_parts, const int64_t *row_bounds, int64_t *counts_out) {
+  if (!wcx_screen_supported(B, S, k) || n_parts < 1 || n_parts > 32 || B < 32768) {
+    wcx_set_error("sharded symmetric sweep: unsupported shape (B=%lld S=%d k=%d parts=%d)", (long long)B, S, k,
+                  n_parts);
+    return WCX_ERR_UNSUPPORTED;
+  }
+  static const int nk_list[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+  int NK = 64;
+  for (int v : nk_list)
+    if (16 * v >= S + 4) { NK = v; break; }
+  ScreenCfg cfg;
+  cfg.nk = NK;
+  cfg.prof = 0;
+  if (NK <= 8) { cfg.ctg = 2; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 3; cfg.ring = 3; }
+  else if (NK <= 32) { cfg.ctg = NK <= 16 ? 2 : 1; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 2; cfg.ring = 2; }
+  else { cfg.ctg = 1; cfg.tt = 1; cfg.wpb = 4; cfg.lb = 1; cfg.ring = 2; }
+  int hw_cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+      hw_cus = prop.multiProcessorCount;
+  }
+  const int slots = hw_cus * (cfg.lb * 4 / cfg.wpb > 0 ? cfg.lb * 4 / cfg.wpb : 1);
+  if (!ctx->sym_state) ctx->sym_state = new SymShardState();
+  SymShardState *Z = reinterpret_cast<SymShardState *>(ctx->sym_state);
+  Z->valid = false;
+  SymShardCall call;
+  call.part = part; call.n_parts = n_parts; call.state = Z;
+  call.rb.n = n_parts;
+  for (int r = 0; r <= n_parts; ++r) call.rb.b[r] = row_bounds[r];
+  for (int r = n_parts + 1; r < 33; ++r) call.rb.b[r] = B;
+  if (row_bounds[0] != 0 || row_bounds[n_parts] != B) {
+    wcx_set_error("row_bounds must run from 0 to B");
+    return WCX_ERR_ARG;
+  }
+  std::vector<ScreenBlock> none;
+  const int rc = screen_sym_path(ctx, dXs, B, S, chr_cum, n_chr, none, cfg, 16, 0, 1, slots, k, nullptr, nullptr,
+                                 &call);
+  if (rc) return rc;
+  for (int r = 0; r < n_parts; ++r) counts_out[r] = (int64_t)Z->counts[r];
+  return WCX_OK;
+}
+
+int wcx_sym_shard_records(wcx_ctx *ctx, void *d_send) {
+  SymShardState *Z = reinterpret_cast<SymShardState *>(ctx->sym_state);
+  if (!Z || !Z->valid) {
+    wcx_set_error("wcx_newref_sym_records_dev without a sweep");
+    return WCX_ERR_ARG;
+  }
+  unsigned long long cur[32];
+  unsigned long long run = 0;
+  for (int r = 0; r < 32; ++r) { cur[r] = run; run += r < Z->n_parts ? Z->counts[r] : 0; }
+  int rc = wcx_upload_small(ctx, Z->d_counts + 32, cur, sizeof(cur));
+  if (rc) return rc;
+  if (run)
+    k_rec_bucket<<<1024, NT, 0, ctx->stream>>>(Z->pool, Z->pool_head, Z->pool_cap, Z->rb, Z->d_counts + 32,
+                                               reinterpret_cast<uint4 *>(d_send));
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
+int wcx_sym_shard_finish(wcx_ctx *ctx, const void *d_recv, int64_t n_recv, int32_t *d_out_idx,
+                         double *d_out_dist) {
+  SymShardState *Z = reinterpret_cast<SymShardState *>(ctx->sym_state);
+  if (!Z || !Z->valid) {
+    wcx_set_error("wcx_newref_sym_finish_dev without a sweep");
+    return WCX_ERR_ARG;
+  }
+  Z->valid = false;
+  hipStream_t st = ctx->stream;
+  const int64_t r0 = Z->row_begin, n_own = Z->row_end - Z->row_begin;
+  if (n_own <= 0) return wcx_timer_end(ctx, "topk");
+  int rc = wcx_timer_begin(ctx, "topk_cut");
+  if (rc) return rc;
+  int *cnt = Z->cnt + r0;
+  unsigned int *flags = Z->flags + r0;
+  WCX_HIP(hipMemsetAsync(cnt, 0, (size_t)n_own * 4, st));
+  if (n_recv > 0)
+    k_rec_regroup<<<2048, NT, 0, st>>>(reinterpret_cast<const uint4 *>(d_recv), n_recv, r0, n_own, Z->sl, cnt, flags,
+                                       Z->cap2);
+  const float gamma = (float)(16 * Z->NK + 12) * 1.1920929e-7f;
+  const unsigned gf = (unsigned)((n_own + 3) / 4 < 65536 ? (n_own + 3) / 4 : 65536);
+  if (Z->cap2 == CAP2)
+    k_sym_final<CAP2 / 64><<<gf, NT, 0, st>>>(Z->info, Z->glob, Z->rowpos + r0, n_own, Z->sl, cnt, flags,
+                                              Z->Dest + r0, Z->k, gamma, CAP, nullptr);
+  else
+    k_sym_final<CAP2_BIG / 64><<<gf, NT, 0, st>>>(Z->info, Z->glob, Z->rowpos + r0, n_own, Z->sl, cnt, flags,
+                                                  Z->Dest + r0, Z->k, gamma, REFINE_MAX, nullptr);
+  WCX_HIP(hipGetLastError());
+  rc = wcx_timer_end(ctx, "topk_cut");
+  if (rc) return rc;
+  if (ctx->ev_after_sweep) WCX_HIP(hipEventRecord(ctx->ev_after_sweep, st));
+  rc = wcx_aux_kick(ctx);
+  if (rc) return rc;
+  rc = wcx_timer_begin(ctx, "topk_refine");
+  if (rc) return rc;
+  rc = wcx_refine_launch(ctx, Z->Xr, Z->S, Z->Sp, Z->tab, r0, n_own, Z->searched, Z->sl, cnt, flags, Z->perm,
+                         Z->k, d_out_idx, d_out_dist, Z->glob, Z->cap2);
+  if (rc) return rc;
+  rc = wcx_timer_end(ctx, "topk_refine");
+  if (rc) return rc;
+  k_collect_redo<<<(unsigned)((n_own + NT - 1) / NT), NT, 0, st>>>(r0, n_own, Z->searched, flags, Z->tab, Z->d_redo,
+                                                                  Z->d_nredo, ctx->d_stats);
+  k_redo_plan<<<1, 64, 0, st>>>(Z->tab, Z->d_nredo, Z->d_rtile);
+  k_redo_fill<<<(unsigned)((n_own + NT - 1) / NT), NT, 0, st>>>(r0, n_own, Z->searched, flags, Z->tab, Z->d_nredo,
+                                                               Z->d_rlist);
+  WCX_HIP(hipGetLastError());
+  rc = wcx_topk_exact_redo_launch(ctx, Z->dXs, Z->B, Z->S, Z->d_redo, Z->d_nredo, Z->d_rtile, Z->d_nredo + 1,
+                                  Z->d_rlist, Z->rscr, r0, Z->k, d_out_idx, d_out_dist);
   if (rc) return rc;
   return wcx_timer_end(ctx, "topk");
 }

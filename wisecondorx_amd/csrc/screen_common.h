@@ -100,14 +100,20 @@ struct SymArgs {
   int *seq;                   // [quad] exclusive items of the quad that have finished
   int glist_cap;              // ints reserved for the visit list in LDS
   int dbg;
+  int hub_appended = 0;       // the hub pass has appended the hits on hub candidates: skip that direction
+  int force_records = 0;      // row-sharded sweep: every hit becomes a record (its row's list lives elsewhere)
+  int part = 0, n_parts = 1;  // ... and this launch takes the work items  item % n_parts == part
   const unsigned int *gate = nullptr;   // not null: the launch does nothing unless *gate != 0
 };
 // Arguments of the hub-count estimator (screen_count.h).
 struct CountArgs {
   const half8 *F;
   const unsigned char *tchr;
-  const ScreenGlobals *glob;  // n_tiles, n_hub_tiles
+  ScreenGlobals *glob;        // n_tiles, n_hub_tiles
   const int *perm;            // sweep position -> row (-1 = padding)
+  uint2 *sl;                  // second pass: the hub hits go to the rows' lists [row][cap2]
+  int cap2;
+  int append_pass = 0;        // 0 = the counting pass (thresholds), 1 = the second pass (needs sl)
   unsigned int *tinfo;        // out: [tile][64] theta | row id
   float *tmin;                // out: [tile]
   float *Dest;                // out: [row] threshold in screen-distance space

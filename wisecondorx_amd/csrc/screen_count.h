@@ -16,6 +16,12 @@
 // symmetric sweep: the sweep will admit exactly these and whatever else lies below D outside H), so the
 // final cut finds its k entries + filter margin whatever the data -- what depends on the data is only how
 // MANY other pairs D admits (15 kb: ~1.4 need; a sampled estimate with its Poisson allowance: ~2.6 need).
+// SECOND PASS over the same hub tiles (A.sl != nullptr): with the thresholds fixed, every (row, hub
+// candidate) pair below its row's threshold is appended to the row's list here -- this workgroup is the
+// only writer of its 128 rows' lists (register counters, plain stores) -- and the symmetric sweep skips
+// that direction for streamed hub tiles: four fifths of all hits fall on hub candidates, and inside the
+// sweep they cost a whole workgroup ~4 000 cycles per tile pair while the matrix pipe idles (the four
+// waves meet at a barrier every iteration); here the hits are the point of the pass.
 // A row without an estimate (no trial reached `need`) is flagged; if more rows than the redo path takes
 // end up flagged after the sweep (data without hubs), the sampled pre-pass + a second sweep run instead
 // (device-side gate, see screen_sym_path).
@@ -61,7 +67,9 @@ constexpr float CNT_VALID = -2.1e9f;   // accumulators below this belong to padd
 
 // One workgroup per target quad (4 tiles of the sweep order, one per wave); NK, CTG, RING as in
 // k_screen_sym (same fragments, same LDS-DMA ring, same accumulator: acc = -d~/2).
-template <int NK, int CTG, int LBW, int RING>
+// APPEND = false: the counting pass (thresholds); APPEND = true: the second pass (the hub hits -> lists,
+// thresholds read back from tinfo) -- two kernels, so that neither carries the other's registers.
+template <int NK, int CTG, int LBW, int RING, bool APPEND>
 __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
   constexpr int WPB = 4;
   constexpr int TILE_H8 = CTG * NK * 64;
@@ -82,6 +90,8 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
   int ngr = ((int)A.glob->n_hub_tiles + CTG - 1) / CTG;  // hub groups
   if (ngr > A.glist_cap - 64) ngr = A.glist_cap - 64;    // (a degenerate norm distribution: cut the region)
   const int n_hub = (int)A.glob->n_hub_tiles < ngr * CTG ? (int)A.glob->n_hub_tiles : ngr * CTG;
+  // (the sweep skips what the second pass covers: it must see the region as it is used here)
+  if (blockIdx.x == 0 && tid == 0 && n_hub < (int)A.glob->n_hub_tiles) A.glob->n_hub_tiles = (unsigned int)n_hub;
   // visit list: the hub groups in a scrambled order (multiplicative step coprime to their number), those
   // that hold a pair for any wave of the quad; entry = group | chromosome of its tiles (5 bits each)
   if (wave == 0) {
@@ -96,7 +106,9 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
     for (int i0 = 0; i0 < ngr; i0 += 64) {
       const int i = i0 + lane;
       const bool in = i < ngr;
-      const int g = in ? (int)(((long long)i * step + quad) % ngr) : 0;
+      // (the second pass walks the tiles in their own order: the lists then name their entries in sweep
+      //  order for every row alike -- what keeps the refine's gathers of neighbouring rows in step)
+      const int g = in ? (APPEND ? i : (int)(((long long)i * step + quad) % ngr)) : 0;
       bool keep = false;
       int ent = g;
       if (in) {
@@ -157,10 +169,6 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
     }
   }
   n_act_all = __builtin_amdgcn_readfirstlane(n_act_all);
-#pragma unroll
-  for (int q = 0; q < RING - 1; ++q)
-    if (q < n_my) fetch(glist[q] & 0xfffff, q);
-
   double s1 = 0.0, s2 = 0.0;
   int nv = 0, seen = 0;
   bool counting = false;
@@ -169,7 +177,15 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
 #pragma unroll
   for (int j = 0; j < CNT_T; ++j) { thr[j] = HUGE_VALF; cj[j] = 0; }
   const int n1 = A.n1 < n_act_all / 4 ? A.n1 : n_act_all / 4;     // (tiny hub regions: a quarter of them)
-
+  float theta = HUGE_VALF;
+  int chosen = -1, cntr = 0, n_app = 0;
+  uint2 *mine = APPEND ? A.sl + (int64_t)(rowj >= 0 ? rowj : 0) * A.cap2 : nullptr;
+  constexpr int pass = APPEND ? 1 : 0;
+  if (APPEND) theta = (tvalid && rowj >= 0) ? __uint_as_float(A.tinfo[(int64_t)t * 64 + l32]) : HUGE_VALF;
+  {
+#pragma unroll
+  for (int q = 0; q < RING - 1; ++q)
+    if (q < n_my) fetch(glist[q] & 0xfffff, q);
   for (int q = 0; q < n_my; ++q) {
     const int cur = __builtin_amdgcn_readfirstlane(glist[q]);
     const int g = cur & 0xfffff;
@@ -217,6 +233,44 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
       }
       __builtin_amdgcn_sched_group_barrier(0x008, PRE, 0);
     }
+    if constexpr (APPEND) {
+      // second pass: column-direction hits against the fixed threshold, straight to my row's list
+#pragma unroll
+      for (int s = 0; s < CTG; ++s) {
+        if (!act[s]) continue;                         // wave-uniform
+        float m = fmaxf(fmaxf(acc[s][0], acc[s][1]), acc[s][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[s][r]), acc[s][r + 1]);
+        m = fmaxf(m, acc[s][15]);
+        if (!__any(m >= theta)) continue;
+        unsigned int pm = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pm = __builtin_amdgcn_alignbit(pm, ~__float_as_uint(acc[s][r] - theta), 31);
+        pm &= 0xffffu;
+        const unsigned int anym = wcx::wave_or_u32(pm);
+        if (anym == 0) continue;
+        const unsigned int pc = (unsigned int)__popc(pm);
+        n_app += (int)pc;
+        const auto pcs = __builtin_amdgcn_permlane32_swap(pc, pc, false, false);
+        int ofs = cntr + (hf ? (int)pcs[0] : 0);
+        cntr += (int)(pcs[0] + pcs[1]);
+        const unsigned int cposb = (unsigned int)((g * CTG + s) * 32 + 4 * hf);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (anym & (0x8000u >> r)) {
+            asm volatile("" ::: "memory");               // (keeps the two tests separate)
+            if (pm & (0x8000u >> r)) {
+              if (ofs < A.cap2)
+                mine[ofs] = make_uint2(__float_as_uint(-2.f * acc[s][r]),
+                                       cposb + (unsigned int)(8 * (r >> 2) + (r & 3)));
+              ++ofs;
+            }
+          }
+        }
+      }
+      continue;
+    } else {
 #pragma unroll
     for (int s = 0; s < CTG; ++s) {
       if (!act[s]) continue;                           // wave-uniform
@@ -263,22 +317,37 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
         cj[j] = c;
       }
     }
+    }
   }
+  if constexpr (!APPEND) {
   // tightest trial with `need` hub candidates below it
-  float theta = HUGE_VALF;
-  int chosen = -1;
 #pragma unroll
   for (int j = CNT_T - 1; j >= 0; --j) {
     const int tot = cj[j] + __shfl_xor(cj[j], 32, 64);
     if (counting && tot >= A.need) { theta = thr[j]; chosen = j; }
   }
+  if (!tvalid || rowj < 0 || chosen < 0 || !(theta > CNT_VALID)) theta = HUGE_VALF;
+  }
+  }
+  (void)pass;
+  if constexpr (APPEND) {
+    if (tvalid && hf == 0 && rowj >= 0) {
+      A.cnt[rowj] = cntr;                            // entries this pass appended
+      if (cntr > A.cap2) A.flags[rowj] = 1u;
+    }
+    if (A.stats) {
+      const int tot_a = wcx::wave_sum_i(n_app);
+      if (lane == 0) atomicAdd(&A.stats[4], (unsigned long long)tot_a);
+    }
+    return;
+  }
   if (tvalid && hf == 0) {
     const int64_t p = (int64_t)t * 32 + l32;
     if (rowj >= 0) {
-      if (chosen < 0 || !(theta > CNT_VALID)) { A.flags[rowj] = 1u; theta = HUGE_VALF; }
+      if (!(theta < HUGE_VALF)) A.flags[rowj] = 1u;
       A.Dest[rowj] = -2.f * theta;                 // threshold in screen-distance space (-inf if none)
       A.cnt[rowj] = 0;
-    } else theta = HUGE_VALF;
+    }
     A.tinfo[(p >> 5) * 64 + l32] = __float_as_uint(theta);
     A.tinfo[(p >> 5) * 64 + 32 + l32] = (unsigned int)rowj;
   }
@@ -291,8 +360,8 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
     }
     if (lane == 0) A.tmin[t] = m;
     if (A.stats) {                                     // (diagnostics: mean trial chosen, rows without one)
-      const bool mine = hf == 0 && rowj >= 0;
-      const int cs = wcx::wave_sum_i(mine && chosen >= 0 ? chosen : 0), cf = wcx::wave_sum_i(mine && chosen < 0 ? 1 : 0);
+      const bool is_row = hf == 0 && rowj >= 0;
+      const int cs = wcx::wave_sum_i(is_row && chosen >= 0 ? chosen : 0), cf = wcx::wave_sum_i(is_row && chosen < 0 ? 1 : 0);
       if (lane == 0) { atomicAdd(&A.stats[12], (unsigned long long)cs); atomicAdd(&A.stats[13], (unsigned long long)cf); }
     }
   }
@@ -300,10 +369,14 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
 
 template <int NK, int CTG, int LBW, int RING>
 int count_launch_t(const CountArgs &a, unsigned grid, size_t lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen_count<NK, CTG, LBW, RING>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen_count<NK, CTG, LBW, RING, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_screen_count<NK, CTG, LBW, RING, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  k_screen_count<NK, CTG, LBW, RING><<<grid, 256, lds, st>>>(a);
+  if (a.append_pass) k_screen_count<NK, CTG, LBW, RING, true><<<grid, 256, lds, st>>>(a);
+  else k_screen_count<NK, CTG, LBW, RING, false><<<grid, 256, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 #define WCX_COUNT_TRY(N, C, L, R) \

@@ -51,6 +51,9 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
   int &s_nlist = *s_nlist_p;
 
   const int n_tiles = (int)A.glob->n_tiles;
+  // hub candidates' hits are already in the lists (second pass of k_screen_count): a streamed hub tile
+  // is only met in the ROW direction (its rows as targets), a pair of two hub tiles not at all
+  const int n_hub = A.hub_appended ? (int)A.glob->n_hub_tiles : 0;
   const int t0 = quad * 4;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -88,7 +91,8 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
           const int cc = c < n_tiles ? (int)A.tchr[c] : 255;
           ent |= (cc & 31) << (20 + 5 * s);
 #pragma unroll
-          for (int w = 0; w < 4; ++w) keep = keep || (cc != 255 && c < t0 + w && tq[w] != 255 && cc != tq[w]);
+          for (int w = 0; w < 4; ++w)
+            keep = keep || (cc != 255 && c < t0 + w && tq[w] != 255 && cc != tq[w] && !(t0 + w < n_hub));
         }
       }
       const unsigned long long bal = __ballot(keep);
@@ -200,7 +204,7 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
 #pragma unroll
     for (int s = 0; s < CTG; ++s) {
       const int c = g * CTG + s;
-      act[s] = c < t && ((cur >> (20 + 5 * s)) & 31) != mychr;
+      act[s] = c < t && ((cur >> (20 + 5 * s)) & 31) != mychr && !(t < n_hub);
       any_act = any_act || act[s];
     }
     if (!any_act) continue;                          // wave-uniform
@@ -250,7 +254,7 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
 #pragma unroll
       for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[s][r]), acc[s][r + 1]);
       m = fmaxf(m, acc[s][15]);
-      const bool col_gate = __any(m >= thj), row_gate = __any(m >= thc[s]);
+      const bool col_gate = (g * CTG + s >= n_hub) && __any(m >= thj), row_gate = __any(m >= thc[s]);
       if (!(col_gate || row_gate) || (A.dbg & 1)) continue;
       ++C.n_slow;
       C.n_cg += col_gate ? 1u : 0u;
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
     __syncthreads();
     const int item_g = s_item;
     if (item_g >= A.total_items) break;
+    if (A.n_parts > 1 && item_g % A.n_parts != A.part) continue;      // another rank's work item
     if (tid < A.n_desc && item_g >= A.desc[tid].item_base &&
         item_g < A.desc[tid].item_base + A.desc[tid].n_q * A.desc[tid].n_split)
       s_desc = tid;
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(256, LBW) void k_screen_sym(const SymArgs A) {
     const int item = item_g - d.item_base;
     const int quad = d.q_first + item / d.n_split, split = item % d.n_split;
     if (quad * 4 >= n_tiles) continue;                 // (the tables are sized for a tile bound)
-    const int excl = d.n_split == 1 ? 1 : 0;
+    const int excl = (d.n_split == 1 && !A.force_records) ? 1 : 0;
     if (excl) {
       if (tid == 0) {
         while (__hip_atomic_load(&A.seq[quad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != d.index)

@@ -87,7 +87,14 @@ struct wcx_ctx {
   int pca_S = 0;
   // host staging for small async uploads (kept alive until the next stream sync)
   std::vector<std::vector<unsigned char>> stage;
+  void *sym_state = nullptr;   // row-sharded symmetric sweep between its phases (newref_topk_screen.hip)
 };
+void wcx_sym_state_free(wcx_ctx *ctx);
+int wcx_sym_shard_sweep(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const int64_t *chr_cum, int n_chr,
+                        int k, int part, int n_parts, const int64_t *row_bounds, int64_t *counts_out);
+int wcx_sym_shard_records(wcx_ctx *ctx, void *d_send);
+int wcx_sym_shard_finish(wcx_ctx *ctx, const void *d_recv, int64_t n_recv, int32_t *d_out_idx,
+                         double *d_out_dist);
 
 struct wcx_ref {
   const int32_t *d_idx = nullptr;

@@ -172,6 +172,106 @@ class GpuBackend(_GpuPredictMixin):
                                                d_idx.data_ptr() + skip * k * 4, real_lo, row_end, k,
                                                ids_p, len(ids), d_nr.data_ptr() + skip * len(ids) * 8))
 
+    # ---- the row-sharded symmetric sweep (wcx_newref_sym_*_dev): search() split around the exchange
+    def sym_sweep(self, d_Xs, B, S, chr_cum, k, rank, world, bounds, sample_ids):
+        """Phase 1: thresholds of all rows + this rank's tile pairs -> records.  Returns the number of
+        records for every destination rank, or None where the library has no symmetric sweep for
+        the shape (the caller then searches its row range the one-directional way)."""
+        from . import _lib
+        lib = self.ctx.lib
+        cum, cum_p = _lib.i64_array(chr_cum)
+        if len(cum) > 22 or world > 32:
+            return None
+        ids, ids_p = _lib.i32_array(sample_ids)
+        bnd, bnd_p = _lib.i64_array(bounds)
+        counts = (_lib.C.c_int64 * world)()
+        if bounds[rank] < bounds[rank + 1]:
+            _lib.check(lib.wcx_null_rank_prepare_dev(self.ctx.h, d_Xs.data_ptr(), B, S, ids_p, len(ids)))
+        rc = lib.wcx_newref_sym_sweep_dev(self.ctx.h, d_Xs.data_ptr(), B, S, cum_p, len(cum), int(k), int(rank),
+                                          int(world), bnd_p, counts)
+        if rc == _lib.WCX_ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc)
+        return [int(c) for c in counts]
+
+    def sym_records(self, send):
+        from . import _lib
+        _lib.check(self.ctx.lib.wcx_newref_sym_records_dev(self.ctx.h, send.data_ptr()))
+
+    def sym_finish(self, recv, d_Xs, B, S, chr_cum, row_begin, row_end, k, sample_ids, d_idx, d_dist, d_nr):
+        from . import _lib
+        lib = self.ctx.lib
+        ids, ids_p = _lib.i32_array(sample_ids)
+        _lib.check(lib.wcx_newref_sym_finish_dev(self.ctx.h, recv.data_ptr() if recv.shape[0] else None,
+                                                 int(recv.shape[0]), d_idx.data_ptr(), d_dist.data_ptr()))
+        if row_begin < row_end:
+            _lib.check(lib.wcx_null_ratios_dev(self.ctx.h, d_Xs.data_ptr(), B, S, d_idx.data_ptr(), row_begin,
+                                               row_end, k, ids_p, len(ids), d_nr.data_ptr()))
+
+
+def exchange_records(send, counts, world, group=None):
+    """The ONE all-to-all of the row-sharded symmetric sweep: `send` holds this rank's records grouped by
+    destination rank ([sum(counts), 4] int32, counts[r] of them for rank r); returns the records the
+    other ranks (and this one) hold for THIS rank's rows.  The counts travel first (world integers)."""
+    import torch
+    import torch.distributed as dist
+    cnt_in = torch.tensor([int(c) for c in counts], dtype=torch.int64)
+    cnt_out = torch.empty(world, dtype=torch.int64)
+    host = dist.get_backend(group) == "gloo"
+    if host:
+        dist.all_to_all_single(cnt_out, cnt_in, group=group)
+    else:
+        ci, co = cnt_in.to(send.device), cnt_out.to(send.device)
+        dist.all_to_all_single(co, ci, group=group)
+        cnt_out = co.cpu()
+    n_recv = int(cnt_out.sum())
+    if host and send.is_cuda:
+        # testing only (ranks sharing one device): gloo exchanges through host memory
+        recv_h = torch.empty((n_recv, 4), dtype=send.dtype)
+        dist.all_to_all_single(recv_h, send.cpu(), [int(c) for c in cnt_out], [int(c) for c in cnt_in],
+                               group=group)
+        return recv_h.to(send.device)
+    recv = torch.empty((n_recv, 4), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send, [int(c) for c in cnt_out], [int(c) for c in cnt_in], group=group)
+    return recv
+
+
+def newref_sym_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, world, out=None):
+    """Sharded build of an AUTOSOMAL pass with the symmetric sweep: newref_sharded's contract (same
+    arguments, same results, bit for bit), but the tile PAIRS of the all-rows sweep are dealt out to the
+    ranks -- each pair computed once, for both directions -- instead of every rank sweeping its target
+    rows against all candidates.  Exchanges: the all-gather of X (as before) + ONE all-to-all of the hit
+    records (16 bytes each, ~0.5 k per row at 15 kb).  Falls back to newref_sharded's search where the
+    backend has no symmetric sweep for the shape (every rank takes the same branch: it depends on the
+    shape alone)."""
+    import torch
+    if world > 1 and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
+        Xs = backend.gather_transpose(gather_padded(local_rows, world), world, local_rows.shape[0],
+                                      n_rows)
+    else:
+        full = allgather_rows(local_rows, n_rows, world).contiguous()
+        Xs = backend.transpose(full) if hasattr(backend, "transpose") else full.t().contiguous()
+    S = Xs.shape[0]
+    b, e = row_shard(rank, world, n_rows)
+    n = e - b
+    dev = local_rows.device
+    if out is None:
+        out = (torch.empty((max(n, 1), k), dtype=torch.int32, device=dev),
+               torch.empty((max(n, 1), k), dtype=torch.float64, device=dev),
+               torch.empty((max(n, 1), len(sample_ids)), dtype=torch.float64, device=dev))
+    bounds = [row_shard(r, world, n_rows)[0] for r in range(world)] + [n_rows]
+    counts = backend.sym_sweep(Xs, n_rows, S, chr_cum, k, rank, world, bounds, sample_ids) \
+        if world > 1 and hasattr(backend, "sym_sweep") else None
+    if counts is None:
+        backend.search(Xs, n_rows, S, chr_cum, b, e, k, sample_ids, out[0], out[1], out[2])
+        return out[0][:n], out[1][:n], out[2][:n], Xs
+    send = torch.empty((int(sum(counts)), 4), dtype=torch.int32, device=dev)
+    backend.sym_records(send)
+    recv = exchange_records(send, counts, world)
+    backend.sym_finish(recv, Xs, n_rows, S, chr_cum, b, e, k, sample_ids, out[0], out[1], out[2])
+    newref_sym_sharded.last_records = (int(sum(counts)), int(recv.shape[0]))       # (bench / tests)
+    return out[0][:n], out[1][:n], out[2][:n], Xs
+
 
 def newref_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, world, out=None):
     """Sharded reference build on torch tensors.

@@ -123,7 +123,9 @@ def _build_sub_reference_sharded(args, gender, total_mask, bins_per_chr, dc, sel
     local = torch.zeros((wd.max_shard_rows(world, B), S), dtype=torch.float64, device=Xs.device)
     local[:re_ - rb] = Xs[:, rb:re_].t()
     if gender == "A":
-        idx_l, dist_l, nr_l, _ = wd.newref_sharded(local, B, cum, k, sample_ids, backend, rank, world)
+        # (the symmetric sweep's tile pairs dealt out to the ranks + one all-to-all of the hit records;
+        #  where the library has no symmetric sweep for the shape it searches the row range itself)
+        idx_l, dist_l, nr_l, _ = wd.newref_sym_sharded(local, B, cum, k, sample_ids, backend, rank, world)
         idx, dist_, nr = wd.gather_reference3(idx_l, dist_l, nr_l, B, world, backend)
     else:
         dev = Xs.device
