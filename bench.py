@@ -45,7 +45,7 @@ def screen_source_sha():
     """Hash of the screen kernel's sources: roofline.traffic (PMC counters recorded by
     scripts/measure_traffic.sh) is only reported while the kernel is the one that was profiled."""
     h = hashlib.sha256()
-    for f in ("screen_kernel.h", "screen_sym.h", "screen_common.h", "newref_topk_screen.hip"):
+    for f in ("screen_kernel.h", "screen_sym.h", "screen_count.h", "screen_common.h", "newref_topk_screen.hip"):
         h.update(open(os.path.join(ROOT, "wisecondorx_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

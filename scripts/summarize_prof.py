@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<round> (scripts/measure_traffic.sh) into profiles/<round>/ (round = $WCX_PROF_ROUND, default r04):
+"""Condense gpurun_out/prof_<round> (scripts/measure_traffic.sh) into profiles/<round>/ (round = $WCX_PROF_ROUND, default r05):
   kernel_stats_S<S>.csv     rocprofv3 --kernel-trace --stats summary of the bench command
   pmc_S<S>.csv              per-kernel sums of every counter (all PMC passes) + dispatch counts
   screen_traffic.json       per-sweep HBM bytes and SQ breakdown of k_screen, keyed by workload, with
@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = os.environ.get("WCX_PROF_ROUND", "r04")
+ROUND = os.environ.get("WCX_PROF_ROUND", "r05")
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
 
@@ -61,6 +61,8 @@ def main():
                     name = short_name(r["Kernel_Name"])
                     if "k_screen_sym<" in r["Kernel_Name"]:
                         name = "k_screen_sym"       # the symmetric sweep of the autosomal pass (one launch)
+                    elif "k_screen_count<" in r["Kernel_Name"]:
+                        name = "k_screen_count"     # its thresholds: counts over the hub region
                     elif "k_screen<" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]:
                         # the step runs three passes: the autosomal one (all S samples: the largest
                         # NK of the run) is the dominant kernel, the two gonosomal ones (S / 2
@@ -80,14 +82,19 @@ def main():
                          + "," + str(len(disp[(k, 1)])) + "\n")
         # the autosomal sweep = (symmetric path) the pre-pass k_screen + k_screen_sym, or k_screen alone
         sym = "k_screen_sym" in agg
+        hub = "k_screen_count" in agg
         p = collections.defaultdict(float)
-        for part in (("k_screen", "k_screen_sym") if sym else ("k_screen",)):
+        # (with hub-count thresholds the sampled pre-pass k_screen only runs behind a gate that stays
+        #  closed: its launches return at once and are counted with the sweep all the same)
+        for part in (("k_screen", "k_screen_count", "k_screen_sym") if sym else ("k_screen",)):
             for c_, v_ in agg[part].items():
                 p[c_] += v_
         wave = p.get("SQ_WAVE_CYCLES", 0.0)
         out["workloads"]["S%d" % S] = {
-            "kernels": "k_screen (sampled pre-pass) + k_screen_sym" if sym else "k_screen",
-            "launches_per_sweep": (len(disp[("k_screen", 1)]) + len(disp[("k_screen_sym", 1)])) / sweeps,
+            "kernels": ("k_screen_count (hub-count thresholds) + k_screen_sym (+ the gated second attempt's "
+                        "empty launches)" if hub else "k_screen (sampled pre-pass) + k_screen_sym") if sym else "k_screen",
+            "launches_per_sweep": (len(disp[("k_screen", 1)]) + len(disp[("k_screen_sym", 1)]) +
+                                   len(disp[("k_screen_count", 1)])) / sweeps,
             "fetch_bytes_per_sweep_raw": p.get("FETCH_SIZE", 0.0) * 1024 / sweeps,
             "fetch_bytes_per_sweep_corrected_x2": 2 * p.get("FETCH_SIZE", 0.0) * 1024 / sweeps,
             "write_bytes_per_sweep": p.get("WRITE_SIZE", 0.0) * 1024 / sweeps,

@@ -203,6 +203,7 @@ class OracleSymBackend(OracleBackend):
 
 def _worker_sym(rank, world, port, X, cum, k, ids, q):
     sys.path.insert(0, ROOT)
+    os.environ["WCX_SYM_SHARD_MIN"] = "2"
     import torch
     import torch.distributed as dist
     from wisecondorx_amd import dist as wd

@@ -122,6 +122,7 @@ def test_bench_two_ranks_smoke(mode):
 
 def _worker_sym(rank, world, port, X, cum, k, ids, q):
     sys.path.insert(0, ROOT)
+    os.environ["WCX_SYM_SHARD_MIN"] = "2"
     import torch
     import torch.distributed as dist
     from wisecondorx_amd import _lib

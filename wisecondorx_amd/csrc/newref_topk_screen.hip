@@ -844,18 +844,47 @@ __global__ __launch_bounds__(NT) void k_rec_hist(const uint4 *__restrict__ pool,
   __syncthreads();
   if (threadIdx.x < 32 && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
-// cursor[r] = first slot of destination r in the send buffer (advanced by the records placed)
-__global__ __launch_bounds__(NT) void k_rec_bucket(const uint4 *__restrict__ pool,
-                                                   const unsigned int *__restrict__ pool_head,
-                                                   unsigned int pool_cap, RowBounds rb,
-                                                   unsigned long long *__restrict__ cursor,
-                                                   uint4 *__restrict__ send) {
+// cursor[r] = first slot of destination r in the send buffer (advanced by the records placed).
+// A workgroup places 1024 records at a time: ranks within the chunk through LDS counters, ONE global
+// atomic per (chunk, destination) -- a returning atomic per record on the same few addresses serialises
+// at ~10 ns each (measured: 0.5 s for 44 M records).
+__global__ __launch_bounds__(1024) void k_rec_bucket(const uint4 *__restrict__ pool,
+                                                     const unsigned int *__restrict__ pool_head,
+                                                     unsigned int pool_cap, RowBounds rb,
+                                                     unsigned long long *__restrict__ cursor,
+                                                     uint4 *__restrict__ send) {
+  __shared__ unsigned int cntL[32];
+  __shared__ unsigned long long baseL[32];
   unsigned int n = *pool_head;
   if (n > pool_cap) n = pool_cap;
-  for (unsigned int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-    const uint4 rec = pool[i];
-    const unsigned long long slot = atomicAdd(&cursor[owner_of(rb, rec.x)], 1ull);
-    send[slot] = rec;
+  const int lane = wcx::lane_id();
+  for (unsigned int c0 = blockIdx.x * 1024u; c0 < n; c0 += gridDim.x * 1024u) {
+    if (threadIdx.x < 32) cntL[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned int i = c0 + threadIdx.x;
+    const bool in = i < n;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    int dest = -1;
+    if (in) { rec = pool[i]; dest = owner_of(rb, rec.x); }
+    // per wave and destination: one LDS atomic, the lanes' ranks from the ballot
+    unsigned int my = 0u;
+    unsigned long long todo = __ballot(in);
+    while (todo) {
+      const int first = __builtin_ctzll(todo);
+      const int d = __builtin_amdgcn_readlane(dest, first);
+      const unsigned long long m = __ballot(dest == d);
+      unsigned int b = 0u;
+      if (lane == first) b = atomicAdd(&cntL[d], (unsigned int)__popcll(m));
+      b = (unsigned int)__builtin_amdgcn_readlane((int)b, first);
+      if (dest == d) my = b + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+      todo &= ~m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && cntL[threadIdx.x])
+      baseL[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)cntL[threadIdx.x]);
+    __syncthreads();
+    if (in) send[baseL[dest] + my] = rec;
+    __syncthreads();
   }
 }
 // records received for the rows [row0, row0 + n_own): into the rows' lists (list index = row - row0)
@@ -960,6 +989,7 @@ static int count_dispatch(int nk, int ctg, int lb, int ring, const CountArgs &a,
   int rc = wcx_count_launch_k1(nk, ctg, lb, ring, a, grid, lds, st);
   if (rc < 0) rc = wcx_count_launch_k2(nk, ctg, lb, ring, a, grid, lds, st);
   if (rc < 0) rc = wcx_count_launch_k3(nk, ctg, lb, ring, a, grid, lds, st);
+  if (rc < 0) rc = wcx_count_launch_k4(nk, ctg, lb, ring, a, grid, lds, st);
   return rc;
 }
 
@@ -989,10 +1019,12 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   // rows, at least 6 x the entries wanted below an estimate (1.18 k: the k-th neighbour's filter bound
   // ranks ~1.14 k)
   const int need = (int)(1.18 * k) + 8;
-  const int hub_frac = env_int("WCX_HUB_FRAC", 32);
+  // (few samples: the distances are noisier and the neighbours less concentrated on the low-norm rows --
+  //  two thirds of them in the lowest 1/16 at S = 100 against 98 % at S = 500: a larger region)
+  const int hub_frac = env_int("WCX_HUB_FRAC", NK >= 16 ? 32 : 12);
   int64_t hub_rows = hub_frac > 1 ? B / hub_frac : 0;
   if (hub_rows < 6 * (int64_t)need) hub_rows = 6 * (int64_t)need;
-  const bool use_hub = env_int("WCX_SYM_HUB", 1) != 0 && NK >= 16 && hub_frac > 1 && hub_rows * 6 <= B;
+  const bool use_hub = env_int("WCX_SYM_HUB", 1) != 0 && NK >= 5 && hub_frac > 1 && hub_rows * 6 <= B;
   if (sh && !use_hub) {
     wcx_set_error("the row-sharded symmetric sweep needs the hub-count thresholds (K >= 256, B >= %lld)",
                   (long long)(36 * (int64_t)need));
@@ -1873,7 +1905,7 @@ int wcx_sym_shard_records(wcx_ctx *ctx, void *d_send) {
   int rc = wcx_upload_small(ctx, Z->d_counts + 32, cur, sizeof(cur));
   if (rc) return rc;
   if (run)
-    k_rec_bucket<<<1024, NT, 0, ctx->stream>>>(Z->pool, Z->pool_head, Z->pool_cap, Z->rb, Z->d_counts + 32,
+    k_rec_bucket<<<2048, 1024, 0, ctx->stream>>>(Z->pool, Z->pool_head, Z->pool_cap, Z->rb, Z->d_counts + 32,
                                                reinterpret_cast<uint4 *>(d_send));
   WCX_HIP(hipGetLastError());
   return WCX_OK;

@@ -128,6 +128,7 @@ struct CountArgs {
 int wcx_count_launch_k1(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_count_launch_k2(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_count_launch_k3(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds, hipStream_t st);
+int wcx_count_launch_k4(int nk, int ctg, int lb, int ring, const CountArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_sym_launch_k1(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_sym_launch_k2(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_sym_launch_k3(int nk, int ctg, int lb, int ring, const SymArgs &a, unsigned grid, size_t lds, hipStream_t st);

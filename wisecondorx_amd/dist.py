@@ -260,8 +260,15 @@ def newref_sym_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank
                torch.empty((max(n, 1), k), dtype=torch.float64, device=dev),
                torch.empty((max(n, 1), len(sample_ids)), dtype=torch.float64, device=dev))
     bounds = [row_shard(r, world, n_rows)[0] for r in range(world)] + [n_rows]
+    # Measured on one device (scripts/bench_shard_sym.py, profiles/r05/shard_sym_S500.json): a rank's wall
+    # at N = 2 / 4 / 8 ranks is 35.2 / 19.1 / 11.2 ms this way against 31.6 / 17.7 / 11.9 ms with the
+    # one-directional sweep of its row range -- every hit travels as a record here (dearer than a direct
+    # append) and prep + thresholds of ALL rows (3 ms) do not shard -- so the symmetric form is the default
+    # from 8 ranks on (WCX_SYM_SHARD_MIN overrides; 2 in the tests).
+    import os
+    sym_min = int(os.environ.get("WCX_SYM_SHARD_MIN", "8"))
     counts = backend.sym_sweep(Xs, n_rows, S, chr_cum, k, rank, world, bounds, sample_ids) \
-        if world > 1 and hasattr(backend, "sym_sweep") else None
+        if world >= max(2, sym_min) and hasattr(backend, "sym_sweep") else None
     if counts is None:
         backend.search(Xs, n_rows, S, chr_cum, b, e, k, sample_ids, out[0], out[1], out[2])
         return out[0][:n], out[1][:n], out[2][:n], Xs
