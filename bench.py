@@ -308,7 +308,7 @@ class Workload:
                     else wd.newref_sharded
                 idx_l, dist_l, nr_l, _ = shard_fn(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
                                                   self.backend, self.rank, self.world, out=P["bufs"])
-                if self.args.debug_flags & 59:           # (ablations leave garbage neighbour tables)
+                if self.args.debug_flags & 123:           # (ablations leave garbage neighbour tables)
                     ctx.timer_tag("")
                     ctx.sync()
                     if record:
@@ -531,8 +531,10 @@ def e2e_cli_block(w, workdir=None):
                        w.args.binsize)
     ref_file = os.path.join(workdir, "ref.npz")
     random.seed(1)
-    out = {"workload": "CLI newref ({} sample files, {} bp bins, refsize {}, --aligned-masks) + predict "
-                       "--bed of 1 sample, one device".format(len(files), w.args.binsize, w.k)}
+    out = {"workload": "CLI newref ({} sample files, {} bp bins, refsize {}, --aligned-masks --yfrac 0.004: the "
+                       "synthetic cohort's gonosomal passes drop an autosomal bin, which the default refuses to "
+                       "write, and its Y fractions have no mixture minimum) + predict --bed of 1 sample, one "
+                       "device".format(len(files), w.args.binsize, w.k)}
     try:
         t0 = time.perf_counter()
         cli.main(["--loglevel", "error", "newref"] + files + [
@@ -772,6 +774,9 @@ def main():
                                 "ms_per_step": dt3 / args.steps * 1e3, "value": w3.pairs_total / (dt3 / args.steps),
                                 "bins": int(w3.B), "screen_ms": r3.get("kernel_ms"), "refine_ms": r3.get("refine_ms"),
                                 "roofline_frac": r3.get("frac"), "null_ratios_ms": r3.get("null_ratios_ms")}
+        # the CLI's wall-clock at the reference's DEFAULT bin size (main.py:377-380) -- the common
+        # production shape -- beside the headline 15 kb one
+        out["e2e_cli_100kb"] = e2e_cli_block(w3)
         del w3
         out["e2e_cli"] = e2e_cli_block(w)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1016,14 +1016,16 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   // list capacity per row: the estimates admit ~4 k entries at k = 300, ~2.7 k at k = 1000
   const int cap2 = k <= 448 ? CAP2 : CAP2_BIG;
   // hub-count estimates (attempt 1): WCX_SYM_HUB=0 turns them off; the region is 1 / WCX_HUB_FRAC of the
-  // rows, at least 6 x the entries wanted below an estimate (1.18 k: the k-th neighbour's filter bound
+  // rows, at least 8 x the entries wanted (+ 512) below an estimate (1.18 k: the k-th neighbour's filter bound
   // ranks ~1.14 k)
   const int need = (int)(1.18 * k) + 8;
   // (few samples: the distances are noisier and the neighbours less concentrated on the low-norm rows --
   //  two thirds of them in the lowest 1/16 at S = 100 against 98 % at S = 500: a larger region)
   const int hub_frac = env_int("WCX_HUB_FRAC", NK >= 16 ? 32 : 12);
   int64_t hub_rows = hub_frac > 1 ? B / hub_frac : 0;
-  if (hub_rows < 6 * (int64_t)need) hub_rows = 6 * (int64_t)need;
+  // (at least 8 x the entries wanted + the 512 candidates of the moment phase: the loosest trial sits at
+  //  4 x need among what is left after the row's own chromosome is taken out)
+  if (hub_rows < 8 * (int64_t)need + 512) hub_rows = 8 * (int64_t)need + 512;
   const bool use_hub = env_int("WCX_SYM_HUB", 1) != 0 && NK >= 5 && hub_frac > 1 && hub_rows * 6 <= B;
   if (sh && !use_hub) {
     wcx_set_error("the row-sharded symmetric sweep needs the hub-count thresholds (K >= 256, B >= %lld)",
@@ -1216,7 +1218,10 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   // quads above it, a quad is one work item per chunk and its column-direction hits go straight to
   // the lists (exclusive items, ordered per quad); the chunks high in the order, which few quads
   // still stream, split a quad over several items that write records instead.
-  int64_t Cz = ((int64_t)env_int("WCX_SYM_CHUNK_KB", NK > 16 ? 8192 : 3072) << 10) / ((int64_t)NK * 1024);
+  // (a chunk that fits an XCD's 4 MB L2 is fetched once per XCD and round of workgroups; an 8 MB chunk --
+  //  the round-4 default at K = 512 -- cycles through it: 45.4 GB fetched per sweep against 16.6 GB at
+  //  3 MB, 21.5 against 20.9 ms; 1.5 / 2 / 4 MB: 19.3 / 16.8 / 21.8 GB: scripts/sweep_sym_chunk_traffic.sh)
+  int64_t Cz = ((int64_t)env_int("WCX_SYM_CHUNK_KB", 3072) << 10) / ((int64_t)NK * 1024);
   Cz = Cz / 8 * 8;
   if (Cz < 32) Cz = 32;
   if (Cz > 8192) Cz = 8192;
@@ -1298,7 +1303,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     ca.F = F; ca.tchr = tchr; ca.glob = glob; ca.perm = perm; ca.tinfo = tinfo; ca.tmin = tmin;
     ca.Dest = Dest; ca.cnt = cnt_out; ca.flags = flags; ca.stats = ctx->d_stats;
     ca.need = need; ca.n1 = n1_tiles; ca.gate = nullptr;
-    const bool hub_pass = env_int("WCX_HUB_APPEND", 0) != 0 && !(ctx->debug_flags & 59) && !sh;
+    const bool hub_pass = env_int("WCX_HUB_APPEND", 0) != 0 && !(ctx->debug_flags & 123) && !sh;
     ca.sl = hub_pass ? sl : nullptr; ca.cap2 = cap2;
     sa.hub_appended = hub_pass ? 1 : 0;
     // the visit list holds the hub groups only: room for twice the rows asked for (the quantile takes a
@@ -1356,7 +1361,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
     }
     rc = sweep_and_cut(nullptr);
     if (rc) return rc;
-    if (!(ctx->debug_flags & 59)) {      // (the ablations leave every row unfinished: one sweep is what they time)
+    if (!(ctx->debug_flags & 123)) {      // (the ablations leave every row unfinished: one sweep is what they time)
       k_hub_count_failed<<<512, NT, 0, st>>>(flags, n_rows, d_failed);
       k_hub_verdict<<<1, 64, 0, st>>>(d_failed, d_gate, ctx->d_stats);
     }

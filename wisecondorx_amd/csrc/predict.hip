@@ -299,10 +299,14 @@ __global__ __launch_bounds__(NT) void k_normalize_pass_tile(
 // of identical values ends like np.std's (see below).  (Measured, 96 samples at 15 kb: the three
 // passes 42.8 -> 34.8 ms; a variant with two bins x 32 samples per wave -- no idle lanes for 96
 // samples -- was slower, 36.4 ms: the kernel is bound by its per-element instructions, not by bytes.)
+// st_S1 != nullptr (pass 0 of the incremental scheme, k_normalize_mask_incr): the sums, the count and the
+// word of newly masked samples of every (bin, 64-sample tile) are kept; the masked copy is not written.
 __global__ __launch_bounds__(NT) void k_normalize_mask_lanes(
     const double *__restrict__ xT, const double *__restrict__ copy_in, double *__restrict__ copy_out,
     const int32_t *__restrict__ idx, const unsigned long long *__restrict__ sel, int64_t B, int k,
-    int ipl, int NS, int64_t lo, int64_t hi, ChrTable chr) {
+    int ipl, int NS, int64_t lo, int64_t hi, ChrTable chr, double *__restrict__ st_S1 = nullptr,
+    double *__restrict__ st_S2 = nullptr, int *__restrict__ st_n = nullptr,
+    unsigned long long *__restrict__ st_mask = nullptr) {
   const int lane = wcx::lane_id();
   const int s = blockIdx.y * 64 + lane;             // my sample (NS is a multiple of 64)
   const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
@@ -362,7 +366,94 @@ __global__ __launch_bounds__(NT) void k_normalize_mask_lanes(
     const double var = (S2 - S1 * (S1 / dn)) / dn;
     const double sd = sqrt(var > 0.0 ? var : 0.0);
     const double z = (c0 - mean) / sd;                // predict_tools.py:136
-    copy_out[i * NS + s] = (fabs(z) >= Z_MASK) ? -1.0 : copy_in[i * NS + s];   // :104
+    if (st_S1) {
+      st_S1[i * NS + s] = S1;
+      st_S2[i * NS + s] = S2;
+      st_n[i * NS + s] = n;
+      const unsigned long long m = __ballot(fabs(z) >= Z_MASK && copy_in[i * NS + s] >= 0.0);
+      if (lane == 0) st_mask[i * (NS >> 6) + blockIdx.y] = m;
+    } else {
+      copy_out[i * NS + s] = (fabs(z) >= Z_MASK) ? -1.0 : copy_in[i * NS + s];   // :104
+    }
+  }
+}
+
+// Pass 1 of a BATCH without a second sweep of the gathers.  Pass 0 (k_normalize_mask_lanes) left every
+// (bin, sample)'s sums S1, S2 about c0 and count n over its selected, kept reference bins, and per (bin,
+// 64-sample tile) the WORD of samples it masked (|z| >= 3).  Pass 1's set is pass 0's minus the reference
+// bins masked meanwhile -- 0.3 % of them per sample: one in six (reference bin, tile) words is non-zero --
+// so the sums are UPDATED: a lane (= reference slot) fetches its reference bin's mask word, the wave walks
+// the non-zero ones, and only their samples' values are fetched and subtracted.  8 bytes per reference bin
+// and tile + a sixth of the 512-byte rows instead of all of them.  Writes the masked copy pass 2 reads
+// (cumulative: masked at pass 0 or now).  (The updated sums differ from freshly accumulated ones by
+// rounding, ~1e-16 relative: a |z| within that of 3 could flip a mask bit against the one-sample path --
+// the same caveat as for the lane-per-sample sums themselves)
+__global__ __launch_bounds__(NT) void k_normalize_mask_incr(
+    const double *__restrict__ xT, double *__restrict__ copy_out, const int32_t *__restrict__ idx,
+    const unsigned long long *__restrict__ sel, int64_t B, int k, int ipl, int NS, int64_t lo, int64_t hi,
+    ChrTable chr, const double *__restrict__ st_S1, const double *__restrict__ st_S2,
+    const int *__restrict__ st_n, const unsigned long long *__restrict__ st_mask) {
+  const int lane = wcx::lane_id();
+  const int s = blockIdx.y * 64 + lane;             // my sample (NS is a multiple of 64)
+  const int n_tiles = NS >> 6;
+  const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
+  for (int64_t i = lo + w0; i < hi; i += nw) {
+    int64_t cs = 0, ce = chr.cum[0];
+    for (int c = 1; c < chr.n_chr && i >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+    const int64_t own = ce - cs;
+    const int64_t len_cd = B - own;
+    const double c0 = xT[i * NS + s];
+    double S1 = st_S1[i * NS + s], S2 = st_S2[i * NS + s];
+    int n = st_n[i * NS + s];
+    for (int q = 0; q < ipl; ++q) {
+      const int t = q * 64 + lane;
+      int gv = 0;
+      bool selq = false;
+      if (t < k) {
+        int64_t c = idx[i * (int64_t)k + t];
+        if (c < 0) c += len_cd;
+        gv = (int)(c < cs ? c : c + own);
+        selq = (sel[i * ipl + q] >> lane) & 1ull;
+      }
+      // my reference bin's word of the samples pass 0 masked (0 for nearly all)
+      const unsigned long long mw = selq ? st_mask[(int64_t)gv * n_tiles + blockIdx.y] : 0ull;
+      unsigned long long todo = __ballot(mw != 0ull);
+      // four reference bins at a time: their (sparse) loads in flight together -- one after the other the
+      // walk is a chain of L2 round trips and costs as much as the full sweep it replaces
+      while (todo) {
+        int g[4];
+        bool hit[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool on = todo != 0ull;
+          const int j = on ? __builtin_ctzll(todo) : 0;
+          todo &= todo - 1ull;                        // (0 & -1 = 0: stays empty)
+          g[u] = __builtin_amdgcn_readlane(gv, j);
+          const unsigned long long wj =
+              ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(mw >> 32), j) << 32) |
+              (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)mw, j);
+          hit[u] = on && ((wj >> lane) & 1ull);
+        }
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = hit[u] ? xT[(int64_t)g[u] * NS + s] : c0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double d = v[u] - c0;                 // (masked by pass 0 => it was kept: x >= 0; no hit: 0)
+          S1 = S1 - d;
+          S2 = S2 - d * d;
+          n -= hit[u] ? 1 : 0;
+        }
+      }
+    }
+    const double dn = (double)n;
+    const double mean = c0 + S1 / dn;
+    const double var = (S2 - S1 * (S1 / dn)) / dn;
+    const double sd = sqrt(var > 0.0 ? var : 0.0);
+    const double z = (c0 - mean) / sd;                // predict_tools.py:136
+    const bool was = (st_mask[i * n_tiles + blockIdx.y] >> lane) & 1ull;
+    copy_out[i * NS + s] = (was || fabs(z) >= Z_MASK) ? -1.0 : c0;   // :104 (c0 < 0 stays as it is)
   }
 }
 
@@ -1187,13 +1278,21 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
   const int NS = lanes ? (n_samples + 63) / 64 * 64 : tiled ? (n_samples + TILE - 1) / TILE * TILE : n_samples;
   const size_t cp_b = (size_t)NS * B * 8;
   const size_t lr_b = (size_t)n_samples * Bp * 8;
+  // incremental pass 1 (k_normalize_mask_incr): pass 0's sums / counts / mask words are kept
+  static const int incr_on = [] { const char *e = getenv("WCX_NORM_INCR"); return e && *e ? atoi(e) : 1; }();
+  const bool incr = lanes && incr_on;
+  const size_t st_b = incr ? 2 * cp_b + (size_t)NS * B * 4 + (size_t)B * (NS / 64) * 8 + 256 : 0;
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, (lanes ? 3 : 2) * cp_b + lr_b, &scr);
+  int rc = wcx_scratch(ctx, (lanes ? 3 : 2) * cp_b + lr_b + st_b, &scr);
   if (rc) return rc;
   double *cA = reinterpret_cast<double *>(scr);
   double *cB = cA + (size_t)NS * B;
   double *lr = cB + (size_t)NS * B;
   double *xT = lanes ? lr + (size_t)n_samples * Bp : nullptr;
+  double *stS1 = incr ? xT + (size_t)NS * B : nullptr;
+  double *stS2 = incr ? stS1 + (size_t)NS * B : nullptr;
+  unsigned long long *stM = incr ? reinterpret_cast<unsigned long long *>(stS2 + (size_t)NS * B) : nullptr;
+  int *stN = incr ? reinterpret_cast<int *>(stM + (size_t)B * (NS / 64) + 8) : nullptr;
   rc = wcx_timer_begin(ctx, "normalize");
   if (rc) return rc;
   if (tiled) {
@@ -1216,8 +1315,18 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
       tab.n_chr = (int)ref->chr_cum.size();
       for (int c = 0; c < 32; ++c) tab.cum[c] = c < tab.n_chr ? ref->chr_cum[c] : B;
       const dim3 grid((unsigned)((Bp + 3) / 4 < 16384 ? (Bp + 3) / 4 : 16384), (unsigned)(NS / 64));
-      k_normalize_mask_lanes<<<grid, NT, 0, ctx->stream>>>(xT, cin, cout, ref->d_idx, ref->d_sel, B, ref->k,
-                                                           ipl_for(ref->k), NS, ct, B, tab);
+      if (incr && pass == 0) {
+        // (rows below ct are never normalised here but ARE reference bins of the others: no mask bits)
+        if (ct > 0) WCX_HIP(hipMemsetAsync(stM, 0, (size_t)ct * (NS / 64) * 8, ctx->stream));
+        k_normalize_mask_lanes<<<grid, NT, 0, ctx->stream>>>(xT, cin, cout, ref->d_idx, ref->d_sel, B, ref->k,
+                                                             ipl_for(ref->k), NS, ct, B, tab, stS1, stS2, stN, stM);
+      } else if (incr) {
+        k_normalize_mask_incr<<<grid, NT, 0, ctx->stream>>>(xT, cout, ref->d_idx, ref->d_sel, B, ref->k,
+                                                            ipl_for(ref->k), NS, ct, B, tab, stS1, stS2, stN, stM);
+      } else {
+        k_normalize_mask_lanes<<<grid, NT, 0, ctx->stream>>>(xT, cin, cout, ref->d_idx, ref->d_sel, B, ref->k,
+                                                             ipl_for(ref->k), NS, ct, B, tab);
+      }
       WCX_HIP(hipGetLastError());
     } else if (tiled)
       rc = launch_pass_tile<TILE>(ctx, ref, d_x, cin, cout, n_samples, NS, ct, pass == 2, d_out_z,
