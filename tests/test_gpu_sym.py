@@ -216,3 +216,31 @@ def test_default_sweep_all_rows_of_the_100_sample_cohort(nt):
     oi, od = _oracle(X, cum, k)
     bad = np.flatnonzero((idx != oi).any(axis=1) | (dist != od).any(axis=1))
     assert bad.size == 0, "{} of {} rows differ (first {})".format(bad.size, B, bad[:5])
+
+
+def test_hub_thresholds_and_the_gated_second_attempt(nt, monkeypatch):
+    """The symmetric sweep takes its thresholds from counts over the low-norm rows (k_screen_count); when
+    more rows than the redo path takes end up unfinished -- data whose neighbours are not its low-norm
+    rows -- a device-side gate opens the second attempt (sampled pre-pass + another sweep).  Same bits
+    with the first attempt succeeding, with it failing for every row (forced), and with it switched off;
+    the counters tell which happened."""
+    from wisecondorx_amd.synth import corrected_matrix
+    monkeypatch.setenv("WCX_SCREEN_SAMPLE", "16")
+    X, mbpc, cum = corrected_matrix([7000, 6500, 6000, 5500, 5000, 4500], 250, seed=77)      # 34 500 rows, K = 256
+    k = 100
+    oi, od = _oracle(X, cum, k)
+    idx, dist, st = _run(nt, X, cum, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert st["sym_gates"] > 0 and st["hub_rows_without_estimate"] < 64
+    first_attempt_failed = st["hub_second_attempt_rows"] > 0          # (this data may or may not have hubs)
+    monkeypatch.setenv("WCX_HUB_TEST_FAIL", "1")
+    idx, dist, st = _run(nt, X, cum, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert st["hub_rows_without_estimate"] == cum[-1] and st["hub_second_attempt_rows"] == cum[-1]
+    assert st["fallback_rows"] <= 2
+    monkeypatch.delenv("WCX_HUB_TEST_FAIL")
+    monkeypatch.setenv("WCX_SYM_HUB", "0")
+    idx, dist, st = _run(nt, X, cum, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert st["hub_rows_without_estimate"] == 0 and st["hub_second_attempt_rows"] == 0 and st["sym_gates"] > 0
+    print("first attempt on prototype-structured data:", "failed" if first_attempt_failed else "succeeded")

@@ -237,7 +237,8 @@ class Context:
         out = (C.c_int64 * 16)()
         check(self.lib.wcx_last_topk_stats(self.h, out))
         return {"rows": out[0], "pairs": out[1], "compactions": out[2], "fallback_rows": out[3],
-                "appends": out[4], "refined": out[5], "sym_gates": out[6], "sym_row_appends": out[7], "phase_cycles": [out[8 + i] for i in range(6)]}
+                "appends": out[4], "refined": out[5], "sym_gates": out[6], "sym_row_appends": out[7], "phase_cycles": [out[8 + i] for i in range(6)],
+                "hub_trial_sum": out[12], "hub_rows_without_estimate": out[13], "hub_second_attempt_rows": out[14]}
 
 
 _default_ctx = {}

@@ -1018,14 +1018,17 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   // hub-count estimates (attempt 1): WCX_SYM_HUB=0 turns them off; the region is 1 / WCX_HUB_FRAC of the
   // rows, at least 8 x the entries wanted (+ 512) below an estimate (1.18 k: the k-th neighbour's filter bound
   // ranks ~1.14 k)
-  const int need = (int)(1.18 * k) + 8;
+  // (WCX_HUB_TEST_FAIL=1, tests: a count nobody reaches -- every row ends without an estimate, the verdict
+  //  opens the gate and the second attempt must deliver the same bits)
+  const int need = env_int("WCX_HUB_TEST_FAIL", 0) ? (1 << 28) : (int)(1.18 * k) + 8;
   // (few samples: the distances are noisier and the neighbours less concentrated on the low-norm rows --
   //  two thirds of them in the lowest 1/16 at S = 100 against 98 % at S = 500: a larger region)
   const int hub_frac = env_int("WCX_HUB_FRAC", NK >= 16 ? 32 : 12);
   int64_t hub_rows = hub_frac > 1 ? B / hub_frac : 0;
   // (at least 8 x the entries wanted + the 512 candidates of the moment phase: the loosest trial sits at
   //  4 x need among what is left after the row's own chromosome is taken out)
-  if (hub_rows < 8 * (int64_t)need + 512) hub_rows = 8 * (int64_t)need + 512;
+  const int64_t need_real = (int64_t)(1.18 * k) + 8;
+  if (hub_rows < 8 * need_real + 512) hub_rows = 8 * need_real + 512;
   const bool use_hub = env_int("WCX_SYM_HUB", 1) != 0 && NK >= 5 && hub_frac > 1 && hub_rows * 6 <= B;
   if (sh && !use_hub) {
     wcx_set_error("the row-sharded symmetric sweep needs the hub-count thresholds (K >= 256, B >= %lld)",
