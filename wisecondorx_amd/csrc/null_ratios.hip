@@ -11,7 +11,7 @@
 // (own sample sort, one segment per null sample: k_rank_*), and the medians are selected on the
 // 32-bit RANKS -- exact, because rank order is value order and equal values give equal medians
 // whichever of them is picked:
-//   k_rank_splitters / _bucket / _scan / _scatter / _sort   ranks R and sorted values V
+//   k_rank_splitters / _bucket / _scan / _scatter / _sort / _pieces   ranks (pieces Rg) and the values by rank V
 //   k_null_ratios   one wave per (row, 8 samples): the 8 samples' ranks of a bin share one 32-byte
 //                   piece (Rg[group][bin][8]); per sample: min/max, 64 buckets (LDS atomics), scan
 //                   to the bucket holding the median rank, exact ranks inside it; the median value
@@ -43,18 +43,18 @@ __device__ __forceinline__ unsigned long long dkey(double x) {
 //                     every fourth = one of 1023 splitters
 //   k_rank_bucket     every element: its bucket by binary search among the splitters (LDS), counted
 //   k_rank_scan       exclusive scan of the 1024 bucket sizes of every sample
-//   k_rank_scatter    elements -> their bucket's range (device-scope cursor per bucket)
-//   k_rank_sort       one wave per bucket (~178 elements; <= 1024 sorted in registers, anything bigger
-//                     ranked by counting): rank = bucket start + position; writes the rank pieces
-//                     Rg[group][bin][8] and the sorted values V
-// The sort key is the COMPOSITE (order-preserving image of the value, bin): all keys are distinct, so
-// equal values cannot pile into one bucket whatever the data (constant samples, integer counts), and
-// the ranks are those of a stable sort by value.
+//   k_rank_scatter    elements -> their bucket's range (one device-scope reservation per (tile, bucket))
+//   k_rank_sort       one wave per bucket (~178 elements; <= 1024 from LDS, anything bigger from memory):
+//                     rank = bucket start + number of smaller keys in the bucket; writes the rank pieces
+//                     Rg[group][bin][8] and the values by rank V
+// The BUCKET key is the COMPOSITE (order-preserving image of the value, bin): all keys are distinct, so
+// equal values cannot pile into one bucket whatever the data (constant samples, integer counts); inside
+// a bucket equal values share a rank (see rank_bucket_counted).
 constexpr int RK_NS = 4096;        // sampled elements per segment
 constexpr int RK_NB = 1024;        // buckets per segment
-constexpr int RK_WMAX = 1024;      // bucket size a wave sorts in registers (16 per lane)
+constexpr int RK_WMAX = 1024;      // bucket size a wave ranks from its LDS slice (16 keys per lane)
+constexpr int RK_TILE = 4096;      // bins of one sample per workgroup of the bucket / scatter passes
 
-struct RKey { unsigned long long k; unsigned int b; };
 __device__ __forceinline__ bool rk_less(unsigned long long ka, unsigned int ba, unsigned long long kb,
                                         unsigned int bb) {
   return ka < kb || (ka == kb && ba < bb);
@@ -91,7 +91,15 @@ __global__ __launch_bounds__(1024) void k_rank_splitters(const double *__restric
   }
 }
 
-// bucket of an element = number of splitters strictly below it (composite order)
+// inverse of dkey() (-0 comes back as +0, the NaN key as a NaN)
+__device__ __forceinline__ double dkey_inv(unsigned long long key) {
+  const unsigned long long u = (key >> 63) ? (key ^ 0x8000000000000000ull) : ~key;
+  return __longlong_as_double((long long)u);
+}
+
+// bucket of an element = number of splitters strictly below it (composite order).  One workgroup per
+// RK_TILE consecutive bins of one sample: the splitters are read once per 4096 elements and the counts
+// reach the sample's histogram as one atomic per (tile, bucket) -- ~4 elements each.
 __global__ __launch_bounds__(NT) void k_rank_bucket(const double *__restrict__ Xs, int64_t B,
                                                     const int32_t *__restrict__ sids,
                                                     const unsigned long long *__restrict__ spk,
@@ -101,26 +109,32 @@ __global__ __launch_bounds__(NT) void k_rank_bucket(const double *__restrict__ X
   __shared__ unsigned long long sk[RK_NB];
   __shared__ unsigned int sb[RK_NB];
   __shared__ int hist[RK_NB];
-  const int m = blockIdx.y;
+  const int m = blockIdx.x;                            // samples fastest: all of them in flight at any time
   for (int j = threadIdx.x; j < RK_NB; j += NT) {
     sk[j] = j < RK_NB - 1 ? spk[(int64_t)m * RK_NB + j] : ~0ull;
     sb[j] = j < RK_NB - 1 ? spb[(int64_t)m * RK_NB + j] : ~0u;
     hist[j] = 0;
   }
   __syncthreads();
-  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (b < B) {
-    const double x = Xs[(int64_t)sids[m] * B + b];
-    const unsigned long long key = dkey(x);
-    int lo = 0, hi = RK_NB - 1;                       // first splitter that is not below the element
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (rk_less(sk[mid], sb[mid], key, (unsigned int)b)) lo = mid + 1; else hi = mid;
+  const double *x = Xs + (int64_t)sids[m] * B;
+  int nan_here = 0;
+#pragma unroll 4
+  for (int i = 0; i < RK_TILE / NT; ++i) {
+    const int64_t b = (int64_t)blockIdx.y * RK_TILE + i * NT + threadIdx.x;
+    if (b < B) {
+      const double xv = x[b];
+      const unsigned long long key = dkey(xv);
+      int lo = 0, hi = RK_NB - 1;                       // first splitter that is not below the element
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (rk_less(sk[mid], sb[mid], key, (unsigned int)b)) lo = mid + 1; else hi = mid;
+      }
+      bkt[(int64_t)m * B + b] = (unsigned short)lo;
+      atomicAdd(&hist[lo], 1);
+      nan_here += xv != xv ? 1 : 0;
     }
-    bkt[(int64_t)m * B + b] = (unsigned short)lo;
-    atomicAdd(&hist[lo], 1);
-    if (x != x) atomicAdd(&n_nan[m], 1);
   }
+  if (nan_here) atomicAdd(&n_nan[m], nan_here);
   __syncthreads();
   for (int j = threadIdx.x; j < RK_NB; j += NT)
     if (hist[j]) atomicAdd(&cnt[(int64_t)m * RK_NB + j], hist[j]);
@@ -143,113 +157,152 @@ __global__ __launch_bounds__(RK_NB) void k_rank_scan(const int *__restrict__ cnt
   cursor[(int64_t)m * RK_NB + t] = part[t] - c;
 }
 
+// Elements -> their bucket's range.  Per tile: positions inside the tile's share of a bucket from an
+// LDS counter, the share itself reserved by ONE returning device atomic per (tile, bucket).
 __global__ __launch_bounds__(NT) void k_rank_scatter(const double *__restrict__ Xs, int64_t B,
                                                      const int32_t *__restrict__ sids,
                                                      const unsigned short *__restrict__ bkt,
                                                      int *__restrict__ cursor,
                                                      unsigned long long *__restrict__ tk,
                                                      unsigned int *__restrict__ tb) {
-  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
-  const int m = blockIdx.y;
-  if (b >= B) return;
-  const int pos = atomicAdd(&cursor[(int64_t)m * RK_NB + bkt[(int64_t)m * B + b]], 1);
-  tk[(int64_t)m * B + pos] = dkey(Xs[(int64_t)sids[m] * B + b]);
-  tb[(int64_t)m * B + pos] = (unsigned int)b;
-}
-
-// wave bitonic sort of 64 IPL composite keys, element e = r * 64 + lane (see wave_sort.h)
-template <int IPL>
-__device__ __forceinline__ void wave_sort_rkeys(unsigned long long (&kk)[IPL], unsigned int (&bb)[IPL]) {
-  constexpr int N = 64 * IPL;
-  const int lane = wcx::lane_id();
+  __shared__ int hist[RK_NB];
+  const int m = blockIdx.x;
+  for (int j = threadIdx.x; j < RK_NB; j += NT) hist[j] = 0;
+  __syncthreads();
+  const double *x = Xs + (int64_t)sids[m] * B;
+  unsigned short bk[RK_TILE / NT], off[RK_TILE / NT];
 #pragma unroll
-  for (int size = 2; size <= N; size <<= 1) {
+  for (int i = 0; i < RK_TILE / NT; ++i) {
+    const int64_t b = (int64_t)blockIdx.y * RK_TILE + i * NT + threadIdx.x;
+    bk[i] = 0;
+    off[i] = 0;
+    if (b < B) {
+      bk[i] = bkt[(int64_t)m * B + b];
+      off[i] = (unsigned short)atomicAdd(&hist[bk[i]], 1);
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < RK_NB; j += NT) {
+    const int h = hist[j];
+    if (h) hist[j] = atomicAdd(&cursor[(int64_t)m * RK_NB + j], h);
+  }
+  __syncthreads();
 #pragma unroll
-    for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-      if (stride >= 64) {
-        const int rs = stride >> 6;
-#pragma unroll
-        for (int r = 0; r < IPL; ++r) {
-          if ((r & rs) == 0) {
-            const bool asc = (((r * 64) & size) == 0);
-            const unsigned long long a = kk[r], b = kk[r | rs];
-            const unsigned int ia = bb[r], ib = bb[r | rs];
-            if (rk_less(b, ib, a, ia) == asc) { kk[r] = b; kk[r | rs] = a; bb[r] = ib; bb[r | rs] = ia; }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < IPL; ++r) {
-          const bool asc = (((r * 64 + lane) & size) == 0);
-          const bool lower = ((lane & stride) == 0);
-          const unsigned long long pk = __shfl_xor(kk[r], stride, 64);
-          const unsigned int pb = __shfl_xor(bb[r], stride, 64);
-          const bool p_less = rk_less(pk, pb, kk[r], bb[r]);
-          const bool take = (lower == asc) ? p_less : !p_less;
-          if (take) { kk[r] = pk; bb[r] = pb; }
-        }
-      }
+  for (int i = 0; i < RK_TILE / NT; ++i) {
+    const int64_t b = (int64_t)blockIdx.y * RK_TILE + i * NT + threadIdx.x;
+    if (b < B) {
+      const int pos = hist[bk[i]] + off[i];
+      tk[(int64_t)m * B + pos] = dkey(x[b]);
+      tb[(int64_t)m * B + pos] = (unsigned int)b;
     }
   }
 }
 
+// Ranks inside one bucket BY COUNTING: rank = start of the bucket + the number of its keys below the
+// element's (the bucket's keys broadcast from wave-private LDS, two per read; a loop of a few
+// instructions instead of the ~2 500 straight-line ones of a register bitonic sort, which ran out of
+// the instruction cache: 3.4 ms for the 102 400 buckets of 100 samples at 15 kb).  Equal VALUES get
+// equal ranks -- the selection of k_null_ratios handles repeated ranks (an index row may repeat a bin
+// anyway), and V[rank] is that value whichever of them wrote it.  V = the inverse image of the key:
+// the value itself but for -0 -> +0, which the median's "+ 0.0" does to it anyway.
 template <int IPL>
-__device__ __forceinline__ void rank_bucket_sorted(const unsigned long long *__restrict__ tk,
-                                                   const unsigned int *__restrict__ tb, int n, int64_t base,
-                                                   int m, int64_t B, const double *__restrict__ x,
-                                                   unsigned int *__restrict__ Rg, double *__restrict__ V) {
+__device__ __forceinline__ void rank_bucket_counted(const unsigned long long *__restrict__ tk,
+                                                    const unsigned int *__restrict__ tb, int n, int64_t base,
+                                                    int m, int64_t B, unsigned long long *lk,
+                                                    unsigned int *__restrict__ R, double *__restrict__ V) {
   const int lane = wcx::lane_id();
   unsigned long long kk[IPL];
   unsigned int bb[IPL];
+  int rk[IPL];
 #pragma unroll
-  for (int r = 0; r < IPL; ++r) {
-    const int e = r * 64 + lane;
-    kk[r] = e < n ? tk[e] : ~0ull;
-    bb[r] = e < n ? tb[e] : ~0u;                      // (padding sorts behind every real key)
+  for (int q = 0; q < IPL; ++q) {
+    const int e = q * 64 + lane;
+    kk[q] = e < n ? tk[e] : ~0ull;                    // (no key is below the padding)
+    bb[q] = e < n ? tb[e] : 0u;
+    lk[e] = kk[q];
+    rk[q] = 0;
   }
-  wave_sort_rkeys<IPL>(kk, bb);
+  __builtin_amdgcn_wave_barrier();
+  const int n2 = (n + 1) & ~1;
+#pragma unroll 4
+  for (int j = 0; j < n2; j += 2) {
+    const ulonglong2 p = *reinterpret_cast<const ulonglong2 *>(lk + j);
 #pragma unroll
-  for (int r = 0; r < IPL; ++r) {
-    const int e = r * 64 + lane;
+    for (int q = 0; q < IPL; ++q) rk[q] += (p.x < kk[q] ? 1 : 0) + (p.y < kk[q] ? 1 : 0);
+  }
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int e = q * 64 + lane;
     if (e < n) {
-      const int64_t b = bb[r];
-      Rg[((int64_t)(m >> 3) * B + b) * 8 + (m & 7)] = (unsigned int)(base + e);
-      V[(int64_t)m * B + base + e] = x[b];
+      const int64_t r = base + rk[q];
+      R[(int64_t)m * B + bb[q]] = (unsigned int)r;
+      V[(int64_t)m * B + r] = dkey_inv(kk[q]);
     }
   }
+  __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(NT) void k_rank_sort(const double *__restrict__ Xs, int64_t B,
-                                                  const int32_t *__restrict__ sids,
+// Workgroups go to the 8 XCDs round robin by their linear id; every XCD has its own L2.  All work of
+// ONE sample is given to ONE XCD (linear id l: XCD l % 8 takes the samples = l % 8 mod 8, one after the
+// other), so that the scattered 4-byte rank stores of a sample -- 730 KB at 15 kb, every 64-byte line of
+// it hit 16 times in random order -- meet in that one L2 and leave it as full lines.  (Ranks straight
+// into the pieces Rg[group][bin][8] were 18 M partial-line writes to memory: 3.4 ms whatever the
+// arithmetic.)  Only the speed depends on the dispatch order.
+__device__ __forceinline__ bool xcd_sample_slot(int per_sample, int n_ids, int &m, int &slot) {
+  const int l = blockIdx.x, s = l >> 3;
+  m = ((s / per_sample) << 3) + (l & 7);
+  slot = s % per_sample;
+  return m < n_ids;
+}
+
+__global__ __launch_bounds__(NT) void k_rank_sort(int64_t B, int n_ids,
                                                   const int *__restrict__ start, const int *__restrict__ cnt,
                                                   const unsigned long long *__restrict__ tk,
                                                   const unsigned int *__restrict__ tb,
-                                                  unsigned int *__restrict__ Rg, double *__restrict__ V) {
+                                                  unsigned int *__restrict__ R, double *__restrict__ V) {
+  __shared__ __attribute__((aligned(16))) unsigned long long s_keys[NT / 64][RK_WMAX];
   const int lane = wcx::lane_id();
-  const int m = blockIdx.y;
-  const int bk = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  int m, slot;
+  if (!xcd_sample_slot(RK_NB / (NT / 64), n_ids, m, slot)) return;
+  const int wave = threadIdx.x >> 6;
+  const int bk = slot * (NT / 64) + wave;
   const int n = cnt[(int64_t)m * RK_NB + bk];
   if (n == 0) return;
   const int64_t base = start[(int64_t)m * RK_NB + bk];
   const unsigned long long *k0 = tk + (int64_t)m * B + base;
   const unsigned int *b0 = tb + (int64_t)m * B + base;
-  const double *x = Xs + (int64_t)sids[m] * B;
-  if (n <= 64) rank_bucket_sorted<1>(k0, b0, n, base, m, B, x, Rg, V);
-  else if (n <= 128) rank_bucket_sorted<2>(k0, b0, n, base, m, B, x, Rg, V);
-  else if (n <= 256) rank_bucket_sorted<4>(k0, b0, n, base, m, B, x, Rg, V);
-  else if (n <= 512) rank_bucket_sorted<8>(k0, b0, n, base, m, B, x, Rg, V);
-  else if (n <= RK_WMAX) rank_bucket_sorted<16>(k0, b0, n, base, m, B, x, Rg, V);
+  unsigned long long *lk = s_keys[wave];
+  if (n <= 64) rank_bucket_counted<1>(k0, b0, n, base, m, B, lk, R, V);
+  else if (n <= 128) rank_bucket_counted<2>(k0, b0, n, base, m, B, lk, R, V);
+  else if (n <= 192) rank_bucket_counted<3>(k0, b0, n, base, m, B, lk, R, V);
+  else if (n <= 256) rank_bucket_counted<4>(k0, b0, n, base, m, B, lk, R, V);
+  else if (n <= 384) rank_bucket_counted<6>(k0, b0, n, base, m, B, lk, R, V);
+  else if (n <= 512) rank_bucket_counted<8>(k0, b0, n, base, m, B, lk, R, V);
+  else if (n <= RK_WMAX) rank_bucket_counted<16>(k0, b0, n, base, m, B, lk, R, V);
   else {
-    // a bucket the sample did not predict (never seen; P ~ 1e-7 per bucket): rank by counting
+    // a bucket the sample did not predict (never seen; P ~ 1e-7 per bucket): the same count from memory
     for (int e = lane; e < n; e += 64) {
       const unsigned long long ke = k0[e];
-      const unsigned int be = b0[e];
       int r = 0;
-      for (int j = 0; j < n; ++j) r += rk_less(k0[j], b0[j], ke, be) ? 1 : 0;
-      Rg[((int64_t)(m >> 3) * B + be) * 8 + (m & 7)] = (unsigned int)(base + r);
-      V[(int64_t)m * B + base + r] = x[be];
+      for (int j = 0; j < n; ++j) r += k0[j] < ke ? 1 : 0;
+      R[(int64_t)m * B + b0[e]] = (unsigned int)(base + r);
+      V[(int64_t)m * B + base + r] = dkey_inv(ke);
     }
   }
+}
+
+// R[sample][bin] -> the pieces Rg[group][bin][8] the selection gathers (samples beyond n_ids: 0)
+__global__ __launch_bounds__(NT) void k_rank_pieces(const unsigned int *__restrict__ R, int64_t B, int n_ids,
+                                                    unsigned int *__restrict__ Rg) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  const int g = blockIdx.y;
+  if (b >= B) return;
+  unsigned int r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = g * 8 + j < n_ids ? R[(int64_t)(g * 8 + j) * B + b] : 0u;
+  uint4 *dst = reinterpret_cast<uint4 *>(Rg + ((int64_t)g * B + b) * 8);
+  dst[0] = make_uint4(r[0], r[1], r[2], r[3]);
+  dst[1] = make_uint4(r[4], r[5], r[6], r[7]);
 }
 
 __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
@@ -364,14 +417,9 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// inverse of dkey() (for keys of non-NaN values; -0 comes back as +0)
-__device__ __forceinline__ double dkey_inv(unsigned long long key) {
-  const unsigned long long u = (key >> 63) ? (key ^ 0x8000000000000000ull) : ~key;
-  return __longlong_as_double((long long)u);
-}
-
 // ---- FEW target rows: selection on the HIGH HALVES of the values' keys (no ranking at all) -------
-// Ranking every bin of every null sample (two radix sorts over n_ids * B elements: 6.7 ms of device
+// Ranking every bin of every null sample (a sample sort of n_ids * B elements: 1.3 ms alone on the device,
+// 3-4 ms beside the refine it shares the chip with -- when round 2 measured this it was a library sort: 6.7 ms of device
 // work at 15 kb) is worth it when ~all rows are targets and the sort hides beside the refine; for
 // the chrX / chrY rows of a gonosomal pass or a rank's shard of an 8-GPU build it is not.
 // hi32(dkey(x)) is monotone in x (not strictly): the bucket selection on it finds the 32-bit keys a0,
@@ -586,10 +634,10 @@ __global__ __launch_bounds__(NT) void k_null_ratios(
 
 extern "C" {
 
-// Ranking of every null sample (keys, two radix sorts, scatter into rank pieces + sorted values)
+// Ranking of every null sample (k_rank_*: ranks, rank pieces, values by rank)
 // on stream `st` into the buffer at `base` (layout from rank_layout()).
 struct RankLayout {
-  size_t o_sid, o_nan, o_cnt, o_start, o_cursor, o_spk, o_spb, o_bkt, o_tk, o_tb, o_rg, o_v, total;
+  size_t o_sid, o_nan, o_cnt, o_start, o_cursor, o_spk, o_spb, o_bkt, o_tk, o_tb, o_r, o_rg, o_v, total;
   int n_sg;
 };
 
@@ -608,6 +656,7 @@ static int rank_layout(int64_t B, int n_ids, hipStream_t, RankLayout &L) {
   L.o_bkt = carve((size_t)n * 2);
   L.o_tk = carve((size_t)n * 8);
   L.o_tb = carve((size_t)n * 4);
+  L.o_r = carve((size_t)n * 4);
   L.o_rg = carve((size_t)L.n_sg * B * 32);
   L.o_v = carve((size_t)n * 8);
   L.total = off;
@@ -626,17 +675,18 @@ static int rank_run(const double *dXs, int64_t B, int n_ids, const RankLayout &L
   unsigned short *bkt = reinterpret_cast<unsigned short *>(base + L.o_bkt);
   unsigned long long *tk = reinterpret_cast<unsigned long long *>(base + L.o_tk);
   unsigned int *tb = reinterpret_cast<unsigned int *>(base + L.o_tb);
+  unsigned int *R = reinterpret_cast<unsigned int *>(base + L.o_r);
   unsigned int *Rg = reinterpret_cast<unsigned int *>(base + L.o_rg);
   double *V = reinterpret_cast<double *>(base + L.o_v);
   WCX_HIP(hipMemsetAsync(d_nan, 0, (size_t)n_ids * 4, st));
   WCX_HIP(hipMemsetAsync(cnt, 0, (size_t)n_ids * RK_NB * 4, st));
-  if (n_ids & 7) WCX_HIP(hipMemsetAsync(Rg + (int64_t)(L.n_sg - 1) * B * 8, 0, (size_t)B * 32, st));
-  const unsigned gb = (unsigned)((B + NT - 1) / NT);
+  const unsigned gb = (unsigned)((B + RK_TILE - 1) / RK_TILE);
   k_rank_splitters<<<(unsigned)n_ids, 1024, 0, st>>>(dXs, B, d_sids, spk, spb);
-  k_rank_bucket<<<dim3(gb, (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, spk, spb, bkt, cnt, d_nan);
+  k_rank_bucket<<<dim3((unsigned)n_ids, gb), NT, 0, st>>>(dXs, B, d_sids, spk, spb, bkt, cnt, d_nan);
   k_rank_scan<<<(unsigned)n_ids, RK_NB, 0, st>>>(cnt, start, cursor);
-  k_rank_scatter<<<dim3(gb, (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, bkt, cursor, tk, tb);
-  k_rank_sort<<<dim3(RK_NB / (NT / 64), (unsigned)n_ids), NT, 0, st>>>(dXs, B, d_sids, start, cnt, tk, tb, Rg, V);
+  k_rank_scatter<<<dim3((unsigned)n_ids, gb), NT, 0, st>>>(dXs, B, d_sids, bkt, cursor, tk, tb);
+  k_rank_sort<<<(unsigned)(L.n_sg * 8 * (RK_NB / (NT / 64))), NT, 0, st>>>(B, n_ids, start, cnt, tk, tb, R, V);
+  k_rank_pieces<<<dim3((unsigned)((B + NT - 1) / NT), (unsigned)L.n_sg), NT, 0, st>>>(R, B, n_ids, Rg);
   WCX_HIP(hipGetLastError());
   return WCX_OK;
 }
@@ -700,7 +750,8 @@ __global__ __launch_bounds__(256) void k_null_dummy(const double *__restrict__ X
   out[r * n_ids + m] = log2(x[row_begin + r] / x[0]);
 }
 
-// Ranking costs ~0.37 ns per (null sample, bin) whatever the number of target rows -- mostly hidden
+// Ranking cost ~0.37 ns per (null sample, bin) when this was measured (round 3; 0.07 ns alone on the
+// device since round 5) whatever the number of target rows -- mostly hidden
 // beside the refine on the auxiliary stream when the refine is long; the high-key selection costs
 // 54 ns per (row, 100 samples) against the rank kernel's 35 ns and needs no ranking.  Measured at
 // 15 kb (scripts/sweep_shard_nr.sh, bench.py): the chrX / chrY rows of a gonosomal pass (B / rows =
@@ -826,12 +877,12 @@ int wcx_null_ratios_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const int *d_nan = reinterpret_cast<const int *>(base + L.o_nan);
   const unsigned int *Rg = reinterpret_cast<const unsigned int *>(base + L.o_rg);
   const double *V = reinterpret_cast<const double *>(base + L.o_v);
+  const int ipl = (k + 63) / 64;
   const int n_sg = L.n_sg;
   const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)n_sg);
 #define WCX_NR_LAUNCH(IPL)                                                                      \
   k_null_ratios<IPL><<<grid, NT, 0, st>>>(Rg, V, d_nan, dXs, d_sids, B, d_idx, row_begin, n_rows, \
                                           k, n_ids, d_out, ctx->debug_flags)
-  const int ipl = (k + 63) / 64;
   if (ipl <= 1) WCX_NR_LAUNCH(1);
   else if (ipl <= 2) WCX_NR_LAUNCH(2);
   else if (ipl <= 3) WCX_NR_LAUNCH(3);
