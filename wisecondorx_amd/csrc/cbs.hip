@@ -30,10 +30,25 @@ __global__ __launch_bounds__(128) void k_segz_partial(const double *__restrict__
   if (j >= m) return;
   double num = 0.0, den = 0.0;
   int any = 0;
-  for (int64_t b = cb0[c]; b < cb1[c]; ++b) {
-    if (r[b] == 0.0) continue;                      // overall_tools.py:98-100
-    const double v = nr[(b % nb) * m + j];
-    if (fabs(v) < HUGE_VAL) { num += v * w[b]; den += w[b]; any = 1; }   // :101-110
+  const int64_t b0 = cb0[c], b1 = cb1[c];
+  int64_t row = b0 % nb;                            // (kept incrementally: no 64-bit modulo per bin)
+  for (int64_t b = b0; b < b1; b += 4) {
+    // four bins' loads in flight; the sums still run in bin order
+    double v[4], wb[4];
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      on[u] = b + u < b1 && r[b + u] != 0.0;        // overall_tools.py:98-100
+      int64_t rw = row + u;
+      if (rw >= nb) rw %= nb;
+      v[u] = on[u] ? nr[rw * m + j] : 0.0;
+      wb[u] = on[u] ? w[b + u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (on[u] && fabs(v[u]) < HUGE_VAL) { num += v[u] * wb[u]; den += wb[u]; any = 1; }   // :101-110
+    row += 4;
+    if (row >= nb) row %= nb;
   }
   pnum[(int64_t)c * m + j] = num;
   pden[(int64_t)c * m + j] = den;
