@@ -237,6 +237,7 @@ int wcx_ctx_destroy(wcx_ctx *ctx) {
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_small) hipFree(ctx->d_small);
   if (ctx->d_nullm) hipFree(ctx->d_nullm);
+  if (ctx->d_nullsrc) hipFree(ctx->d_nullsrc);
   if (ctx->d_pca) hipFree(ctx->d_pca);
   if (ctx->sweep_stream) {
     hipStreamSynchronize(ctx->sweep_stream);

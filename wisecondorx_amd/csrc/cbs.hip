@@ -3,6 +3,7 @@
 // (The segmentation itself -- row a16 -- lives in cbs_seg.hip.)
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "wave_sort.h"
 #include "wcx_common.h"
@@ -139,11 +140,25 @@ int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
   WCX_ARG(ctx && d_nr && mask, "NULL argument");
   WCX_ARG(B > 0 && n_bins >= B && m > 0 && m <= 128, "bad sizes (m <= 128)");
   WCX_HIP(hipSetDevice(ctx->device));
-  std::vector<int32_t> src((size_t)n_bins, -1);
-  int64_t j = 0;
-  for (int64_t i = 0; i < n_bins; ++i)
-    if (mask[i]) src[(size_t)i] = (int32_t)j++;
-  WCX_ARG(j == B, "mask does not select B bins");
+  // the bin -> row map depends on the mask only: built and uploaded once per mask (a predict batch,
+  // or the bench's step, attaches a table per call), so that the call is one kernel and no host wait
+  unsigned long long h = 1469598103934665603ull ^ (unsigned long long)n_bins;
+  int64_t sel = 0;
+  for (int64_t i = 0; i < n_bins;) {
+    if (i + 8 <= n_bins) {                      // eight bytes per step (the per-byte chain costs 0.3 ms at 15 kb)
+      unsigned long long wd;
+      memcpy(&wd, mask + i, 8);
+      h = (h ^ wd) * 1099511628211ull;
+      if ((wd & ~0x0101010101010101ull) == 0) sel += __builtin_popcountll(wd);
+      else for (int u = 0; u < 8; ++u) sel += mask[i + u] != 0;
+      i += 8;
+    } else {
+      h = (h ^ mask[i]) * 1099511628211ull;
+      sel += mask[i] != 0;
+      ++i;
+    }
+  }
+  WCX_ARG(sel == B, "mask does not select B bins");
   const size_t bytes = (size_t)n_bins * m * 8;
   if (!(ctx->d_nullm && ctx->nullm_bins == n_bins && ctx->nullm_m == m)) {
     WCX_HIP(hipStreamSynchronize(ctx->stream));
@@ -154,14 +169,28 @@ int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
       return WCX_ERR_NOMEM;
     }
   }
-  void *scr = nullptr;
-  int rc = wcx_scratch2(ctx, (size_t)n_bins * 4 + 256, &scr);
-  if (rc) return rc;
-  WCX_HIP(hipMemcpyAsync(scr, src.data(), (size_t)n_bins * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!(ctx->d_nullsrc && ctx->nullsrc_bins == n_bins && ctx->nullsrc_hash == h)) {
+    std::vector<int32_t> src((size_t)n_bins, -1);
+    int64_t j = 0;
+    for (int64_t i = 0; i < n_bins; ++i)
+      if (mask[i]) src[(size_t)i] = (int32_t)j++;
+    WCX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->nullsrc_bins != n_bins) {
+      if (ctx->d_nullsrc) { WCX_HIP(hipFree(ctx->d_nullsrc)); ctx->d_nullsrc = nullptr; }
+      ctx->nullsrc_bins = 0;
+      if (hipMalloc(reinterpret_cast<void **>(&ctx->d_nullsrc), (size_t)n_bins * 4) != hipSuccess) {
+        wcx_set_error("hipMalloc(%zu) for the null-ratio row map failed", (size_t)n_bins * 4);
+        return WCX_ERR_NOMEM;
+      }
+    }
+    WCX_HIP(hipMemcpyAsync(ctx->d_nullsrc, src.data(), (size_t)n_bins * 4, hipMemcpyHostToDevice, ctx->stream));
+    WCX_HIP(hipStreamSynchronize(ctx->stream));   // (src is a host temporary)
+    ctx->nullsrc_bins = n_bins;
+    ctx->nullsrc_hash = h;
+  }
   k_inflate_rows<<<(unsigned)(n_bins < 65536 ? n_bins : 65536), 128, 0, ctx->stream>>>(
-      d_nr, reinterpret_cast<const int32_t *>(scr), n_bins, m, ctx->d_nullm);
+      d_nr, ctx->d_nullsrc, n_bins, m, ctx->d_nullm);
   WCX_HIP(hipGetLastError());
-  WCX_HIP(hipStreamSynchronize(ctx->stream));   // (src is a host temporary)
   ctx->nullm_bins = n_bins;
   ctx->nullm_m = m;
   return WCX_OK;

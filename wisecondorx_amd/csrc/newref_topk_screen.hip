@@ -1495,7 +1495,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const int TGT_WG = 32 * cfg.tt * cfg.wpb;
   const int GRr = CTG * 32;
   // Sampled pre-pass: the rows b = 0 (mod SF) are swept first (own region of the sweep order).
-  int SF = (B >= 32768) ? 16 : 0;
+  // (small problems with few samples -- the reference's default 100 kb bins: 27 k rows -- are bound by
+  //  their appends like every K < 256 sweep; without estimates the lists fill to the cut trigger first:
+  //  100 kb x 100 samples, sampling 0 / 4 / 8 / 16: appends per row 1 540 / 1 230 / 1 080 / 1 075, sweep
+  //  1.61 / 1.49 / 1.44 / 1.56 ms.  K >= 256 below 32 768 rows stays without: the symmetric path it would
+  //  open is sized and tested for the larger problems.)
+  int SF = (B >= 32768) ? 16 : ((B >= 8192 && NK < 16) ? 8 : 0);
   SF = env_int("WCX_SCREEN_SAMPLE", SF);
   if (SF < 2 || SF > 64) SF = 0;
   const int64_t n_s = SF ? (B + SF - 1) / SF : 0;             // rows in the sample

@@ -62,6 +62,9 @@ struct wcx_ctx {
   double *d_nullm = nullptr;
   int64_t nullm_bins = 0;
   int nullm_m = 0;
+  int32_t *d_nullsrc = nullptr;     // bin -> row of the masked table (-1: masked out), kept per mask
+  int64_t nullsrc_bins = 0;
+  unsigned long long nullsrc_hash = 0;
   // null-sample ranking done ahead on an auxiliary stream (wcx_null_rank_prepare_dev)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_main = nullptr, ev_rank = nullptr;
