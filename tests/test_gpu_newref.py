@@ -268,6 +268,37 @@ def test_null_ratios_nan_duplicates_and_ties(nt):
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13, equal_nan=True)
 
 
+@pytest.mark.parametrize("B,S,k,n_ids,kind", [
+    (70, 5, 7, 5, "real"),            # fewer bins than sampled splitters, one sample group
+    (4097, 17, 65, 16, "counts"),     # one bin past a bucket / scatter tile; integer data = heavy ties
+    (5000, 9, 64, 9, "constant"),     # a constant null sample: every key equal but for the bin
+    (12000, 130, 90, 128, "counts"),  # the most null samples the API takes (16 groups of 8)
+    (9000, 12, 300, 11, "nan"),       # NaNs rank last; a group that is not full
+])
+def test_null_sample_ranking_shapes(nt, B, S, k, n_ids, kind):
+    """The ranking of the null samples (k_rank_*: sample sort, buckets ranked by counting, equal values
+    sharing a rank, one sample per XCD) on shapes around its tile and group sizes, all rows as targets so
+    that the rank path runs (not the few-rows selection on key halves)."""
+    rng = np.random.default_rng(B + n_ids)
+    if kind == "counts":
+        X = rng.poisson(6.0, (B, S)).astype(np.float64) / 4.0 + 0.25
+    else:
+        X = 1.0 + 0.1 * rng.standard_normal((B, S))
+    if kind == "constant":
+        X[:, 3] = 0.75
+    if kind == "nan":
+        X[rng.integers(0, B, 40), 2] = np.nan
+        X[:, 7] = np.nan
+    X = np.asfortranarray(X)
+    idx = rng.integers(0, B, (B, k)).astype(np.int32)
+    idx[1, :] = idx[1, 0]                                   # one bin repeated k times
+    ids = [int(i) for i in rng.permutation(S)[:n_ids]]
+    got = nt.get_null_ratios(X, idx, 0, B, ids)
+    with np.errstate(all="ignore"):
+        want = O.null_ratios(X, idx, 0, B, ids)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13, equal_nan=True)
+
+
 def test_null_ratios_direct_kernel_equals_rank_path(nt):
     """Both selection paths on a realistic shape (k = 300, 100 null samples): the rows of a small
     shard (high-key kernel: bucket selection on hi32 of the values' keys, ties settled on the doubles)
