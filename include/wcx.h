@@ -365,7 +365,9 @@ int wcx_cbs_getbdry(double eta, int nperm, int max_ones, int32_t *out);
 int wcx_set_null_matrix(wcx_ctx *ctx, const double *nr, int64_t n_bins, int m);
 /* The same from a DEVICE table of the masked bins' rows (d_nr double[B][m], e.g. straight out of
  * wcx_null_ratios_dev): inflated to n_bins rows on the device with the reference's mask
- * (mask[n_bins] host bytes, B of them non-zero; masked-out rows = 0, predict_tools.py:163-170). */
+ * (mask[n_bins] host bytes, B of them non-zero; masked-out rows = 0, predict_tools.py:163-170).
+ * Asynchronous on the context's stream: the bin -> row map is kept per mask, so only the first
+ * call with a mask uploads anything and waits; `mask` is read before the call returns. */
 int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
                             const unsigned char *mask, int64_t n_bins);
 int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,
