@@ -39,6 +39,7 @@
 
 #include "screen_kernel.h"
 #include "screen_common.h"
+#include "screen_hub1.h"
 
 namespace {
 
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict_
                                                  int fair_sample,
                                                  const ScreenGlobals *__restrict__ glob,
                                                  int *__restrict__ rkey, int *__restrict__ cellcnt,
-                                                 const unsigned int *__restrict__ gate = nullptr) {
+                                                 const unsigned int *__restrict__ gate = nullptr,
+                                                 const unsigned int *__restrict__ rfine = nullptr) {
   __shared__ int lh[2 * NCELL];
   if (gate && !*gate) return;
   for (int i = threadIdx.x; i < 2 * NCELL; i += NT) lh[i] = 0;
@@ -210,7 +212,9 @@ __global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict_
     const unsigned int u = rbits[b];
     unsigned int bucket = NBUCKET - 1;
     if (u != 0xffffffffu && u >= umin && u - umin < NBUCKET - 1) bucket = u - umin;
-    const bool sample = SF > 0 && (b % SF) == 0;
+    // (rfine: the head region is the HUB region -- the rows at or below the norm quantile -- instead of a
+    //  sample: screen_hub1.h)
+    const bool sample = rfine ? rfine[b] <= glob->hub_key : (SF > 0 && (b % SF) == 0);
     // sample rows of a SEGMENTED sweep: by chromosome only (bucket 0), i.e. in random order with
     // respect to the norm, so that the split of the sample's groups over the candidate segments
     // gives every segment a fair subsample (best-first order would hand the few groups that hold
@@ -227,9 +231,12 @@ __global__ __launch_bounds__(NT) void k_row_hist(const unsigned int *__restrict_
 
 // Exclusive scan of the cell counts -> first sweep position of every cell; the main region starts
 // `pad` positions later so that the sample region ends on a group boundary.
+// hub_glob != nullptr: the head region's size is only known here (the hub rows): pad is computed from it
+// and the region's length in 32-row tiles goes to hub_glob->n_hub_tiles.
 __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cellcnt,
                                                      int *__restrict__ cursor, int pad,
-                                                     const unsigned int *__restrict__ gate = nullptr) {
+                                                     const unsigned int *__restrict__ gate = nullptr,
+                                                     ScreenGlobals *__restrict__ hub_glob = nullptr) {
   __shared__ int part[1024];
   if (gate && !*gate) return;
   const int t = threadIdx.x;
@@ -244,6 +251,11 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int *__restrict__ cel
     __syncthreads();
     part[t] += v;
     __syncthreads();
+  }
+  if (hub_glob) {
+    const int total0 = part[NCELL / PER - 1];            // rows of the head region
+    pad = (CT - total0 % CT) % CT;
+    if (t == 0) hub_glob->n_hub_tiles = (unsigned int)((total0 + pad) >> 5);
   }
   const int base = part[t] - s + (t * PER >= NCELL ? pad : 0);
 #pragma unroll
@@ -1503,9 +1515,9 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   int SF = (B >= 32768) ? 16 : ((B >= 8192 && NK < 16) ? 8 : 0);
   SF = env_int("WCX_SCREEN_SAMPLE", SF);
   if (SF < 2 || SF > 64) SF = 0;
-  const int64_t n_s = SF ? (B + SF - 1) / SF : 0;             // rows in the sample
-  const int64_t P_s = (n_s + CT - 1) / CT * CT;               // positions of the sample region
-  const int64_t Bpad = P_s + ((B - n_s) + CT - 1) / CT * CT;
+  int64_t n_s = SF ? (B + SF - 1) / SF : 0;                   // rows in the sample
+  int64_t P_s = (n_s + CT - 1) / CT * CT;                     // positions of the sample region
+  int64_t Bpad = P_s + ((B - n_s) + CT - 1) / CT * CT;
   // regroup the searched row ranges into workgroups of <= TGT_WG rows (same chromosome)
   std::vector<ScreenBlock> blocks;
   {
@@ -1529,7 +1541,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       i = j;
     }
   }
-  const int64_t n_iter_groups = Bpad / GRr;
+  int64_t n_iter_groups = Bpad / GRr;
   // Candidate segments fill the chip when a row shard has few target blocks (multi-GPU builds)
   // and even out the last round of workgroups: work items = blocks x segments.
   int hw_cus = 256;
@@ -1581,7 +1593,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     if (forced > 0 && forced < k) r = forced;
     return r;
   };
-  const int cut_r = sample_rank(n_seg);
+  int cut_r = sample_rank(n_seg);
   // All rows searched against all rows with a sampled pre-pass available: the symmetric sweep
   // (half the matrix work; screen_sym.h).  WCX_SCREEN_SYM=0 keeps the one-directional sweep.
   {
@@ -1602,6 +1614,27 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // refsize of a row shard / gonosomal pass goes to the exact kernel
   if (k > KMAX_ONE_DIR)
     return wcx_topk_exact_launch(ctx, dXs, B, S, exact_blocks, row_begin, n_rows, k, d_out_idx, d_out_dist);
+  // Thresholds from COUNTS over the low-norm rows instead of the sampled pre-pass (screen_hub1.h; round 6:
+  // what round 5 gave the symmetric sweep, for row shards, gonosomal passes and K < 256).  The head region
+  // of the sweep order is then the hub region -- 1 / WCX_HUB_FRAC of the rows, at least 8 x the entries
+  // wanted below an estimate + the 512 candidates of the moment phase -- whose size only the device knows:
+  // the host sizes everything for the bound (one more group of padding at most).  WCX_SCREEN_HUB=0: off.
+  const int need1 = (int)(1.18 * k) + 8;
+  const int hub_frac1 = env_int("WCX_HUB_FRAC", NK >= 16 ? 32 : 12);
+  int64_t hub_rows1 = hub_frac1 > 1 ? B / hub_frac1 : 0;
+  if (hub_rows1 < 8 * (int64_t)need1 + 512) hub_rows1 = 8 * (int64_t)need1 + 512;
+  // (an explicit sampling rate / sample rank asks for the sampled pre-pass: tests of that path)
+  const int hub1_dflt = (getenv("WCX_SCREEN_SAMPLE") || getenv("WCX_SCREEN_CUT_R")) ? 0 : 1;
+  const bool use_hub1 = env_int("WCX_SCREEN_HUB", hub1_dflt) != 0 && NK >= 5 && hub_frac1 > 1 && hub_rows1 * 6 <= B &&
+                        cfg.tt == 1 && cfg.wpb == 4 && cfg.ring >= 2 && !cfg.prof;
+  if (use_hub1) {
+    SF = 0;
+    n_s = 0;
+    P_s = 0;
+    Bpad = (B + CT - 1) / CT * CT + CT;
+    n_iter_groups = Bpad / GRr;
+    cut_r = 0;
+  }
   // scratch layout
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
@@ -1615,6 +1648,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_perm = carve((size_t)Bpad * 4);
   const size_t o_rpos = carve((size_t)B * 4);
   const size_t o_rbit = carve((size_t)B * 4);
+  const size_t o_rfin = carve(use_hub1 ? (size_t)B * 4 : 0);
+  const size_t o_hubh = carve(use_hub1 ? (size_t)HUB_BINS * 4 : 0);
   const size_t o_rchr = carve((size_t)B * 4);
   const size_t o_rkey = carve((size_t)B * 4);
   const size_t o_cell = carve((size_t)2 * NCELL * 4);
@@ -1690,9 +1725,19 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     const unsigned gb = (unsigned)((B + NT - 1) / NT);
     WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
     WCX_HIP(hipMemsetAsync(perm, 0xff, (size_t)Bpad * 4, st));
-    k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
-    k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, SF, n_seg > 1 ? 1 : 0, glob, rkey, cellcnt);
-    k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, (int)(P_s - n_s));
+    if (use_hub1) {
+      unsigned int *rfine = reinterpret_cast<unsigned int *>(base + o_rfin);
+      int *hubhist = reinterpret_cast<int *>(base + o_hubh);
+      WCX_HIP(hipMemsetAsync(hubhist, 0, (size_t)HUB_BINS * 4, st));
+      k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr, rfine, hubhist);
+      k_hub_cut<<<1, 1024, 0, st>>>(hubhist, (int)hub_rows1, glob);
+      k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, 0, 0, glob, rkey, cellcnt, nullptr, rfine);
+      k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, 0, nullptr, glob);
+    } else {
+      k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
+      k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, SF, n_seg > 1 ? 1 : 0, glob, rkey, cellcnt);
+      k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, (int)(P_s - n_s));
+    }
     k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
     k_group_mask<<<(unsigned)((n_groups + NT - 1) / NT), NT, 0, st>>>(perm, rchr, n_groups, gmask);
   }
@@ -1752,6 +1797,38 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // in two halves that sweep the same chunks on two streams: when one half's launch drains, the
   // other half's workgroups fill the freed slots -- the per-launch tails overlap instead of adding
   // up.  (Blocks are independent: all per-target state is addressed through ScreenBlock::row0.)
+  if (use_hub1) {
+    rc = wcx_timer_begin(ctx, "topk_pre");
+    if (rc) return rc;
+    Hub1Args ha;
+    ha.F = F; ha.glob = glob; ha.perm = perm; ha.rowpos = rowpos; ha.gmask = gmask; ha.blocks = d_blocks;
+    ha.g_state = g_state; ha.cnt = cnt_out; ha.stats = ctx->d_stats; ha.row_begin = row_begin;
+    ha.n_rows_all = n_rows; ha.n_seg = n_seg; ha.need = env_int("WCX_HUB_TEST_FAIL", 0) ? (1 << 28) : need1;
+    ha.n1 = env_int("WCX_HUB_N1", 16);
+    // the visit list holds the hub groups: room for twice the rows asked for (the quantile takes a whole
+    // histogram bin); a bigger region is cut off there by the kernel
+    int64_t cap_g = (hub_rows1 * 2 + GRr - 1) / GRr + 2;
+    if (cap_g > n_iter_groups) cap_g = n_iter_groups;
+    if (cap_g > 8192) cap_g = 8192;
+    ha.glist_cap = (int)cap_g + 64;
+    const size_t lds_h = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)ha.glist_cap * 4;
+    const int trials = env_int("WCX_HUB1_TRIALS", NK >= 16 ? 8 : 4);
+    int e = wcx_hub1_launch_k1(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
+    if (e < 0) e = wcx_hub1_launch_k2(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
+    if (e < 0) e = wcx_hub1_launch_k3(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
+    if (e < 0) e = wcx_hub1_launch_k4(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
+    if (e < 0) {
+      wcx_set_error("hub-count kernel (one-directional) nk=%d ctg=%d lb=%d ring=%d trials=%d is not instantiated",
+                    NK, CTG, cfg.lb, cfg.ring, trials);
+      return (int)WCX_ERR_UNSUPPORTED;
+    }
+    if (e != 0) {
+      wcx_set_error("hub-count kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+      return (int)WCX_ERR_HIP;
+    }
+    rc = wcx_timer_end(ctx, "topk_pre");
+    if (rc) return rc;
+  }
   int n_streams = ((int)blocks.size() > slots && n_seg == 1) ? 2 : 1;
   n_streams = env_int("WCX_SCREEN_STREAMS", n_streams);
   if (n_streams != 2 || n_seg != 1 || blocks.size() < 2) n_streams = 1;
@@ -1767,7 +1844,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     WCX_HIP(hipStreamWaitEvent(st2, ctx->ev_sweep0, 0));
   }
   const int half0 = n_streams == 2 ? (int)(blocks.size() + 1) / 2 : (int)blocks.size();
-  bool first = true;
+  bool first = !use_hub1;          // (hub counts: the per-row state -- threshold, estimate bit -- is there already)
   auto launch = [&](int64_t g0, int64_t g1, int cut_k, int cut_mode, int trig, int end_cut) {
     a.g_start = g0; a.g_count = (int)(g1 - g0);
     a.cut_k = cut_k; a.cut_mode = cut_mode; a.trig = trig; a.end_cut = end_cut;

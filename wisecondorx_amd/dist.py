@@ -17,6 +17,63 @@ import numpy as np
 from .newref_tools import _get_part
 
 
+def force_collectives():
+    """WCX_FORCE_COLLECTIVES=1: the world == 1 short-circuits below are off -- a one-rank process group
+    runs every collective of the multi-GPU path (all-gather of X and of the row blocks, the all-to-all
+    of the hit records, the all-reduces of the sharded cut-off) through its real backend.  This is how
+    RCCL is exercised on a one-GPU box (tests/test_gpu_rccl.py, bench.py's `rccl_world1`)."""
+    import os
+    if os.environ.get("WCX_FORCE_COLLECTIVES", "0") != "1":
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+COLLECTIVE_LOG = None      # a list: every collective of this module appends (op, bytes, backend, events)
+
+
+def _logged(op, nbytes, cuda, fn, group=None):
+    """Runs the collective `fn`; with COLLECTIVE_LOG set, its name, payload and -- on device tensors --
+    a pair of events on the current stream around it (the process-group stream is joined to it by
+    torch on both sides of a blocking collective) are recorded for collective_report()."""
+    if COLLECTIVE_LOG is None:
+        return fn()
+    import torch
+    import torch.distributed as dist
+    ev = None
+    if cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    import time
+    t0 = time.perf_counter()
+    out = fn()
+    if ev:
+        ev[1].record()
+    COLLECTIVE_LOG.append({"op": op, "bytes": int(nbytes), "backend": dist.get_backend(group), "ev": ev,
+                           "host_ms": 1e3 * (time.perf_counter() - t0)})
+    return out
+
+
+def collective_report():
+    """COLLECTIVE_LOG with the event pairs resolved to milliseconds (synchronises); the log is emptied."""
+    global COLLECTIVE_LOG
+    out = []
+    for e in COLLECTIVE_LOG or []:
+        e = dict(e)
+        ev = e.pop("ev")
+        if ev:
+            ev[1].synchronize()
+            e["ms"] = ev[0].elapsed_time(ev[1])
+        out.append(e)
+    if COLLECTIVE_LOG is not None:
+        COLLECTIVE_LOG = []
+    return out
+
+
+def _single(world):
+    return world == 1 and not force_collectives()
+
+
 def row_shard(rank, world, n_rows):
     """[begin, end) rows of `rank` -- the reference's part boundaries."""
     return _get_part(rank, world, n_rows)
@@ -36,11 +93,14 @@ def gather_padded(local_rows, world, group=None):
     if dist.get_backend(group) == "gloo" and local_rows.is_cuda:
         # testing only (two ranks sharing one device): gloo gathers through host memory
         host = torch.empty((world * pad,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype)
-        dist.all_gather_into_tensor(host, local_rows.cpu(), group=group)
+        src = local_rows.cpu()
+        _logged("all_gather_into_tensor", host.numel() * host.element_size(), False,
+                lambda: dist.all_gather_into_tensor(host, src, group=group), group)
         return host.to(local_rows.device)
     gathered = torch.empty((world * pad,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype,
                            device=local_rows.device)
-    dist.all_gather_into_tensor(gathered, local_rows, group=group)
+    _logged("all_gather_into_tensor", gathered.numel() * gathered.element_size(), gathered.is_cuda,
+            lambda: dist.all_gather_into_tensor(gathered, local_rows, group=group), group)
     return gathered
 
 
@@ -50,7 +110,7 @@ def allgather_rows(local_rows, n_rows, world, group=None, backend=None):
     backend the padding is squeezed out by one device kernel (wcx_compact_rows_dev); the generic
     path (CPU tests) concatenates the shards."""
     import torch
-    if world == 1:
+    if _single(world):
         return local_rows[:n_rows]
     pad = local_rows.shape[0]
     gathered = gather_padded(local_rows, world, group)
@@ -219,20 +279,24 @@ def exchange_records(send, counts, world, group=None):
     cnt_out = torch.empty(world, dtype=torch.int64)
     host = dist.get_backend(group) == "gloo"
     if host:
-        dist.all_to_all_single(cnt_out, cnt_in, group=group)
+        _logged("all_to_all_single", 8 * world, False, lambda: dist.all_to_all_single(cnt_out, cnt_in, group=group),
+                group)
     else:
         ci, co = cnt_in.to(send.device), cnt_out.to(send.device)
-        dist.all_to_all_single(co, ci, group=group)
+        _logged("all_to_all_single", 8 * world, True, lambda: dist.all_to_all_single(co, ci, group=group), group)
         cnt_out = co.cpu()
     n_recv = int(cnt_out.sum())
+    split_out, split_in = [int(c) for c in cnt_out], [int(c) for c in cnt_in]
     if host and send.is_cuda:
         # testing only (ranks sharing one device): gloo exchanges through host memory
         recv_h = torch.empty((n_recv, 4), dtype=send.dtype)
-        dist.all_to_all_single(recv_h, send.cpu(), [int(c) for c in cnt_out], [int(c) for c in cnt_in],
-                               group=group)
+        send_h = send.cpu()
+        _logged("all_to_all_single", 16 * int(send.shape[0]), False,
+                lambda: dist.all_to_all_single(recv_h, send_h, split_out, split_in, group=group), group)
         return recv_h.to(send.device)
     recv = torch.empty((n_recv, 4), dtype=send.dtype, device=send.device)
-    dist.all_to_all_single(recv, send, [int(c) for c in cnt_out], [int(c) for c in cnt_in], group=group)
+    _logged("all_to_all_single", 16 * int(send.shape[0]), send.is_cuda,
+            lambda: dist.all_to_all_single(recv, send, split_out, split_in, group=group), group)
     return recv
 
 
@@ -245,7 +309,7 @@ def newref_sym_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank
     backend has no symmetric sweep for the shape (every rank takes the same branch: it depends on the
     shape alone)."""
     import torch
-    if world > 1 and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
+    if not _single(world) and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
         Xs = backend.gather_transpose(gather_padded(local_rows, world), world, local_rows.shape[0],
                                       n_rows)
     else:
@@ -268,7 +332,7 @@ def newref_sym_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank
     import os
     sym_min = int(os.environ.get("WCX_SYM_SHARD_MIN", "8"))
     counts = backend.sym_sweep(Xs, n_rows, S, chr_cum, k, rank, world, bounds, sample_ids) \
-        if world >= max(2, sym_min) and hasattr(backend, "sym_sweep") else None
+        if world >= max(1 if force_collectives() else 2, sym_min) and hasattr(backend, "sym_sweep") else None
     if counts is None:
         backend.search(Xs, n_rows, S, chr_cum, b, e, k, sample_ids, out[0], out[1], out[2])
         return out[0][:n], out[1][:n], out[2][:n], Xs
@@ -287,7 +351,7 @@ def newref_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, wo
     Returns (idx [n_local,k] int32, dist [n_local,k] f64, nr [n_local,m] f64) for this rank's
     rows, plus the gathered sample-major matrix it was computed from."""
     import torch
-    if world > 1 and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
+    if not _single(world) and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
         # the ONE exchange, then padded shards -> sample-major in one kernel
         Xs = backend.gather_transpose(gather_padded(local_rows, world), world, local_rows.shape[0],
                                       n_rows)
@@ -317,14 +381,14 @@ def newref_gonosomal_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend
     full = (idx [n_rows,k] int32, dist [n_rows,k] f64, nr [n_rows,m] f64) device buffers that
     receive the complete tables of the pass.  Returns them."""
     import torch
-    if world > 1 and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
+    if not _single(world) and hasattr(backend, "gather_transpose") and local_rows.is_cuda:
         Xs = backend.gather_transpose(gather_padded(local_rows, world), world, local_rows.shape[0], n_rows)
     else:
         fullX = allgather_rows(local_rows, n_rows, world).contiguous()
         Xs = backend.transpose(fullX) if hasattr(backend, "transpose") else fullX.t().contiguous()
     S = Xs.shape[0]
     ct = int(chr_cum[21])
-    if world == 1:
+    if _single(world):
         backend.search(Xs, n_rows, S, chr_cum, 0, n_rows, k, sample_ids, full[0], full[1], full[2])
         return full
     n_g = n_rows - ct
@@ -356,7 +420,7 @@ def _padded(t, pad):
 def gather_reference(idx_local, dist_local, n_rows, world, backend=None):
     """All-gather the finished row blocks so every rank (= predict replica) holds the whole
     reference.  Inputs are this rank's [n_local, k] blocks."""
-    if world == 1:
+    if _single(world):
         return idx_local, dist_local
     pad = max_shard_rows(world, n_rows)
     return (allgather_rows(_padded(idx_local, pad), n_rows, world, backend=backend),
@@ -365,7 +429,7 @@ def gather_reference(idx_local, dist_local, n_rows, world, backend=None):
 
 def gather_reference3(idx_local, dist_local, nr_local, n_rows, world, backend=None):
     """gather_reference + the null-ratio rows: the three tables `newref` writes to disk."""
-    if world == 1:
+    if _single(world):
         return idx_local, dist_local, nr_local
     pad = max_shard_rows(world, n_rows)
     return tuple(allgather_rows(_padded(t, pad), n_rows, world, backend=backend)
@@ -554,14 +618,14 @@ def predict_full_dev(backend, A, G, d_xA, d_xG, rem_input, pt, want_host=False):
 
 
 def _allreduce2(a, b, world):
-    if world == 1:
+    if _single(world):
         return a, b
     import torch
     import torch.distributed as dist
     t = torch.tensor([a, b], dtype=torch.float64)
     if dist.get_backend() == "nccl":
         t = t.cuda()
-    dist.all_reduce(t)
+    _logged("all_reduce", 16, t.is_cuda, lambda: dist.all_reduce(t))
     return float(t[0]), float(t[1])
 
 
@@ -593,7 +657,7 @@ def normalize_sharded(backend, ref, x, n_rows, ct, cutoff, rank, world):
     rB, nB, lB = torch.zeros_like(zB), torch.zeros_like(zB), torch.zeros_like(zB)
 
     def exchange(v):
-        if world == 1:
+        if _single(world):
             return v
         loc = torch.zeros(pad, dtype=v.dtype, device=v.device)
         loc[:e - b] = v[b:e]
