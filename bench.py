@@ -304,7 +304,8 @@ class Workload:
                 # (N > 1: the tile pairs of the symmetric sweep dealt out to the ranks + ONE all-to-all of
                 #  the hit records, dist.newref_sym_sharded; WCX_BENCH_SYM_SHARD=0: every rank sweeps its
                 #  target rows against all candidates, the round-1..4 form)
-                shard_fn = wd.newref_sym_sharded if (self.world > 1 and os.environ.get("WCX_BENCH_SYM_SHARD", "1") != "0") \
+                shard_fn = wd.newref_sym_sharded if ((self.world > 1 or wd.force_collectives()) and
+                                                     os.environ.get("WCX_BENCH_SYM_SHARD", "1") != "0") \
                     else wd.newref_sharded
                 idx_l, dist_l, nr_l, _ = shard_fn(P["Xrow"], P["B"], P["cum"], self.k, P["ids"],
                                                   self.backend, self.rank, self.world, out=P["bufs"])
@@ -374,8 +375,9 @@ class Workload:
             flops = 2.0 * S * pairs_A
             achieved = flops / (screen_ms * 1e-3) / 1e12
             sym = stats.get("sym_gates", 0) > 0
-            r = {"kernel": ("k_screen_sym (symmetric sweep: every tile pair once, both directions) + sampled "
-                            "pre-pass k_screen + final cut" if sym else "k_screen") +
+            r = {"kernel": ("k_screen_count (thresholds from counts over the low-norm rows) + k_screen_sym (symmetric "
+                            "sweep: every tile pair once, both directions) + k_sym_regroup + k_sym_final" if sym
+                            else "k_screen_hub1 (thresholds from counts over the low-norm rows) + k_screen") +
                            " of the autosomal pass (v_mfma_f32_32x32x16_f16, fp16 hi plane, fp32 acc) + fused "
                            "top-k filter", "bound": "mfma", "achieved": achieved,
                  "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -389,10 +391,10 @@ class Workload:
                  "refined_pairs": stats["refined"], "sym_gates": stats.get("sym_gates", 0),
                  "sym_row_appends": stats.get("sym_row_appends", 0), "sym_counts": stats["phase_cycles"][:4], "pre_ms": self.mean_ms("A:topk_pre"),
                  "kernel_ms_note": "wall time of one whole sweep of the A pass (HIP events on the launch "
-                                   "stream): symmetric path = pre-pass k_screen + k_sym_setup + ONE persistent "
-                                   "k_screen_sym launch + k_sym_regroup + k_sym_final (rocprofv3: the sum of "
-                                   "those dispatches); one-directional path = chunk launches on two "
-                                   "concurrent streams (average launch duration x launches per sweep / 2)",
+                                   "stream): symmetric path = k_screen_count + ONE persistent k_screen_sym launch "
+                                   "+ k_sym_regroup + k_sym_final (rocprofv3: the sum of those dispatches); "
+                                   "one-directional path = k_screen_hub1 + chunk launches on two concurrent "
+                                   "streams (average launch duration x launches per sweep / 2)",
                  "attainable_note": "the dense-f16 peak is not attainable on random data: a bare "
                                     "LDS-fed MFMA loop with DMA staging and no epilogue is power-limited "
                                     "to 1.1-1.35 PFLOP/s on this chip, box to box (1.9-2.0 on all-zero "
@@ -458,7 +460,7 @@ def hbm_kernels(w, rf):
     return out
 
 
-def config5_block(w, batch=96, runs=3):
+def config5_block(w, batch=96, runs=3, verify=True):
     """BASELINE configs[4]: predict a batch of 96 samples at 15 kb, device-resident end to end
     (dist.predict_batch_dev) against the reference of the last timed step, on this one device (8 GPUs
     stripe the samples, no collective)."""
@@ -495,13 +497,38 @@ def config5_block(w, batch=96, runs=3):
         torch.cuda.synchronize()
         t_all.append(time.perf_counter() - t0)
     ms = {k_: w.ctx.kernel_ms(k_) for k_ in ("aut:normalize", "normalize", "cbs", "segment_z")}
+    checked = None
+    if verify:
+        # one sample of the batch against the pinned NumPy oracle (predict_tools.py:94-142: three dependent
+        # passes over every autosomal bin, ~15 s on one core): n exact, z / r / medians to 1e-9
+        from oracle import wcx_oracle as O
+        i_chk = 41
+        bufs = w.backend._predict_full_bufs
+        gz, gr, gn = (bufs["a"][j][i_chk].cpu().numpy() for j in range(3))
+        gmed = bufs["med"][:2, i_chk].cpu().numpy()
+        idx_h, dist_h = A["idx"].cpu().numpy(), A["dist"].cpu().numpy()
+        mb = [int(v) for v in w.p["masked_bins_per_chr"]]
+        cum = [int(v) for v in w.cum]
+        t0 = time.perf_counter()
+        cutoff = float(O.get_optimal_cutoff(dist_h, int(w.pargs.maskrepeats)))
+        oz, orr, on, omlr, omz = O.normalize_repeat(xA[i_chk].cpu().numpy(), mb, cum, idx_h, dist_h, cutoff, 0, 0)
+        with np.errstate(all="ignore"):
+            ok_n = bool(np.array_equal(gn, on))
+            ok_r = bool(np.allclose(gr, orr, rtol=1e-9, atol=0.0, equal_nan=True))
+            ok_z = bool(np.allclose(gz, oz, rtol=1e-9, atol=1e-9, equal_nan=True))
+            ok_m = bool(np.allclose(gmed, [omlr, omz], rtol=1e-9, atol=1e-12))
+        checked = {"sample": i_chk, "bins": int(len(on)), "n_exact": ok_n, "r_1e-9": ok_r, "z_1e-9": ok_z,
+                   "medians_1e-9": ok_m, "mismatches": int(not (ok_n and ok_r and ok_z and ok_m)),
+                   "oracle_seconds": time.perf_counter() - t0,
+                   "what": "autosomal normalize_repeat outputs of one sample of the batch against "
+                           "oracle.wcx_oracle.normalize_repeat (all bins, three passes)"}
     B, BG, k = int(w.B), int(w.P["F"]["B"] - int(w.P["F"]["cum"][21])), int(w.k)
     nbytes = 3 * (B + BG) * (k * 4 + k // 8) + 3 * batch * (B + BG) * 32
     norm_ms = max(ms["aut:normalize"], 0.0) + max(ms["normalize"], 0.0)
     return {"workload": "BASELINE configs[4]: predict {} samples at {} kb (autosomes + gonosomes, merge, "
                         "CBS, segment z), one device".format(batch, w.args.binsize // 1000),
             "batch_s": min(t_all), "runs_s": t_all, "prep_s": min(t_prep), "samples_per_s": batch / min(t_all),
-            "kernel_ms": ms, "segments": int(sum(len(r_) for r_ in rows)),
+            "kernel_ms": ms, "segments": int(sum(len(r_) for r_ in rows)), "verified": checked,
             "normalize_roofline": {"ms": norm_ms, "algorithmic_bytes": int(nbytes),
                                    "achieved_GBs": nbytes / (norm_ms * 1e-3) / 1e9 if norm_ms > 0 else None,
                                    "frac_of_hbm_peak": nbytes / (norm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if norm_ms > 0 else None,
@@ -582,6 +609,72 @@ def cpu_baseline_predict(w, budget_bins=2048):
             "gpu_ms_per_sample_A_plus_gonosomes": w.mean_ms("normalize")}
 
 
+def summarize_collectives(log):
+    """Per collective op of dist.collective_report(): calls, payload bytes, device ms (events on the
+    current stream around the blocking collective) and host ms."""
+    out = {}
+    for e in log:
+        d = out.setdefault(e["op"], {"calls": 0, "bytes": 0, "ms": 0.0, "host_ms": 0.0, "backend": e["backend"]})
+        d["calls"] += 1
+        d["bytes"] += e["bytes"]
+        d["ms"] += e.get("ms", 0.0)
+        d["host_ms"] += e["host_ms"]
+    return out
+
+
+def rccl_world1_block(w, torch, dev):
+    """The multi-GPU code path on the ONE GPU this run has: a process group of one rank on backend
+    "nccl" (= RCCL), the world == 1 short-circuits of dist.py off (WCX_FORCE_COLLECTIVES=1), one extra
+    untimed step -- A pass through dist.newref_sym_sharded (all-gather of X, all-to-all of the hit
+    records), F / M passes through newref_gonosomal_sharded, gather_reference3 (padded all-gather +
+    compaction) -- and its tables compared bit for bit with those of the last timed step.  Says that the
+    collectives EXECUTE and order correctly against the library's kernels; no scaling is measured."""
+    import socket
+    import torch.distributed as dist
+    wd = w.wd
+    out = {"ok": False, "what": "one untimed step with every collective of dist.py forced through a 1-rank "
+                                "process group on backend nccl (RCCL); tables == the last timed step's, bitwise"}
+    keep = {tag: {k_: v.clone() for k_, v in w.last_ref[tag].items() if k_ != "cum"} for tag in w.last_ref}
+    env_old = {k_: os.environ.get(k_) for k_ in ("WCX_FORCE_COLLECTIVES", "WCX_SYM_SHARD_MIN", "MASTER_ADDR",
+                                                 "MASTER_PORT")}
+    side_, w.side = w.side, {}
+    try:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.environ.update({"WCX_FORCE_COLLECTIVES": "1", "WCX_SYM_SHARD_MIN": "1", "MASTER_ADDR": "127.0.0.1",
+                           "MASTER_PORT": str(port)})
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        try:
+            wd.COLLECTIVE_LOG = []
+            wd.newref_sym_sharded.last_records = None
+            w.step(False)
+            torch.cuda.synchronize()
+            log = wd.collective_report()
+            same = True
+            for tag in keep:
+                for k_, v in keep[tag].items():
+                    g = w.last_ref[tag][k_]
+                    same = same and g.shape == v.shape and bool(
+                        torch.equal(g.contiguous().view(torch.uint8), v.contiguous().view(torch.uint8)))
+            out.update({"ok": bool(same and len(log) > 0), "tables_equal": bool(same),
+                        "records_sent_received": wd.newref_sym_sharded.last_records,
+                        "collectives": summarize_collectives(log)})
+        finally:
+            wd.COLLECTIVE_LOG = None
+            dist.destroy_process_group()
+    except Exception as e:          # (reported, never fatal for the bench line)
+        out["error"] = "{}: {}".format(type(e).__name__, e)
+    finally:
+        w.side = side_
+        for k_, v in env_old.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+    return out
+
+
 def run_steps(w, steps, warmup, spinup, barrier):
     # Untimed spin-up (setup, not one of the contract's warm-up steps; reported in config): the
     # first process on an idle box otherwise measures the clock ramp.  A FIXED number of steps:
@@ -659,6 +752,27 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
 
+    ranks_info = None
+    if world > 1 and not args.replicas and not args.debug_flags:
+        # one extra untimed step with the collectives logged (events around each blocking collective):
+        # per rank its rows, the hit records it sent / received, and what each collective cost
+        from wisecondorx_amd import dist as wd_
+        from wisecondorx_amd.newref_tools import _get_part as gp_
+        wd_.COLLECTIVE_LOG = []
+        wd_.newref_sym_sharded.last_records = None
+        w.step(False)
+        torch.cuda.synchronize()
+        log_ = wd_.collective_report()
+        wd_.COLLECTIVE_LOG = None
+        rb_, re_ = gp_(rank, world, int(w.B))
+        st_ = w.ctx.topk_stats()
+        info_ = {"rank": rank, "rows_A": int(re_ - rb_), "pairs_A": int(st_.get("pairs", 0)),
+                 "records_sent_received": wd_.newref_sym_sharded.last_records,
+                 "collectives": summarize_collectives(log_)}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, info_)
+        barrier()
+
     def sequential_kernel_times(w_):
         """Per-kernel times (roofline, hbm_kernels) come from three EXTRA, untimed steps with the passes
         one after another: in the timed steps the F / M passes overlap the A pass's refine."""
@@ -726,7 +840,11 @@ def main():
                                "bins x S={}) + F pass ({} chrX rows x S={}) + M pass ({} chrX/Y rows x "
                                "S={}), each search + null ratios + gather of the reference; + predict of "
                                "1 sample (cut-off, weights, 3 normalisation passes for autosomes and "
-                               "gonosomes, merge, post-processing, CBS of 23 chromosomes, segment z)".format(
+                               "gonosomes, merge, post-processing, CBS of 23 chromosomes, segment z).  The step "
+                               "starts from the prepared matrices resident in HBM: masks, depth normalisation, "
+                               "PCA correction + distance filter (newref_tools.py:77-147, newref_control.py:38-58) "
+                               "and all file I/O are OUTSIDE it -- their device time is `prep_pipeline`, the "
+                               "whole CLI `e2e_cli`".format(
                                    args.binsize // 1000, w.S, w.k,
                                    w.B, w.S, w.P["F"]["B"] - int(w.P["F"]["cum"][21]), w.P["F"]["S"],
                                    w.P["M"]["B"] - int(w.P["M"]["cum"][21]), w.P["M"]["S"]),
@@ -758,13 +876,20 @@ def main():
                             "roofline": {k_: r2[k_] for k_ in r2
                                          if k_ not in ("kernel", "attainable_note",
                                                        "fallback_rows_per_step")}}
+        if not args.no_verify:
+            out["secondary"]["verified"] = verify_rows(w2, n_blocks=40, rows_per_block=16, gon_blocks=8)
+    if ranks_info is not None:
+        out["ranks"] = ranks_info
     if rank == 0 and world == 1 and not args.debug_flags:
         out["hbm_kernels"] = hbm_kernels(w, roofline)
     if rank == 0 and not args.debug_flags and not args.no_verify:
         out["verified"] = verify_rows(w)
+    if rank == 0 and world == 1 and not args.debug_flags and not args.no_extras and backend_name == "nccl":
+        out["rccl_world1"] = rccl_world1_block(w, torch, dev)
+        out["extra"] = {"rccl_world1_ok": out["rccl_world1"]["ok"]}
     if rank == 0 and world == 1 and not args.debug_flags and not args.no_extras:
         # the other BASELINE configs and the literal wall-clock metric, outside the timed region
-        out["config5"] = config5_block(w)
+        out["config5"] = config5_block(w, verify=not args.no_verify)
         a2 = argparse.Namespace(**dict(vars(args), binsize=100000))
         w3 = Workload(a2, 100, torch, dev, dev_index, rank, world)
         dt3 = run_steps(w3, args.steps, args.warmup, SPINUP_STEPS, barrier)
@@ -773,7 +898,12 @@ def main():
         out["config2_100kb"] = {"workload": "BASELINE configs[1]: 100 kb x 100 samples, same step",
                                 "ms_per_step": dt3 / args.steps * 1e3, "value": w3.pairs_total / (dt3 / args.steps),
                                 "bins": int(w3.B), "screen_ms": r3.get("kernel_ms"), "refine_ms": r3.get("refine_ms"),
-                                "roofline_frac": r3.get("frac"), "null_ratios_ms": r3.get("null_ratios_ms")}
+                                "roofline_frac": r3.get("frac"), "null_ratios_ms": r3.get("null_ratios_ms"),
+                                "pre_ms": r3.get("pre_ms"), "appends": r3.get("appends"),
+                                "fallback_rows": r3.get("fallback_rows"),
+                                "gonosomal_passes": r3.get("gonosomal_passes")}
+        if not args.no_verify:
+            out["config2_100kb"]["verified"] = verify_rows(w3, n_blocks=40, rows_per_block=16, gon_blocks=8)
         # the CLI's wall-clock at the reference's DEFAULT bin size (main.py:377-380) -- the common
         # production shape -- beside the headline 15 kb one
         out["e2e_cli_100kb"] = e2e_cli_block(w3)

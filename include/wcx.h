@@ -77,9 +77,13 @@ double wcx_last_kernel_ms(wcx_ctx *ctx, const char *name);
 int wcx_timer_tag(wcx_ctx *ctx, const char *tag);
 /* Counters of the last wcx_newref_topk*: [0] rows searched, [1] candidate pairs evaluated,
  * [2] shortlist compactions, [3] rows that fell back to the exact brute-force path,
- * [4] pairs that passed the MFMA screen (shortlist appends), [5..7] reserved (0),
- * [8..13] per-phase wave cycles of the screen kernel (only with wcx_debug_flags(4)), [14..15] 0. */
-int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[16]);
+ * [4] pairs that passed the MFMA screen (shortlist appends), [5] pairs refined exactly,
+ * [6] tile pairs of the symmetric sweep that took the per-output path, [7] its row-direction appends,
+ * [8..13] one-directional sweep with wcx_debug_flags(4): per-phase wave cycles; symmetric sweep:
+ * [8..11] column / row gates opened and column / row events, [14..15] 0,
+ * [16] sum of the trial indices the hub-count estimators chose, [17] rows they left without an estimate,
+ * [18] rows that sent the symmetric sweep into its second attempt (0: the first one stood), [19..23] 0. */
+int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[24]);
 
 /* Device transpose of a row-major double matrix: d_dst[c][r] = d_src[r][c] (rows < 2^21).  A
  * multi-GPU build all-gathers row shards of the (bins x samples) matrix; this turns the result
@@ -171,7 +175,9 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
  * (row, partner sweep position, screen distance bits, 0) for the rank that owns the row:
  *   wcx_newref_sym_sweep_dev    rank `part` of `n_parts` (<= 32); row_bounds int64[n_parts + 1]: rank r owns
  *                               rows [row_bounds[r], row_bounds[r + 1]).  counts_out int64[n_parts] (host):
- *                               records for each destination rank.  Synchronises.
+ *                               records for each destination rank; all -1 when this rank's record pool
+ *                               overflowed: the exchange is then VOID on every rank (the counts reach all
+ *                               peers first) and each rank finishes with n_recv = -1.  Synchronises.
  *                               WCX_ERR_UNSUPPORTED where the symmetric sweep does not apply (K < 256,
  *                               B < 32768, a gonosomal pass): use wcx_newref_topk_dev on the row range.
  *   wcx_newref_sym_records_dev  the records, grouped by destination rank in rank order, into d_send
@@ -179,7 +185,8 @@ int wcx_newref_topk_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
  *   -- the caller exchanges them: ONE all-to-all --
  *   wcx_newref_sym_finish_dev   d_recv: the n_recv records received for this rank's rows: lists, final
  *                               cut, exact fp64 refine, exact redo -> out_idx int32[own rows][k],
- *                               out_dist double[own rows][k], identical to wcx_newref_topk_dev's. */
+ *                               out_dist double[own rows][k], identical to wcx_newref_topk_dev's.
+ *                               n_recv < 0 (void exchange): every own row is redone by the exact kernel. */
 int wcx_newref_sym_sweep_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const int64_t *chr_cum,
                              int n_chr, int k, int part, int n_parts, const int64_t *row_bounds,
                              int64_t *counts_out);

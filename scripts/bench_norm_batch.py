@@ -21,7 +21,12 @@ for rep in range(3):
 bad = 0
 for i in (0, 5, 17, 48, 95):
     z1, r1, n1, mlr1, mz1 = pt.normalize_repeat(xs[i], ref, cutoff, 0, 0, "", cache)
-    same = np.array_equal(z1, z[i], equal_nan=True) and np.array_equal(r1, r[i], equal_nan=True) and np.array_equal(n1, n[i])
-    print(i, "batch == single:", same, "n diffs", int(np.sum(n1 != n[i])))
-    bad += not same
+    same = np.array_equal(r1, r[i], equal_nan=True) and np.array_equal(n1, n[i]) and mlr1 == mlr[i]
+    with np.errstate(all="ignore"):
+        zerr = np.nanmax(np.abs(z1 - z[i]) / np.maximum(1e-300, np.abs(z1)))
+    zsame = np.array_equal(z1, z[i], equal_nan=True)
+    print(i, "batch == single (r, n, m_lr):", same, "n diffs", int(np.sum(n1 != n[i])), "r diffs",
+          int(np.sum(~((r1 == r[i]) | (np.isnan(r1) & np.isnan(r[i]))))), "z bitwise", zsame, "z max rel", zerr,
+          "m_z", mz1, mz[i])
+    bad += not same or not (zerr < 1e-11)
 print("BAD" if bad else "OK")

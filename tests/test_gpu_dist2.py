@@ -120,9 +120,19 @@ def test_bench_two_ranks_smoke(mode):
     assert d["verified"]["mismatches"] == 0 and d["verified"]["rows"] > 100
 
 
-def _worker_sym(rank, world, port, X, cum, k, ids, q):
+def _worker_sym(rank, world, port, X, cum, k, ids, q, ovf_rank=-1):
+    try:
+        _worker_sym_body(rank, world, port, X, cum, k, ids, q, ovf_rank)
+    except Exception as e:            # (the parent must not wait for its timeout)
+        import traceback
+        q.put((rank, "error", "{}\n{}".format(e, traceback.format_exc())))
+
+
+def _worker_sym_body(rank, world, port, X, cum, k, ids, q, ovf_rank=-1):
     sys.path.insert(0, ROOT)
     os.environ["WCX_SYM_SHARD_MIN"] = "2"
+    if rank == ovf_rank:
+        os.environ["WCX_SYM_TEST_POOL_OVF"] = "1"      # this rank reports a record-pool overflow
     import torch
     import torch.distributed as dist
     from wisecondorx_amd import _lib
@@ -187,3 +197,35 @@ def test_row_sharded_symmetric_sweep(world):
             enr = O.null_ratios(X, ei[lo:lo + 1000], lo, lo + 1000, ids)
         np.testing.assert_allclose(gnr[lo:lo + 1000], enr, rtol=1e-12, atol=1e-13)
     assert max(r[5] for r in res) <= 64              # rows the exact kernel had to redo, per rank
+
+
+def test_row_sharded_symmetric_sweep_void_exchange():
+    """A record-pool overflow on ONE rank (data-dependent in production, forced here) must not leave its
+    peers waiting in the all-to-all nor cost a hit: the counts of -1 it sends make the exchange void on
+    every rank alike, and each rank redoes its own rows with the exact kernel -- same bits as ever."""
+    import torch.multiprocessing as mp
+    from oracle import c_oracle as CO
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([7100, 6600, 6100, 5400, 4700, 3901], 256, seed=29)
+    X = np.asfortranarray(X)
+    B, k, ids, world = cum[-1], 64, [3, 1, 7, 0, 22, 39, 255, 100], 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker_sym, args=(r, world, port, X, cum, k, ids, q, 1)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    assert all(not (isinstance(r[1], str) and r[1] == "error") for r in res), [r[2] for r in res if r[1] == "error"]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[4] is not None and r[4][1] == -1, "rank {}: the exchange was not void".format(r[0])
+    ei, ed = CO.get_reference_rows_threaded(np.ascontiguousarray(X.T), cum, 0, B, k)
+    gi, gd = np.concatenate([r[1] for r in res]), np.concatenate([r[2] for r in res])
+    bad = np.flatnonzero((gi != ei).any(axis=1) | (gd != ed).any(axis=1))
+    assert bad.size == 0, "{} of {} rows differ (first {})".format(bad.size, B, bad[:5])
+    assert min(r[5] for r in res) > B // 4            # every rank redid its rows exactly

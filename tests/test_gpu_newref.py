@@ -488,3 +488,59 @@ def test_null_ratios_few_rows_any_refsize(nt, k):
     assert np.isnan(few[6, 7])
     full = nt.get_null_ratios(X, idx, 0, B, ids)
     assert np.array_equal(few, full[:500], equal_nan=True)
+
+
+@pytest.mark.parametrize("S,k", [(100, 100), (250, 120)])
+def test_one_directional_sweep_hub_count_thresholds(nt, S, k, monkeypatch):
+    """Round 6: the one-directional sweep (row shards, gonosomal passes, K < 256) takes its thresholds from
+    COUNTS over the low-norm rows (csrc/screen_hub1.h) instead of the sampled pre-pass.  Same bits as the
+    C oracle on a whole matrix, a row shard and a few-block range (candidate segments); the counters say
+    the estimator ran (one cut per row and segment -- the final one --, trials chosen); with a count nobody
+    reaches (forced) every row starts without an estimate and sweeps as the streaming top-k: same bits;
+    and switched off (the sampled pre-pass): same bits."""
+    from wisecondorx_amd import _lib
+    from wisecondorx_amd.synth import corrected_matrix
+    monkeypatch.setenv("WCX_SCREEN_SYM", "0")             # (K = 256 would take the symmetric sweep for all rows)
+    X, mbpc, cum = corrected_matrix([7000, 6500, 6000, 5500, 5000, 4500], S, seed=S + 3)      # 34 500 rows
+    B = cum[-1]
+    Xs = np.ascontiguousarray(np.asarray(X).T)
+    oi, od = CO.get_reference_rows_threaded(Xs, cum, 0, B, k)
+    ctx = _lib.default_context()
+    for r0, r1 in ((0, B), (9000, 21000), (B - 1800, B)):
+        idx, dist = nt.get_ref_for_rows(X, cum, k, r0, r1, mode=2)
+        st = ctx.topk_stats()
+        bad = np.flatnonzero((idx != oi[r0:r1]).any(axis=1) | (dist != od[r0:r1]).any(axis=1))
+        assert bad.size == 0, "rows [{}, {}): {} differ (first {})".format(r0, r1, bad.size, bad[:5])
+        assert st["rows"] == r1 - r0 and st["fallback_rows"] == 0
+        assert st["hub_trial_sum"] > 0 and st["hub_rows_without_estimate"] < 64       # the estimator ran
+        assert st["appends"] < 4 * k * (r1 - r0)           # (the streaming top-k admits k ln(B / k) ~ 6 k per row)
+    monkeypatch.setenv("WCX_HUB_TEST_FAIL", "1")
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 9000, 21000, mode=2)
+    st = ctx.topk_stats()
+    assert st["hub_rows_without_estimate"] == 12000 and st["fallback_rows"] == 0
+    assert np.array_equal(idx, oi[9000:21000]) and np.array_equal(dist, od[9000:21000])
+    monkeypatch.delenv("WCX_HUB_TEST_FAIL")
+    monkeypatch.setenv("WCX_SCREEN_HUB", "0")
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 9000, 21000, mode=2)
+    assert ctx.topk_stats()["hub_trial_sum"] == 0
+    assert np.array_equal(idx, oi[9000:21000]) and np.array_equal(dist, od[9000:21000])
+
+
+def test_one_directional_hub_thresholds_on_data_without_hubs(nt, monkeypatch):
+    """Prototype-structured rows (every row = one of a few hundred prototypes + small noise): a row's
+    neighbours are its prototype's other copies, NOT the low-norm rows -- the hub estimates come out far
+    too loose, the lists overflow into the in-sweep cuts (rigorous) and nothing changes in the results."""
+    from wisecondorx_amd import _lib
+    monkeypatch.setenv("WCX_SCREEN_SYM", "0")
+    rng = np.random.default_rng(12)
+    mb = [6000, 5600, 5200, 4800, 4400, 4000]
+    cum = np.cumsum(mb).tolist()
+    B, S, k = cum[-1], 96, 60
+    proto = 1.0 + 0.3 * rng.standard_normal((300, S))
+    X = np.asfortranarray(proto[rng.integers(0, 300, B)] * (1.0 + 0.01 * rng.standard_normal((B, S))))
+    idx, dist = nt.get_ref_for_rows(X, cum, k, 0, B, mode=2)
+    st = _lib.default_context().topk_stats()
+    oi, od = CO.get_reference_rows_threaded(np.ascontiguousarray(X.T), cum, 0, B, k)
+    bad = np.flatnonzero((idx != oi).any(axis=1) | (dist != od).any(axis=1))
+    assert bad.size == 0, "{} of {} rows differ (first {})".format(bad.size, B, bad[:5])
+    assert st["hub_trial_sum"] > 0

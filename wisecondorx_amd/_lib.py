@@ -234,11 +234,11 @@ class Context:
         return out
 
     def topk_stats(self):
-        out = (C.c_int64 * 16)()
+        out = (C.c_int64 * 24)()
         check(self.lib.wcx_last_topk_stats(self.h, out))
         return {"rows": out[0], "pairs": out[1], "compactions": out[2], "fallback_rows": out[3],
                 "appends": out[4], "refined": out[5], "sym_gates": out[6], "sym_row_appends": out[7], "phase_cycles": [out[8 + i] for i in range(6)],
-                "hub_trial_sum": out[12], "hub_rows_without_estimate": out[13], "hub_second_attempt_rows": out[14]}
+                "hub_trial_sum": out[16], "hub_rows_without_estimate": out[17], "hub_second_attempt_rows": out[18]}
 
 
 _default_ctx = {}

@@ -212,8 +212,8 @@ int wcx_ctx_create(int device, void *stream, wcx_ctx **out) {
     WCX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
   }
-  WCX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 128));
-  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, ctx->stream));
+  WCX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 256));
+  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 256, ctx->stream));
   WCX_HIP(hipMalloc(&ctx->d_small, 8192));
   *out = ctx;
   return WCX_OK;
@@ -326,16 +326,16 @@ int wcx_transpose_dev(wcx_ctx *ctx, const double *d_src, int64_t rows, int64_t c
   return wcx_transpose_launch(ctx, d_src, rows, cols, d_dst);
 }
 
-int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[16]) {
+int wcx_last_topk_stats(wcx_ctx *ctx, int64_t out[24]) {
   WCX_ARG(ctx && out, "NULL argument");
-  unsigned long long h[16] = {0};
-  WCX_HIP(hipMemcpyAsync(h, ctx->d_stats, 128, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long h[24] = {0};
+  WCX_HIP(hipMemcpyAsync(h, ctx->d_stats, 24 * 8, hipMemcpyDeviceToHost, ctx->stream));
   WCX_HIP(hipStreamSynchronize(ctx->stream));
   out[0] = ctx->topk_stats[0];
   out[1] = ctx->topk_stats[1];
   out[2] = (int64_t)h[2];
   out[3] = (int64_t)h[3];
-  for (int i = 4; i < 16; ++i) out[i] = (int64_t)h[i];
+  for (int i = 4; i < 24; ++i) out[i] = (int64_t)h[i];
   return WCX_OK;
 }
 
@@ -376,7 +376,7 @@ int wcx_newref_sym_records_dev(wcx_ctx *ctx, void *d_send) {
 
 int wcx_newref_sym_finish_dev(wcx_ctx *ctx, const void *d_recv, int64_t n_recv, int32_t *d_out_idx,
                               double *d_out_dist) {
-  WCX_ARG(ctx && d_out_idx && d_out_dist && n_recv >= 0 && (d_recv || n_recv == 0), "bad argument");
+  WCX_ARG(ctx && d_out_idx && d_out_dist && (d_recv || n_recv <= 0), "bad argument");   // (n_recv < 0: void exchange)
   WCX_HIP(hipSetDevice(ctx->device));
   return wcx_sym_shard_finish(ctx, d_recv, n_recv, d_out_idx, d_out_dist);
 }

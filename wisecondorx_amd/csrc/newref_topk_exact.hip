@@ -376,7 +376,7 @@ int wcx_topk_exact_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   unsigned long long *d_stats = ctx->d_stats;
   rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blk_bytes);
   if (rc) return rc;
-  WCX_HIP(hipMemsetAsync(d_stats, 0, 128, ctx->stream));   // (all counters: the screen's too -- this call did not screen)
+  WCX_HIP(hipMemsetAsync(d_stats, 0, 256, ctx->stream));   // (all counters: the screen's too -- this call did not screen)
   WCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_topk_exact),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   rc = wcx_timer_begin(ctx, "topk");

@@ -46,7 +46,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int CSPLIT = 16;   // workgroups per sample column
 
-// per-sample mean over finite entries: partial sums, fp64 atomics
+// per-sample mean over finite entries: deterministic partial sums (no floating-point atomics)
 __device__ __forceinline__ unsigned long long dord(double x) {   // order-preserving image
   const unsigned long long u = (unsigned long long)__double_as_longlong(x);
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
@@ -57,11 +57,16 @@ __device__ __forceinline__ double dord_inv(unsigned long long k) {
 
 // ONE sweep of X: per-sample sum, count, min and max over finite entries (max |x - mean| follows
 // from min and max: it is attained at one of them, with the same rounding as fabs(x - mean)).
+// The sums are DETERMINISTIC: every workgroup writes its partial (its waves added in wave order) to a
+// table and k_col_stats adds the CSPLIT partials of a column in index order -- no floating-point atomics.
+// The row-sharded symmetric sweep depends on it: every rank must derive bit-identical means, hence
+// fragments, sweep order and thresholds (the records it exchanges name sweep positions).
 __global__ __launch_bounds__(NT) void k_col_sum(const double *__restrict__ Xs, int64_t B,
-                                                double *__restrict__ csum,
-                                                double *__restrict__ ccnt,
+                                                double *__restrict__ psum,      // [S][CSPLIT]
+                                                double *__restrict__ pcnt,      // [S][CSPLIT]
                                                 unsigned long long *__restrict__ cmin,
                                                 unsigned long long *__restrict__ cmax) {
+  __shared__ double ws[NT / 64], wc[NT / 64];
   const double *x = Xs + (int64_t)blockIdx.x * B;
   double s = 0.0, c = 0.0, mn = HUGE_VAL, mx = -HUGE_VAL;
   for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < B; i += (int64_t)NT * CSPLIT) {
@@ -72,23 +77,33 @@ __global__ __launch_bounds__(NT) void k_col_sum(const double *__restrict__ Xs, i
   c = wcx::wave_sum(c);
   mn = wcx::wave_min_f64(mn);
   mx = wcx::wave_max_f64(mx);
-  if ((threadIdx.x & 63) == 0 && c > 0.0) {
-    atomicAdd(&csum[blockIdx.x], s);
-    atomicAdd(&ccnt[blockIdx.x], c);
-    atomicMin(&cmin[blockIdx.x], dord(mn));
-    atomicMax(&cmax[blockIdx.x], dord(mx));
+  if ((threadIdx.x & 63) == 0) {
+    ws[threadIdx.x >> 6] = s;
+    wc[threadIdx.x >> 6] = c;
+    if (c > 0.0) {
+      atomicMin(&cmin[blockIdx.x], dord(mn));       // (min / max: order-independent)
+      atomicMax(&cmax[blockIdx.x], dord(mx));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (int w = 0; w < NT / 64; ++w) { ts += ws[w]; tc += wc[w]; }
+    psum[(int64_t)blockIdx.x * CSPLIT + blockIdx.y] = ts;
+    pcnt[(int64_t)blockIdx.x * CSPLIT + blockIdx.y] = tc;
   }
 }
 
-// cmean[j] = csum/ccnt; global max |x - mean| over finite entries
-__global__ void k_col_stats(int S, const double *__restrict__ csum, const double *__restrict__ ccnt,
+// cmean[j] = sum / count (partials added in index order); global max |x - mean| over finite entries
+__global__ void k_col_stats(int S, const double *__restrict__ psum, const double *__restrict__ pcnt,
                             const unsigned long long *__restrict__ cmin,
                             const unsigned long long *__restrict__ cmax,
                             double *__restrict__ cmean, ScreenGlobals *__restrict__ glob) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= S) return;
-  const double cc = ccnt[j];
-  const double m = cc > 0 ? csum[j] / cc : 0.0;
+  double cs = 0.0, cc = 0.0;
+  for (int p = 0; p < CSPLIT; ++p) { cs += psum[(int64_t)j * CSPLIT + p]; cc += pcnt[(int64_t)j * CSPLIT + p]; }
+  const double m = cc > 0 ? cs / cc : 0.0;
   cmean[j] = m;
   if (cc > 0) {
     const double a0 = fabs(dord_inv(cmax[j]) - m), a1 = fabs(dord_inv(cmin[j]) - m);
@@ -818,7 +833,7 @@ __global__ void k_hub_verdict(const unsigned int *__restrict__ n_failed, unsigne
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const unsigned int bad = *n_failed > HUB_FAIL_MAX ? 1u : 0u;
     *gate = bad;
-    if (stats) stats[14] = bad ? *n_failed : 0ull;       // (diagnostics: rows that sent the sweep round again)
+    if (stats) stats[18] = bad ? *n_failed : 0ull;       // (diagnostics: rows that sent the sweep round again)
   }
 }
 // Second attempt only: lists, flags, record pool, work queue and sequence counters back to empty.
@@ -993,6 +1008,7 @@ struct SymShardState {
   int32_t *d_rlist = nullptr;
   void *rscr = nullptr;
   unsigned long long counts[32] = {0};
+  bool overflow = false;                         // this rank's record pool overflowed: the exchange is void
 };
 struct SymShardCall { int part, n_parts; RowBounds rb; SymShardState *state; };
 
@@ -1056,7 +1072,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_glob = carve(sizeof(ScreenGlobals));
-  const size_t o_mean = carve((size_t)S * 8 * 5);
+  const size_t o_mean = carve((size_t)S * 8 * (3 + 2 * CSPLIT));   // mean | min | max | partial sums | partial counts
   const size_t o_xr = carve((size_t)B * Sp * 8 + 256);
   const size_t o_F = carve((size_t)PB * NK * 32);
   const size_t o_Fs = carve((size_t)P_s * NK * 32);
@@ -1155,7 +1171,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   WCX_HIP(hipMemsetAsync(searched, 1, (size_t)n_rows, st));          // every row is a target
   WCX_HIP(hipMemsetAsync(pool_head, 0, 256, st));
   WCX_HIP(hipMemsetAsync(d_nredo, 0, 512, st));
-  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, st));
+  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 256, st));
   rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
   if (rc) return rc;
 
@@ -1163,14 +1179,13 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   if (rc) return rc;
   rc = wcx_timer_begin(ctx, "topk_prep");
   if (rc) return rc;
-  unsigned long long *cmin = reinterpret_cast<unsigned long long *>(cmean + 3 * S);
+  unsigned long long *cmin = reinterpret_cast<unsigned long long *>(cmean + S);
   unsigned long long *cmax = cmin + S;
-  WCX_HIP(hipMemsetAsync(cmean + S, 0, (size_t)S * 16, st));
+  double *psum = cmean + 3 * S, *pcnt = psum + (size_t)S * CSPLIT;
   WCX_HIP(hipMemsetAsync(cmin, 0xff, (size_t)S * 8, st));
   WCX_HIP(hipMemsetAsync(cmax, 0, (size_t)S * 8, st));
-  k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, cmean + S, cmean + 2 * S, cmin, cmax);
-  k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, cmean + S, cmean + 2 * S, cmin, cmax, cmean,
-                                                         glob);
+  k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, psum, pcnt, cmin, cmax);
+  k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, psum, pcnt, cmin, cmax, cmean, glob);
   k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
   ChrTab tab;
   tab.n_chr = n_chr;
@@ -1360,10 +1375,15 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
       WCX_HIP(hipMemcpyAsync(Z.counts, d_counts, 32 * 8, hipMemcpyDeviceToHost, st));
       WCX_HIP(hipMemcpyAsync(head2, pool_head, 8, hipMemcpyDeviceToHost, st));
       WCX_HIP(hipStreamSynchronize(st));
-      if (head2[1] || head2[0] > pool_cap) {
-        wcx_set_error("record pool of the sharded sweep overflowed (%u records, room for %u)", head2[0], pool_cap);
-        return (int)WCX_ERR_NOMEM;
-      }
+      // Record pool overflow (loose thresholds on data without hubs; data-dependent, per rank): a lost record
+      // would be a wrong neighbour list somewhere, so the whole exchange is declared void -- counts of -1
+      // reach every peer with the counts' all-to-all, nobody sends records, and every rank redoes its own
+      // rows with the exact kernel (wcx_newref_sym_finish_dev, n_recv < 0): the unsharded path's answer to
+      // the same overflow.  No rank raises alone, nobody is left waiting in a collective.
+      // (WCX_SYM_TEST_POOL_OVF=1, tests: as if the pool had overflowed)
+      Z.overflow = head2[1] || head2[0] > pool_cap || env_int("WCX_SYM_TEST_POOL_OVF", 0) != 0;
+      if (Z.overflow)
+        for (int r = 0; r < 32; ++r) Z.counts[r] = 0;
       Z.valid = true;
       Z.B = B; Z.row_begin = sh->rb.b[sh->part]; Z.row_end = sh->rb.b[sh->part + 1];
       Z.S = S; Z.Sp = Sp; Z.NK = NK; Z.k = k; Z.cap2 = cap2; Z.n_parts = sh->n_parts; Z.part = sh->part;
@@ -1626,7 +1646,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // (an explicit sampling rate / sample rank asks for the sampled pre-pass: tests of that path)
   const int hub1_dflt = (getenv("WCX_SCREEN_SAMPLE") || getenv("WCX_SCREEN_CUT_R")) ? 0 : 1;
   const bool use_hub1 = env_int("WCX_SCREEN_HUB", hub1_dflt) != 0 && NK >= 5 && hub_frac1 > 1 && hub_rows1 * 6 <= B &&
-                        cfg.tt == 1 && cfg.wpb == 4 && cfg.ring >= 2 && !cfg.prof;
+                        cfg.tt == 1 && cfg.wpb == 4 && cfg.ring >= 2;
   if (use_hub1) {
     SF = 0;
     n_s = 0;
@@ -1639,7 +1659,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_glob = carve(sizeof(ScreenGlobals));
-  const size_t o_mean = carve((size_t)S * 8 * 5);   // mean | sum | count | min | max
+  const size_t o_mean = carve((size_t)S * 8 * (3 + 2 * CSPLIT));   // mean | min | max | partial sums | partial counts
   const int Sp = row_pitch(S);
   const size_t o_xr = carve((size_t)B * Sp * 8 + 256);   // + slack: refine loads whole 128-B chunks
   const size_t o_F = carve((size_t)Bpad * NK * 32);  // Bpad/32 tiles * NK * 1 KiB
@@ -1700,7 +1720,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipMemsetAsync(flags, 0, (size_t)n_seg * n_rows * 4, st));
   WCX_HIP(hipMemsetAsync(searched, 0, (size_t)n_rows, st));
   WCX_HIP(hipMemsetAsync(d_nredo, 0, 512, st));
-  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 128, st));
+  WCX_HIP(hipMemsetAsync(ctx->d_stats, 0, 256, st));
   rc = wcx_upload_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(ScreenBlock));
   if (rc) return rc;
   k_mark<<<(unsigned)blocks.size(), 256, 0, st>>>(searched, d_blocks, row_begin);
@@ -1709,14 +1729,13 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   if (rc) return rc;
   rc = wcx_timer_begin(ctx, "topk_prep");
   if (rc) return rc;
-  unsigned long long *cmin = reinterpret_cast<unsigned long long *>(cmean + 3 * S);
+  unsigned long long *cmin = reinterpret_cast<unsigned long long *>(cmean + S);
   unsigned long long *cmax = cmin + S;
-  WCX_HIP(hipMemsetAsync(cmean + S, 0, (size_t)S * 16, st));
+  double *psum = cmean + 3 * S, *pcnt = psum + (size_t)S * CSPLIT;
   WCX_HIP(hipMemsetAsync(cmin, 0xff, (size_t)S * 8, st));
   WCX_HIP(hipMemsetAsync(cmax, 0, (size_t)S * 8, st));
-  k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, cmean + S, cmean + 2 * S, cmin, cmax);
-  k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, cmean + S, cmean + 2 * S, cmin, cmax, cmean,
-                                                         glob);
+  k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, psum, pcnt, cmin, cmax);
+  k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, psum, pcnt, cmin, cmax, cmean, glob);
   k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
   ChrTab tab;
   tab.n_chr = n_chr;
@@ -1812,7 +1831,11 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
     if (cap_g > 8192) cap_g = 8192;
     ha.glist_cap = (int)cap_g + 64;
     const size_t lds_h = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)ha.glist_cap * 4;
-    const int trials = env_int("WCX_HUB1_TRIALS", NK >= 16 ? 8 : 4);
+    // (trial thresholds per row: eight are a finer ladder -- fewer rows whose estimate overshoots into an
+    //  in-sweep cut -- but cost the count pass 2 x 8 vector instructions per output, which at K <= 128 and
+    //  more than a round of workgroups is what bounds it: 15 kb x 100: 4 / 8 trials = pass 1.24 / 1.91 ms,
+    //  sweep total 11.59 / 11.89; 100 kb x 100, 213 workgroups: 1.63 / 1.36 ms)
+    const int trials = env_int("WCX_HUB1_TRIALS", (NK >= 16 || (int)blocks.size() <= slots) ? 8 : 4);
     int e = wcx_hub1_launch_k1(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
     if (e < 0) e = wcx_hub1_launch_k2(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
     if (e < 0) e = wcx_hub1_launch_k3(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
@@ -1979,7 +2002,7 @@ int wcx_sym_shard_sweep(wcx_ctx *ctx, const double *dXs, int64_t B, int S, const
   const int rc = screen_sym_path(ctx, dXs, B, S, chr_cum, n_chr, none, cfg, 16, 0, 1, slots, k, nullptr, nullptr,
                                  &call);
   if (rc) return rc;
-  for (int r = 0; r < n_parts; ++r) counts_out[r] = (int64_t)Z->counts[r];
+  for (int r = 0; r < n_parts; ++r) counts_out[r] = Z->overflow ? -1 : (int64_t)Z->counts[r];
   return WCX_OK;
 }
 
@@ -2017,6 +2040,9 @@ int wcx_sym_shard_finish(wcx_ctx *ctx, const void *d_recv, int64_t n_recv, int32
   int *cnt = Z->cnt + r0;
   unsigned int *flags = Z->flags + r0;
   WCX_HIP(hipMemsetAsync(cnt, 0, (size_t)n_own * 4, st));
+  // n_recv < 0: some rank's record pool overflowed, the exchange is void -- every row of this rank goes to
+  // the exact kernel (flags != 0), like the unsharded path's overflow
+  if (n_recv < 0) WCX_HIP(hipMemsetAsync(flags, 1, (size_t)n_own * 4, st));
   if (n_recv > 0)
     k_rec_regroup<<<2048, NT, 0, st>>>(reinterpret_cast<const uint4 *>(d_recv), n_recv, r0, n_own, Z->sl, cnt, flags,
                                        Z->cap2);

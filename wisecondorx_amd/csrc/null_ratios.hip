@@ -417,6 +417,181 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// The two middle order statistics of an ARBITRARY active set (bit q of `act` <-> element v[q] of this
+// lane; n = its size, wave-uniform, >= 1): wave_middle_u32 for sets that are not a dense prefix -- the
+// reference bins of a normalisation pass that are selected (distance below the cut-off) and not masked.
+template <int IPL>
+__device__ __forceinline__ void wave_middle_u32_act(const unsigned int (&v)[IPL], unsigned int act, int n,
+                                                    int *hist, unsigned int *slots, unsigned int &a0,
+                                                    unsigned int &a1) {
+  const int lane = wcx::lane_id();
+  const int r0 = (n - 1) >> 1, r1 = n >> 1;
+  unsigned int lo = 0xffffffffu, nhi = 0xffffffffu;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q)
+    if ((act >> q) & 1u) { lo = v[q] < lo ? v[q] : lo; nhi = ~v[q] < nhi ? ~v[q] : nhi; }
+  lo = wave_min_u32(lo);
+  const unsigned int hi = ~wave_min_u32(nhi);
+  if (hi == lo) { a0 = lo; a1 = lo; return; }
+  const float scale = 64.0f / ((float)(hi - lo) * 1.0000002f + 1.0f);   // bucket(hi) <= 63
+  hist[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  int b[IPL];
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    b[q] = -1;
+    if ((act >> q) & 1u) {
+      int bb = (int)((float)(v[q] - lo) * scale);          // monotone in v
+      bb = bb > 63 ? 63 : bb;
+      b[q] = bb;
+      atomicAdd(&hist[bb], 1);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int h = hist[lane];
+  const int cum = wcx::wave_incl_scan_i(h);
+  const unsigned long long gt = __ballot(cum > r0);
+  const int B0 = __ffsll((long long)gt) - 1;                 // gt != 0: cum[63] = n > r0
+  const int before = B0 > 0 ? __builtin_amdgcn_readlane(cum, B0 - 1) : 0;
+  const int need = r0 - before;
+  const int cB = __builtin_amdgcn_readlane(h, B0);
+  if (cB > 64) {                                             // heavy duplicates: general path
+    a0 = select_u32_bisect<IPL>(v, act, r0);
+    a1 = r1 == r0 ? a0 : select_u32_bisect<IPL>(v, act, r1);
+    return;
+  }
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const bool m = b[q] == B0;
+    const unsigned long long mm = __ballot(m);
+    if (m) slots[base + __popcll(mm & ((1ull << lane) - 1ull))] = v[q];
+    base += __popcll(mm);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned int w = lane < cB ? slots[lane] : 0xffffffffu;
+  int rk = 0;
+  for (int L = 0; L < cB; ++L) {
+    const unsigned int p = (unsigned int)__builtin_amdgcn_readlane((int)w, L);
+    rk += ((p < w) || (p == w && L < lane)) ? 1 : 0;
+  }
+  const unsigned long long hit = __ballot(lane < cB && rk == need);
+  a0 = (unsigned int)__builtin_amdgcn_readlane((int)w, __ffsll((long long)hit) - 1);
+  a1 = a0;
+  if (r1 != r0) {
+    if (need + 1 < cB) {
+      const unsigned long long hit1 = __ballot(lane < cB && rk == need + 1);
+      a1 = (unsigned int)__builtin_amdgcn_readlane((int)w, __ffsll((long long)hit1) - 1);
+    } else {                         // next order statistic = smallest value of the later buckets
+      unsigned int mn = 0xffffffffu;
+#pragma unroll
+      for (int q = 0; q < IPL; ++q)
+        if (b[q] > B0 && v[q] < mn) mn = v[q];
+      a1 = wave_min_u32(mn);
+    }
+  }
+}
+
+// ---- The medians of the LAST normalisation pass of a batch (predict_tools.py:137: the ratio's divisor)
+// on RANKS.  A batch's samples are ranked once (k_rank_*: the same pipeline, the batch's [n][B] matrix of
+// projected coverages as "the null samples"); k_norm_rank_mark sets bit 31 of the rank of every (bin,
+// sample) the first two passes masked (or that fails the >= 0 test anyway: predict_tools.py:134); then one
+// wave per (bin, 8 samples) gathers the 32-byte rank pieces of the bin's selected reference bins -- the
+// gathers k_null_ratios does -- and takes the middle of the unmasked ones: exact (rank order is value
+// order), 4 bytes and one-instruction compares per element where the tiled kernel selects on doubles.
+constexpr unsigned int RANK_MASKED = 0x80000000u;
+__global__ __launch_bounds__(NT) void k_norm_rank_mark(unsigned int *__restrict__ Rg,
+                                                       const double *__restrict__ copyT, int64_t B, int NS,
+                                                       int n_samples) {
+  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+  const int g = blockIdx.y;
+  if (b >= B) return;
+  uint4 *p = reinterpret_cast<uint4 *>(Rg + ((int64_t)g * B + b) * 8);
+  uint4 r0 = p[0], r1 = p[1];
+  unsigned int r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int s = g * 8 + j;
+    if (s < n_samples && !(copyT[b * NS + s] >= 0.0)) { r[j] |= RANK_MASKED; any = true; }
+  }
+  if (any) {
+    p[0] = make_uint4(r[0], r[1], r[2], r[3]);
+    p[1] = make_uint4(r[4], r[5], r[6], r[7]);
+  }
+}
+
+template <int IPL>
+__global__ __launch_bounds__(NT) void k_norm_median_rank(
+    const unsigned int *__restrict__ Rg, const double *__restrict__ V, const int32_t *__restrict__ idx,
+    const unsigned long long *__restrict__ sel, const double *__restrict__ xT, int64_t B, int k, int NS,
+    int n_samples, int64_t ct, WcxChrCum chr, double *__restrict__ rT, double *__restrict__ lrT) {
+  const int lane = wcx::lane_id();
+  const int wave = threadIdx.x >> 6;
+  __shared__ int s_hist[NT / 64][64];
+  __shared__ unsigned int s_slots[NT / 64][64];
+  const int64_t i = ct + (int64_t)blockIdx.x * (NT / 64) + wave;
+  if (i >= B) return;
+  const int sg = blockIdx.y;
+  const uint4 *slab = reinterpret_cast<const uint4 *>(Rg + (int64_t)sg * B * 8);
+  int64_t cs = 0, ce = chr.cum[0];
+  for (int c = 1; c < chr.n_chr && i >= ce; ++c) { cs = ce; ce = chr.cum[c]; }
+  const int64_t own = ce - cs;
+  const int64_t len_cd = B - own;                 // len(chr_data), predict_tools.py:125-130
+  unsigned int v[8][IPL];
+  unsigned int selmask = 0;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int t = q * 64 + lane;
+    const bool selq = (t < k) && ((sel[i * IPL + q] >> lane) & 1ull);
+    uint4 a0 = make_uint4(RANK_MASKED, RANK_MASKED, RANK_MASKED, RANK_MASKED), a1 = a0;
+    if (selq) {
+      int64_t c = idx[i * (int64_t)k + t];
+      if (c < 0) c += len_cd;                      // NumPy negative index
+      const int64_t g = c < cs ? c : c + own;      // chr_data index -> row
+      a0 = slab[g * 2];
+      a1 = slab[g * 2 + 1];
+      selmask |= 1u << q;
+    }
+    v[0][q] = a0.x; v[1][q] = a0.y; v[2][q] = a0.z; v[3][q] = a0.w;
+    v[4][q] = a1.x; v[5][q] = a1.y; v[6][q] = a1.z; v[7][q] = a1.w;
+  }
+  unsigned int my_a0 = 0, my_a1 = 0;
+  int my_n = 0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (sg * 8 + s >= n_samples) break;            // (wave-uniform: padding samples of the last group)
+    unsigned int act = 0;
+    int n = 0;
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+      const bool on = !(v[s][q] & RANK_MASKED);    // selected (unselected slots carry the bit) and kept
+      act |= on ? (1u << q) : 0u;
+      n += __popcll(__ballot(on));
+    }
+    unsigned int a0 = 0, a1 = 0;
+    if (n > 0) wave_middle_u32_act<IPL>(v[s], act, n, s_hist[wave], s_slots[wave], a0, a1);
+    if (lane == s) { my_a0 = a0; my_a1 = a1; my_n = n; }
+  }
+  const int m = sg * 8 + lane;
+  if (lane < 8 && m < n_samples) {
+    const double *Vm = V + (int64_t)m * B;
+    double med = __builtin_nan("");                // np.median of nothing
+    if (my_n > 0) {
+      const double a = Vm[my_a0];
+      med = (my_n & 1) ? a : (a + Vm[my_a1]) / 2.0;
+    }
+    const double r = xT[i * NS + m] / med;         // predict_tools.py:137
+    rT[i * NS + m] = r;
+    lrT[i * NS + m] = log2(r);
+  }
+}
+
+__global__ void k_iota_i32(int32_t *p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
 // ---- FEW target rows: selection on the HIGH HALVES of the values' keys (no ranking at all) -------
 // Ranking every bin of every null sample (a sample sort of n_ids * B elements: 1.3 ms alone on the device,
 // 3-4 ms beside the refine it shares the chip with -- when round 2 measured this it was a library sort: 6.7 ms of device
@@ -690,6 +865,63 @@ static int rank_run(const double *dXs, int64_t B, int n_ids, const RankLayout &L
   WCX_HIP(hipGetLastError());
   return WCX_OK;
 }
+
+}  // extern "C"
+
+size_t wcx_rank_bytes(int64_t B, int n) {
+  RankLayout L;
+  rank_layout(B, n, nullptr, L);
+  return L.total;
+}
+
+int wcx_rank_rows_launch(const double *d_x, int64_t B, int n, char *base, hipStream_t st, WcxRankView *out) {
+  WCX_ARG(n > 0 && n <= 128 && B < (1ll << BIN_BITS) && (int64_t)n * B < (1ll << 31), "too many rows / bins to rank");
+  RankLayout L;
+  rank_layout(B, n, st, L);
+  k_iota_i32<<<1, 128, 0, st>>>(reinterpret_cast<int32_t *>(base + L.o_sid), n);
+  const int rc = rank_run(d_x, B, n, L, base, st);
+  if (rc) return rc;
+  out->Rg = reinterpret_cast<unsigned int *>(base + L.o_rg);
+  out->V = reinterpret_cast<const double *>(base + L.o_v);
+  out->n_sg = L.n_sg;
+  return WCX_OK;
+}
+
+int wcx_norm_rank_mark_launch(const WcxRankView &rk, const double *copyT, int64_t B, int NS, int n_samples,
+                              hipStream_t st) {
+  k_norm_rank_mark<<<dim3((unsigned)((B + NT - 1) / NT), (unsigned)rk.n_sg), NT, 0, st>>>(rk.Rg, copyT, B, NS,
+                                                                                          n_samples);
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
+int wcx_norm_median_rank_launch(const WcxRankView &rk, const int32_t *d_idx, const unsigned long long *d_sel,
+                                const double *xT, int64_t B, int k, int ipl, int NS, int n_samples, int64_t ct,
+                                const WcxChrCum &chr, double *rT, double *lrT, hipStream_t st) {
+  const int64_t n_rows = B - ct;
+  if (n_rows <= 0) return WCX_OK;
+  const dim3 grid((unsigned)((n_rows + NT / 64 - 1) / (NT / 64)), (unsigned)rk.n_sg);
+#define WCX_NMR_LAUNCH(IPL)                                                                            \
+  k_norm_median_rank<IPL><<<grid, NT, 0, st>>>(rk.Rg, rk.V, d_idx, d_sel, xT, B, k, NS, n_samples, ct, chr, rT, lrT)
+  switch (ipl) {
+    case 1: WCX_NMR_LAUNCH(1); break;
+    case 2: WCX_NMR_LAUNCH(2); break;
+    case 3: WCX_NMR_LAUNCH(3); break;
+    case 4: WCX_NMR_LAUNCH(4); break;
+    case 5: WCX_NMR_LAUNCH(5); break;
+    case 6: WCX_NMR_LAUNCH(6); break;
+    case 7: WCX_NMR_LAUNCH(7); break;
+    case 8: WCX_NMR_LAUNCH(8); break;
+    default:
+      wcx_set_error("rank medians: %d values per lane are not instantiated", ipl);
+      return WCX_ERR_UNSUPPORTED;
+  }
+#undef WCX_NMR_LAUNCH
+  WCX_HIP(hipGetLastError());
+  return WCX_OK;
+}
+
+extern "C" {
 
 static int check_ids(const int32_t *sample_ids, int n_ids, int S) {
   for (int i = 0; i < n_ids; ++i)

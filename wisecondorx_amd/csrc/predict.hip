@@ -388,11 +388,17 @@ __global__ __launch_bounds__(NT) void k_normalize_mask_lanes(
 // (cumulative: masked at pass 0 or now).  (The updated sums differ from freshly accumulated ones by
 // rounding, ~1e-16 relative: a |z| within that of 3 could flip a mask bit against the one-sample path --
 // the same caveat as for the lane-per-sample sums themselves)
+// st_mask_new != nullptr (rank-median scheme): the updated sums and counts are written back and the word of
+// samples masked NOW goes to st_mask_new -- the same kernel then runs once more as the statistics of the
+// LAST pass (zT != nullptr: its set = this pass's minus the bins in st_mask; z and n, sample-minor, are the
+// outputs; nothing else is written).
 __global__ __launch_bounds__(NT) void k_normalize_mask_incr(
     const double *__restrict__ xT, double *__restrict__ copy_out, const int32_t *__restrict__ idx,
     const unsigned long long *__restrict__ sel, int64_t B, int k, int ipl, int NS, int64_t lo, int64_t hi,
-    ChrTable chr, const double *__restrict__ st_S1, const double *__restrict__ st_S2,
-    const int *__restrict__ st_n, const unsigned long long *__restrict__ st_mask) {
+    ChrTable chr, double *__restrict__ st_S1, double *__restrict__ st_S2,
+    int *__restrict__ st_n, const unsigned long long *__restrict__ st_mask,
+    const unsigned long long *__restrict__ st_was = nullptr, unsigned long long *__restrict__ st_mask_new = nullptr,
+    double *__restrict__ zT = nullptr, double *__restrict__ nT = nullptr) {
   const int lane = wcx::lane_id();
   const int s = blockIdx.y * 64 + lane;             // my sample (NS is a multiple of 64)
   const int n_tiles = NS >> 6;
@@ -452,8 +458,40 @@ __global__ __launch_bounds__(NT) void k_normalize_mask_incr(
     const double var = (S2 - S1 * (S1 / dn)) / dn;
     const double sd = sqrt(var > 0.0 ? var : 0.0);
     const double z = (c0 - mean) / sd;                // predict_tools.py:136
-    const bool was = (st_mask[i * n_tiles + blockIdx.y] >> lane) & 1ull;
+    if (zT) {                                         // statistics of the last pass
+      zT[i * NS + s] = z;
+      nT[i * NS + s] = dn;
+      continue;
+    }
+    const bool was = ((st_was ? st_was : st_mask)[i * n_tiles + blockIdx.y] >> lane) & 1ull;
     copy_out[i * NS + s] = (was || fabs(z) >= Z_MASK) ? -1.0 : c0;   // :104 (c0 < 0 stays as it is)
+    if (st_mask_new) {
+      st_S1[i * NS + s] = S1;
+      st_S2[i * NS + s] = S2;
+      st_n[i * NS + s] = n;
+      const unsigned long long m = __ballot(!was && fabs(z) >= Z_MASK && c0 >= 0.0);
+      if (lane == 0) st_mask_new[i * n_tiles + blockIdx.y] = m;
+    }
+  }
+}
+
+// sample-minor [B - ct rows from ct][NS] -> [n_samples][Bp] (the layout of the outputs)
+__global__ __launch_bounds__(256) void k_from_sample_minor(const double *__restrict__ aT, int64_t ct, int64_t Bp,
+                                                           int NS, int n_samples, double *__restrict__ out) {
+  __shared__ double tile[32][33];
+  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int s0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t bb = b0 + r;
+    const int sx = s0 + tx;
+    tile[r][tx] = (bb < Bp && sx < NS) ? aT[(ct + bb) * NS + sx] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int sx = s0 + r;
+    const int64_t bb = b0 + tx;
+    if (sx < n_samples && bb < Bp) out[(int64_t)sx * Bp + bb] = tile[tx][r];
   }
 }
 
@@ -1282,8 +1320,16 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
   static const int incr_on = [] { const char *e = getenv("WCX_NORM_INCR"); return e && *e ? atoi(e) : 1; }();
   const bool incr = lanes && incr_on;
   const size_t st_b = incr ? 2 * cp_b + (size_t)NS * B * 4 + (size_t)B * (NS / 64) * 8 + 256 : 0;
+  // rank medians (round 6): the last pass's medians on the samples' RANKS (null_ratios.hip:
+  // k_norm_median_rank), its statistics from the incrementally updated sums; WCX_NORM_RANKMED=0: the tiled
+  // kernel does the whole last pass (and for batches beyond the ranking's 128 rows)
+  static const int rankmed_on = [] { const char *e = getenv("WCX_NORM_RANKMED"); return e && *e ? atoi(e) : 1; }();
+  const bool rankmed = incr && rankmed_on && n_samples <= 128 && B < (1ll << 25) &&
+                       (int64_t)n_samples * B < (1ll << 31);
+  const size_t mw_b = (size_t)B * (NS / 64) * 8 + 256;
+  const size_t rk_b = rankmed ? 2 * mw_b + 4 * cp_b + wcx_rank_bytes(B, n_samples) + 1024 : 0;
   void *scr = nullptr;
-  int rc = wcx_scratch(ctx, (lanes ? 3 : 2) * cp_b + lr_b + st_b, &scr);
+  int rc = wcx_scratch(ctx, (lanes ? 3 : 2) * cp_b + lr_b + st_b + rk_b, &scr);
   if (rc) return rc;
   double *cA = reinterpret_cast<double *>(scr);
   double *cB = cA + (size_t)NS * B;
@@ -1293,8 +1339,22 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
   double *stS2 = incr ? stS1 + (size_t)NS * B : nullptr;
   unsigned long long *stM = incr ? reinterpret_cast<unsigned long long *>(stS2 + (size_t)NS * B) : nullptr;
   int *stN = incr ? reinterpret_cast<int *>(stM + (size_t)B * (NS / 64) + 8) : nullptr;
+  char *rkp = rankmed ? reinterpret_cast<char *>(stN) + ((size_t)NS * B * 4 + 255) / 256 * 256 : nullptr;
+  unsigned long long *stM1 = reinterpret_cast<unsigned long long *>(rkp);          // masked at pass 1
+  unsigned long long *stM01 = reinterpret_cast<unsigned long long *>(rkp + mw_b);  // (unused words: spare)
+  double *zT = reinterpret_cast<double *>(rkp + 2 * mw_b);
+  double *nT = rankmed ? zT + (size_t)NS * B : nullptr;
+  double *rT = rankmed ? nT + (size_t)NS * B : nullptr;
+  double *lrT = rankmed ? rT + (size_t)NS * B : nullptr;
+  char *rank_base = rankmed ? reinterpret_cast<char *>(lrT + (size_t)NS * B) : nullptr;
+  (void)stM01;
   rc = wcx_timer_begin(ctx, "normalize");
   if (rc) return rc;
+  WcxRankView rkv{nullptr, nullptr, 0};
+  if (rankmed) {
+    rc = wcx_rank_rows_launch(d_x, B, n_samples, rank_base, ctx->stream, &rkv);
+    if (rc) return rc;
+  }
   if (tiled) {
     k_to_sample_minor<<<dim3((unsigned)((B + 31) / 32), (unsigned)((NS + 31) / 32)), 256, 0,
                         ctx->stream>>>(d_x, B, n_samples, NS, cA, cB);
@@ -1321,12 +1381,39 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
         k_normalize_mask_lanes<<<grid, NT, 0, ctx->stream>>>(xT, cin, cout, ref->d_idx, ref->d_sel, B, ref->k,
                                                              ipl_for(ref->k), NS, ct, B, tab, stS1, stS2, stN, stM);
       } else if (incr) {
+        if (rankmed && ct > 0) WCX_HIP(hipMemsetAsync(stM1, 0, (size_t)ct * (NS / 64) * 8, ctx->stream));
         k_normalize_mask_incr<<<grid, NT, 0, ctx->stream>>>(xT, cout, ref->d_idx, ref->d_sel, B, ref->k,
-                                                            ipl_for(ref->k), NS, ct, B, tab, stS1, stS2, stN, stM);
+                                                            ipl_for(ref->k), NS, ct, B, tab, stS1, stS2, stN, stM,
+                                                            nullptr, rankmed ? stM1 : nullptr);
       } else {
         k_normalize_mask_lanes<<<grid, NT, 0, ctx->stream>>>(xT, cin, cout, ref->d_idx, ref->d_sel, B, ref->k,
                                                              ipl_for(ref->k), NS, ct, B, tab);
       }
+      WCX_HIP(hipGetLastError());
+    } else if (rankmed) {
+      // the last pass without the tiled kernel: statistics by one more incremental update (the bins pass 1
+      // masked leave the sums), medians on ranks; all four outputs sample-minor, transposed at the end
+      ChrTable tab;
+      tab.n_chr = (int)ref->chr_cum.size();
+      for (int c = 0; c < 32; ++c) tab.cum[c] = c < tab.n_chr ? ref->chr_cum[c] : B;
+      WcxChrCum cc;
+      cc.n_chr = tab.n_chr;
+      for (int c = 0; c < 32; ++c) cc.cum[c] = tab.cum[c];
+      const dim3 grid((unsigned)((Bp + 3) / 4 < 16384 ? (Bp + 3) / 4 : 16384), (unsigned)(NS / 64));
+      k_normalize_mask_incr<<<grid, NT, 0, ctx->stream>>>(xT, nullptr, ref->d_idx, ref->d_sel, B, ref->k,
+                                                          ipl_for(ref->k), NS, ct, B, tab, stS1, stS2, stN, stM1,
+                                                          nullptr, nullptr, zT, nT);
+      WCX_HIP(hipGetLastError());
+      rc = wcx_norm_rank_mark_launch(rkv, cin, B, NS, n_samples, ctx->stream);   // cin = the copy pass 1 wrote
+      if (rc) return rc;
+      rc = wcx_norm_median_rank_launch(rkv, ref->d_idx, ref->d_sel, xT, B, ref->k, ipl_for(ref->k), NS, n_samples,
+                                       ct, cc, rT, lrT, ctx->stream);
+      if (rc) return rc;
+      const dim3 gt((unsigned)((Bp + 31) / 32), (unsigned)((n_samples + 31) / 32));
+      k_from_sample_minor<<<gt, 256, 0, ctx->stream>>>(zT, ct, Bp, NS, n_samples, d_out_z);
+      k_from_sample_minor<<<gt, 256, 0, ctx->stream>>>(nT, ct, Bp, NS, n_samples, d_out_n);
+      k_from_sample_minor<<<gt, 256, 0, ctx->stream>>>(rT, ct, Bp, NS, n_samples, d_out_r);
+      k_from_sample_minor<<<gt, 256, 0, ctx->stream>>>(lrT, ct, Bp, NS, n_samples, lr);
       WCX_HIP(hipGetLastError());
     } else if (tiled)
       rc = launch_pass_tile<TILE>(ctx, ref, d_x, cin, cout, n_samples, NS, ct, pass == 2, d_out_z,

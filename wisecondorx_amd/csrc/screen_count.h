@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, LBW) void k_screen_count(const CountArgs A) {
     if (A.stats) {                                     // (diagnostics: mean trial chosen, rows without one)
       const bool is_row = hf == 0 && rowj >= 0;
       const int cs = wcx::wave_sum_i(is_row && chosen >= 0 ? chosen : 0), cf = wcx::wave_sum_i(is_row && chosen < 0 ? 1 : 0);
-      if (lane == 0) { atomicAdd(&A.stats[12], (unsigned long long)cs); atomicAdd(&A.stats[13], (unsigned long long)cf); }
+      if (lane == 0) { atomicAdd(&A.stats[16], (unsigned long long)cs); atomicAdd(&A.stats[17], (unsigned long long)cf); }
     }
   }
 }

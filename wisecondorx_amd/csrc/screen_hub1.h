@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, LBW) void k_screen_hub1(const Hub1Args A) {
   if (A.stats && wave_on) {
     const bool is_row = hf == 0 && tvalid;
     const int cs = wcx::wave_sum_i(is_row && have ? chosen : 0), cf = wcx::wave_sum_i(is_row && !have ? 1 : 0);
-    if (lane == 0) { atomicAdd(&A.stats[12], (unsigned long long)cs); atomicAdd(&A.stats[13], (unsigned long long)cf); }
+    if (lane == 0) { atomicAdd(&A.stats[16], (unsigned long long)cs); atomicAdd(&A.stats[17], (unsigned long long)cf); }
   }
 }
 

@@ -230,18 +230,24 @@ __device__ __forceinline__ double wave_select_bucket_at(const double (&v)[IPL], 
   hist[lane] = 0;
   __builtin_amdgcn_wave_barrier();
   int b[IPL];
+  // The two END buckets take everything beyond the grid -- a third of the values when the grid is the
+  // caller's mean +- one standard deviation: as LDS atomics that is a ten-lane conflict on one address in
+  // every instruction.  They are counted by ballots (scalar popcounts) instead; only the inner buckets,
+  // a few values each, go through the atomics.
+  int c_lo = 0, c_hi = 0;
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
-    b[q] = 0;
-    if ((act >> q) & 1u) {
-      int bb = (int)((float)(v[q] - lo) * scale);     // monotone in v
-      bb = bb > 63 ? 63 : (bb < 0 ? 0 : bb);
-      b[q] = bb;
-      atomicAdd(&hist[bb], 1);
-    }
+    b[q] = -1;
+    const bool on = (act >> q) & 1u;
+    int bb = (int)((float)(v[q] - lo) * scale);       // monotone in v
+    bb = bb > 63 ? 63 : (bb < 0 ? 0 : bb);
+    if (on) b[q] = bb;
+    c_lo += __popcll(__ballot(on && bb == 0));
+    c_hi += __popcll(__ballot(on && bb == 63));
+    if (on && bb > 0 && bb < 63) atomicAdd(&hist[bb], 1);
   }
   __builtin_amdgcn_wave_barrier();
-  const int h = hist[lane];
+  const int h = lane == 0 ? c_lo : (lane == 63 ? c_hi : hist[lane]);
   const int cum = wave_incl_scan_i(h);
   const unsigned long long gt = __ballot(cum > rank);
   if (gt == 0ull) return wave_quickselect<IPL>(v, act, rank);   // cannot happen for rank < n

@@ -44,7 +44,7 @@ struct wcx_ctx {
   std::string timer_tag;                  // prefix of the timer names (wcx_timer_tag)
   int debug_flags = 0;                    // diagnostics (wcx_debug_flags): per context
   int64_t topk_stats[4] = {0, 0, 0, 0};
-  unsigned long long *d_stats = nullptr;  // 16 device counters
+  unsigned long long *d_stats = nullptr;  // 32 device counters (wcx_last_topk_stats reports the first 24)
   void *d_small = nullptr;                // 8 KB of persistent device workspace (radix-select state)
   // growable device scratch owned by the context
   void *scratch = nullptr;
@@ -135,6 +135,18 @@ constexpr int WCX_REDO_FAST = 128;  // flagged rows that take the device-wide re
 size_t wcx_topk_redo_scratch_bytes(int k, int64_t B);
 int wcx_host_scratch(wcx_ctx *ctx, size_t bytes, void **out);
 int wcx_aux_kick(wcx_ctx *ctx);   // null_ratios.hip: start pending auxiliary-stream work
+// null_ratios.hip, for the batched normalise (predict.hip): the rows of a row-major [n][B] matrix ranked
+// (n <= 128; pieces Rg[group of 8 rows][bin][8], values by rank V[n][B]) into `base` (wcx_rank_bytes), and
+// the medians of the LAST normalisation pass selected on those ranks.
+struct WcxRankView { unsigned int *Rg; const double *V; int n_sg; };
+struct WcxChrCum { int n_chr; int64_t cum[32]; };
+size_t wcx_rank_bytes(int64_t B, int n);
+int wcx_rank_rows_launch(const double *d_x, int64_t B, int n, char *base, hipStream_t st, WcxRankView *out);
+int wcx_norm_rank_mark_launch(const WcxRankView &rk, const double *copyT, int64_t B, int NS, int n_samples,
+                              hipStream_t st);
+int wcx_norm_median_rank_launch(const WcxRankView &rk, const int32_t *d_idx, const unsigned long long *d_sel,
+                                const double *xT, int64_t B, int k, int ipl, int NS, int n_samples, int64_t ct,
+                                const WcxChrCum &chr, double *rT, double *lrT, hipStream_t st);
 bool wcx_null_ratios_direct_pays(int64_t B, int64_t n_rows);
 void wcx_aux_cancel_if_few_rows(wcx_ctx *ctx, int64_t B, int64_t n_rows);
 int wcx_topk_exact_redo_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,

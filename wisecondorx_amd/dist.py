@@ -262,8 +262,10 @@ class GpuBackend(_GpuPredictMixin):
         from . import _lib
         lib = self.ctx.lib
         ids, ids_p = _lib.i32_array(sample_ids)
-        _lib.check(lib.wcx_newref_sym_finish_dev(self.ctx.h, recv.data_ptr() if recv.shape[0] else None,
-                                                 int(recv.shape[0]), d_idx.data_ptr(), d_dist.data_ptr()))
+        # recv None: the exchange was void (some rank's record pool overflowed): exact redo of the own rows
+        n_recv = -1 if recv is None else int(recv.shape[0])
+        _lib.check(lib.wcx_newref_sym_finish_dev(self.ctx.h, recv.data_ptr() if n_recv > 0 else None,
+                                                 n_recv, d_idx.data_ptr(), d_dist.data_ptr()))
         if row_begin < row_end:
             _lib.check(lib.wcx_null_ratios_dev(self.ctx.h, d_Xs.data_ptr(), B, S, d_idx.data_ptr(), row_begin,
                                                row_end, k, ids_p, len(ids), d_nr.data_ptr()))
@@ -272,7 +274,9 @@ class GpuBackend(_GpuPredictMixin):
 def exchange_records(send, counts, world, group=None):
     """The ONE all-to-all of the row-sharded symmetric sweep: `send` holds this rank's records grouped by
     destination rank ([sum(counts), 4] int32, counts[r] of them for rank r); returns the records the
-    other ranks (and this one) hold for THIS rank's rows.  The counts travel first (world integers)."""
+    other ranks (and this one) hold for THIS rank's rows.  The counts travel first (world integers); a
+    rank whose record pool overflowed sends -1 to everybody, which makes the exchange VOID on every rank
+    alike (returns None: no second collective, each rank redoes its rows exactly)."""
     import torch
     import torch.distributed as dist
     cnt_in = torch.tensor([int(c) for c in counts], dtype=torch.int64)
@@ -285,6 +289,8 @@ def exchange_records(send, counts, world, group=None):
         ci, co = cnt_in.to(send.device), cnt_out.to(send.device)
         _logged("all_to_all_single", 8 * world, True, lambda: dist.all_to_all_single(co, ci, group=group), group)
         cnt_out = co.cpu()
+    if bool((cnt_out < 0).any()) or bool((cnt_in < 0).any()):
+        return None
     n_recv = int(cnt_out.sum())
     split_out, split_in = [int(c) for c in cnt_out], [int(c) for c in cnt_in]
     if host and send.is_cuda:
@@ -336,11 +342,13 @@ def newref_sym_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank
     if counts is None:
         backend.search(Xs, n_rows, S, chr_cum, b, e, k, sample_ids, out[0], out[1], out[2])
         return out[0][:n], out[1][:n], out[2][:n], Xs
-    send = torch.empty((int(sum(counts)), 4), dtype=torch.int32, device=dev)
-    backend.sym_records(send)
+    void = any(c < 0 for c in counts)
+    send = torch.empty((0 if void else int(sum(counts)), 4), dtype=torch.int32, device=dev)
+    if not void:
+        backend.sym_records(send)
     recv = exchange_records(send, counts, world)
     backend.sym_finish(recv, Xs, n_rows, S, chr_cum, b, e, k, sample_ids, out[0], out[1], out[2])
-    newref_sym_sharded.last_records = (int(sum(counts)), int(recv.shape[0]))       # (bench / tests)
+    newref_sym_sharded.last_records = (max(0, int(sum(counts))), -1 if recv is None else int(recv.shape[0]))   # (bench / tests)
     return out[0][:n], out[1][:n], out[2][:n], Xs
 
 
