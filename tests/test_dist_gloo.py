@@ -204,6 +204,8 @@ class OracleSymBackend(OracleBackend):
 def _worker_sym(rank, world, port, X, cum, k, ids, q):
     sys.path.insert(0, ROOT)
     os.environ["WCX_SYM_SHARD_MIN"] = "2"
+    if world == 8:
+        os.environ["WCX_A2A_MAX_RECORDS"] = "7"      # the exchange in several rounds (dist._a2a_max_records)
     import torch
     import torch.distributed as dist
     from wisecondorx_amd import dist as wd

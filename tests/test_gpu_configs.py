@@ -137,10 +137,17 @@ def test_config5_predict_batch_of_96_at_15kb(ref15):
     cache = {}
     cutoff = pt.get_optimal_cutoff(ref, 5, cache)
     z, r, n, mlr, mz = pt.normalize_repeat_batch(xs, ref, cutoff, 0, 0, "", cache)
-    for i in (0, 5, 17, 48, 95):                # batch == single, bit for bit
+    # batch == single: reference-bin counts, ratios (the medians) and their median bit for bit; z to 1e-9
+    # (round 6: a batch's last pass takes mean / sd from incrementally updated sums about the
+    # bin's own value, the one-sample kernel from wave reductions: rounding apart -- largest where the
+    # bin's own value lies many sd off its reference bins, the planted CNVs and the zero stretch;
+    # north_star asks 1e-5 relative, the oracle comparisons below 1e-9)
+    for i in (0, 5, 17, 48, 95):
         z1, r1, n1, mlr1, mz1 = pt.normalize_repeat(xs[i], ref, cutoff, 0, 0, "", cache)
-        assert np.array_equal(z1, z[i], equal_nan=True) and np.array_equal(r1, r[i], equal_nan=True)
-        assert np.array_equal(n1, n[i]) and mlr1 == mlr[i] and mz1 == mz[i]
+        assert np.array_equal(r1, r[i], equal_nan=True)
+        assert np.array_equal(n1, n[i]) and mlr1 == mlr[i]
+        np.testing.assert_allclose(z[i], z1, rtol=1e-9, atol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(mz[i], mz1, rtol=1e-9, atol=1e-12)
     # one whole sample against the NumPy oracle (three dependent passes over all 182 k bins)
     oz, orr, on, omlr, omz = O.normalize_repeat(xs[5], mb, cum, ref["indexes"], ref["distances"],
                                                 cutoff, 0, 0)

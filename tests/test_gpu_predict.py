@@ -58,6 +58,33 @@ def test_batch_equals_single(pt, g_pipe):
         assert np.array_equal(n, nb[i]) and mlr == mlrb[i] and mz == mzb[i]
 
 
+@pytest.mark.parametrize("ns", [40, 131])
+def test_large_batches_equal_single(pt, g_pipe, ns):
+    """Batches of 16 .. 128 samples take the lane-per-sample passes + the rank medians of the last pass
+    (counts and ratios bit-identical to the one-sample path, z to rounding); beyond 128 -- the ranking's
+    limit -- the tiled kernel does the last pass (everything bit-identical).  Masked stretches, a zero
+    stretch and a NaN included."""
+    g = g_pipe
+    ref = ref_dict_from_golden(g)
+    rng = np.random.default_rng(ns)
+    base = np.stack([g["t0_A_x"], g["t1_A_x"], g["t2_A_x"]])
+    xs = base[rng.integers(0, 3, ns)] * (1.0 + 0.03 * rng.standard_normal((ns, base.shape[1])))
+    xs[1, 50:90] = 0.0
+    xs[2, 200:260] *= 1.6
+    xs[3, 7] = np.nan
+    cache = {}
+    cutoff = pt.get_optimal_cutoff(ref, 5, cache)
+    zb, rb, nb, mlrb, mzb = pt.normalize_repeat_batch(xs, ref, cutoff, 0, 0, "", cache)
+    for i in list(range(6)) + [ns - 1]:
+        z, r, n, mlr, mz = pt.normalize_repeat(xs[i], ref, cutoff, 0, 0, "", cache)
+        assert np.array_equal(r, rb[i], equal_nan=True) and np.array_equal(n, nb[i])
+        assert mlr == mlrb[i] or (np.isnan(mlr) and np.isnan(mlrb[i]))
+        if ns > 128:
+            assert np.array_equal(z, zb[i], equal_nan=True) and (mz == mzb[i] or (np.isnan(mz) and np.isnan(mzb[i])))
+        else:
+            np.testing.assert_allclose(zb[i], z, rtol=1e-9, atol=1e-9, equal_nan=True)
+
+
 def test_seeded_k300_vs_oracle(pt):
     """k=300 (8 values per lane), masked bins, degenerate rows."""
     rng = np.random.default_rng(4)

@@ -24,6 +24,7 @@ def _init(port):
     sys.path.insert(0, ROOT)
     os.environ["WCX_FORCE_COLLECTIVES"] = "1"
     os.environ["WCX_SYM_SHARD_MIN"] = "1"
+    os.environ["WCX_A2A_MAX_RECORDS"] = "400000"      # the record exchange of the test problem in several rounds
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -69,9 +70,18 @@ def _worker_autosomal(port, X, cum, k, ids, q):
         be.free_ref(h)
         r4 = (cutoff, z.cpu().numpy().copy(), r.cpu().numpy().copy(), n.cpu().numpy().copy(), mlr, mz)
         log = wd.collective_report()
+        # A record exchange beyond 1 GiB: RCCL 2.26.6 delivers only the first half of a send / receive
+        # pair above 1 GiB (scripts/debug_rccl_a2a.py) -- exchange_records must split it into rounds
+        os.environ["WCX_A2A_MAX_RECORDS"] = str(32 << 20)           # the production value: 512 MiB
+        n_big = 80_000_000                                            # 1.28 GB
+        big = torch.arange(n_big * 4, dtype=torch.int32, device=dev).reshape(n_big, 4)
+        got = wd.exchange_records(big, [n_big], 1)
+        torch.cuda.synchronize()
+        big_ok = bool(torch.equal(got, big))
+        del big, got
         dist.barrier()
         dist.destroy_process_group()
-        q.put(("ok", r1, r2, r3, r4, log))
+        q.put(("ok", r1, r2, r3, r4, log, big_ok))
     except Exception as e:            # (the parent must not wait for its timeout)
         import traceback
         q.put(("error", "{}\n{}".format(e, traceback.format_exc())))
@@ -100,7 +110,8 @@ def test_rccl_world1_autosomal_build_and_sharded_predict():
     X, mbpc, cum = corrected_matrix([7100, 6600, 6100, 5400, 4700, 3901], 256, seed=29)    # 33 801 rows, K = 272
     X = np.asfortranarray(X)
     B, k, ids = cum[-1], 64, [3, 1, 7, 0, 22, 39, 255, 100]
-    r1, r2, r3, r4, log = _spawn(_worker_autosomal, (X, cum, k, ids))
+    r1, r2, r3, r4, log, big_ok = _spawn(_worker_autosomal, (X, cum, k, ids))
+    assert big_ok, "a 1.28 GB record exchange did not arrive intact"
     ei, ed = CO.get_reference_rows_threaded(np.ascontiguousarray(X.T), cum, 0, B, k)
     for tag, (gi, gd) in (("row shards", r1[:2]), ("symmetric shards", r2[:2]), ("gathered tables", r3[:2])):
         bad = np.flatnonzero((gi != ei).any(axis=1) | (gd != ed).any(axis=1))
@@ -124,6 +135,7 @@ def test_rccl_world1_autosomal_build_and_sharded_predict():
     # which collectives RCCL executed (name -> calls): all three kinds must be there
     kinds = {e["op"] for e in log}
     assert {"all_gather_into_tensor", "all_to_all_single", "all_reduce"} <= kinds, log
+    assert sum(1 for e in log if e["op"] == "all_to_all_single") >= 3        # counts + more than one round
     assert all(e["backend"] == "nccl" for e in log)
 
 

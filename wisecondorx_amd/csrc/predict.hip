@@ -64,6 +64,12 @@ __global__ __launch_bounds__(NT) void k_cut_final(double *__restrict__ state, in
   }
 }
 
+// (Round 6, built, measured, removed: partial + final as ONE launch -- every workgroup takes a ticket after
+//  its partial and the last one adds them up -- and the same for the wide nanmedian's histogram + decide
+//  pairs: 10 + 18 launches instead of 20 + 36 per predict.  The device-scope release every workgroup needs
+//  before its ticket (__threadfence: on this multi-XCD part an L2 write-back + invalidate) costs more than
+//  the launches it saves: cut-off 0.73 -> 1.30 ms at 15 kb, the 100 kb step 6.4 -> 7.0 ms.  A kernel
+//  boundary is the cheap device-wide fence here.)
 // out[0] = sum of part_sum, out[1] = sum of part_cnt  (row-sharded cut-off: the host all-reduces)
 __global__ __launch_bounds__(NT) void k_sum_parts(const double *__restrict__ part_sum,
                                                   const double *__restrict__ part_cnt, int nparts,
@@ -410,6 +416,56 @@ __global__ __launch_bounds__(NT) void k_normalize_mask_incr(
     const int64_t own = ce - cs;
     const int64_t len_cd = B - own;
     const double c0 = xT[i * NS + s];
+    if (zT) {
+      // Statistics of the last pass for a bin with FEW selected reference bins (its distances mostly beyond
+      // the cut-off: one or two references are common among them): the updated sums carry the rounding of
+      // everything added and taken away before -- harmless against a variance of hundreds of values, but a
+      // set of one value has variance 0 EXACTLY (z = +-inf, as np.std gives it), not dust.  Such a bin is
+      // small for every sample alike (the selection is per bin): its few rows are walked again, mean and
+      // squared deviations taken directly (copy_out = the masked copy pass 1 wrote).
+      int nsel = 0;
+      for (int q = 0; q < ipl; ++q) {
+        unsigned long long w = sel[i * ipl + q];
+        if (q == ipl - 1 && (k & 63)) w &= (1ull << (k & 63)) - 1ull;
+        nsel += __popcll(w);
+      }
+      nsel = __builtin_amdgcn_readfirstlane(nsel);
+      if (nsel <= 32) {
+        double sum = 0.0, ss = 0.0;
+        int ne = 0;
+        for (int walk = 0; walk < 2; ++walk) {
+          const double mean_e = walk ? sum / (double)ne : 0.0;
+          for (int q = 0; q < ipl; ++q) {
+            const int t = q * 64 + lane;
+            int gv = 0;
+            if (t < k) {
+              int64_t c = idx[i * (int64_t)k + t];
+              if (c < 0) c += len_cd;
+              gv = (int)(c < cs ? c : c + own);
+            }
+            const unsigned long long wv = sel[i * ipl + q];
+            unsigned long long w = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(wv >> 32)) << 32) |
+                                   (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)wv);
+            if (q == ipl - 1 && (k & 63)) w &= (1ull << (k & 63)) - 1ull;
+            while (w) {
+              const int b = __builtin_ctzll(w);
+              w &= w - 1ull;
+              const int g = __builtin_amdgcn_readlane(gv, b);
+              const double v = copy_out[(int64_t)g * NS + s];
+              if (v >= 0.0) {                         // predict_tools.py:134
+                if (walk == 0) { sum += v; ne += 1; }
+                else { const double e = v - mean_e; ss += e * e; }
+              }
+            }
+          }
+        }
+        const double dne = (double)ne;
+        const double mean_e = sum / dne;
+        zT[i * NS + s] = (c0 - mean_e) / sqrt(ss / dne);
+        nT[i * NS + s] = dne;
+        continue;
+      }
+    }
     double S1 = st_S1[i * NS + s], S2 = st_S2[i * NS + s];
     int n = st_n[i * NS + s];
     for (int q = 0; q < ipl; ++q) {
@@ -1400,9 +1456,9 @@ int wcx_predict_normalize_dev(wcx_ctx *ctx, const wcx_ref *ref_c, const double *
       cc.n_chr = tab.n_chr;
       for (int c = 0; c < 32; ++c) cc.cum[c] = tab.cum[c];
       const dim3 grid((unsigned)((Bp + 3) / 4 < 16384 ? (Bp + 3) / 4 : 16384), (unsigned)(NS / 64));
-      k_normalize_mask_incr<<<grid, NT, 0, ctx->stream>>>(xT, nullptr, ref->d_idx, ref->d_sel, B, ref->k,
-                                                          ipl_for(ref->k), NS, ct, B, tab, stS1, stS2, stN, stM1,
-                                                          nullptr, nullptr, zT, nT);
+      k_normalize_mask_incr<<<grid, NT, 0, ctx->stream>>>(xT, const_cast<double *>(cin), ref->d_idx, ref->d_sel, B,
+                                                          ref->k, ipl_for(ref->k), NS, ct, B, tab, stS1, stS2, stN,
+                                                          stM1, nullptr, nullptr, zT, nT);
       WCX_HIP(hipGetLastError());
       rc = wcx_norm_rank_mark_launch(rkv, cin, B, NS, n_samples, ctx->stream);   // cin = the copy pass 1 wrote
       if (rc) return rc;

@@ -271,39 +271,69 @@ class GpuBackend(_GpuPredictMixin):
                                                row_end, k, ids_p, len(ids), d_nr.data_ptr()))
 
 
+def _a2a_max_records():
+    """Most records (16 bytes each) one rank hands ONE peer in one all_to_all_single call.  Measured on the
+    MI355X box (scripts/debug_rccl_a2a.py, RCCL 2.26.6 under torch 2.10): a send / receive pair above 1 GiB
+    delivers only its first half -- silently; up to 1 GiB everything arrives (all_gather_into_tensor has no
+    such limit up to the 3 GiB tried).  The exchange therefore runs in rounds of at most 512 MiB per
+    peer; 8 ranks at 15 kb x 500 need one (22 MB per peer), a one-rank group needs three."""
+    import os
+    return max(1, int(os.environ.get("WCX_A2A_MAX_RECORDS", str(32 << 20))))
+
+
 def exchange_records(send, counts, world, group=None):
     """The ONE all-to-all of the row-sharded symmetric sweep: `send` holds this rank's records grouped by
     destination rank ([sum(counts), 4] int32, counts[r] of them for rank r); returns the records the
-    other ranks (and this one) hold for THIS rank's rows.  The counts travel first (world integers); a
-    rank whose record pool overflowed sends -1 to everybody, which makes the exchange VOID on every rank
-    alike (returns None: no second collective, each rank redoes its rows exactly)."""
+    other ranks (and this one) hold for THIS rank's rows, grouped by source rank.  The counts travel first
+    (two integers per peer: the count for that peer and this rank's largest count, from which every rank
+    derives the same number of ROUNDS -- see _a2a_max_records); a rank whose record pool overflowed sends
+    -1 to everybody, which makes the exchange VOID on every rank alike (returns None: no further
+    collective, each rank redoes its rows exactly)."""
     import torch
     import torch.distributed as dist
-    cnt_in = torch.tensor([int(c) for c in counts], dtype=torch.int64)
-    cnt_out = torch.empty(world, dtype=torch.int64)
+    cnts = [int(c) for c in counts]
+    cmax = max(cnts) if cnts else 0
+    cnt_in2 = torch.tensor([[c, cmax] for c in cnts], dtype=torch.int64)
+    cnt_out2 = torch.empty((world, 2), dtype=torch.int64)
     host = dist.get_backend(group) == "gloo"
     if host:
-        _logged("all_to_all_single", 8 * world, False, lambda: dist.all_to_all_single(cnt_out, cnt_in, group=group),
+        _logged("all_to_all_single", 16 * world, False, lambda: dist.all_to_all_single(cnt_out2, cnt_in2, group=group),
                 group)
     else:
-        ci, co = cnt_in.to(send.device), cnt_out.to(send.device)
-        _logged("all_to_all_single", 8 * world, True, lambda: dist.all_to_all_single(co, ci, group=group), group)
-        cnt_out = co.cpu()
+        ci, co = cnt_in2.to(send.device), cnt_out2.to(send.device)
+        _logged("all_to_all_single", 16 * world, True, lambda: dist.all_to_all_single(co, ci, group=group), group)
+        cnt_out2 = co.cpu()
+    cnt_in, cnt_out = cnt_in2[:, 0], cnt_out2[:, 0]
     if bool((cnt_out < 0).any()) or bool((cnt_in < 0).any()):
         return None
     n_recv = int(cnt_out.sum())
     split_out, split_in = [int(c) for c in cnt_out], [int(c) for c in cnt_in]
-    if host and send.is_cuda:
-        # testing only (ranks sharing one device): gloo exchanges through host memory
-        recv_h = torch.empty((n_recv, 4), dtype=send.dtype)
-        send_h = send.cpu()
-        _logged("all_to_all_single", 16 * int(send.shape[0]), False,
-                lambda: dist.all_to_all_single(recv_h, send_h, split_out, split_in, group=group), group)
-        return recv_h.to(send.device)
-    recv = torch.empty((n_recv, 4), dtype=send.dtype, device=send.device)
-    _logged("all_to_all_single", 16 * int(send.shape[0]), send.is_cuda,
-            lambda: dist.all_to_all_single(recv, send, split_out, split_in, group=group), group)
-    return recv
+    lim = _a2a_max_records()
+    rounds = max(1, -(-int(cnt_out2[:, 1].max()) // lim))          # the same on every rank
+    via_host = host and send.is_cuda       # testing only (ranks sharing one device): gloo exchanges through host memory
+    src = send.cpu() if via_host else send
+    recv = torch.empty((n_recv, 4), dtype=send.dtype, device=src.device)
+
+    def a2a(dst, buf, so, si):
+        _logged("all_to_all_single", 16 * int(buf.shape[0]), buf.is_cuda,
+                lambda: dist.all_to_all_single(dst, buf, so, si, group=group), group)
+    if rounds == 1:
+        a2a(recv, src, split_out, split_in)
+    else:
+        off_in = [0] + list(np.cumsum(split_in))
+        off_out = [0] + list(np.cumsum(split_out))
+        for j in range(rounds):
+            si = [min(max(c - j * lim, 0), lim) for c in split_in]
+            so = [min(max(c - j * lim, 0), lim) for c in split_out]
+            pieces = [src[off_in[r] + j * lim: off_in[r] + j * lim + si[r]] for r in range(world)]
+            buf = pieces[0] if world == 1 else torch.cat(pieces, 0)
+            got = torch.empty((sum(so), 4), dtype=send.dtype, device=src.device)
+            a2a(got, buf.contiguous(), so, si)
+            o = 0
+            for r in range(world):
+                recv[off_out[r] + j * lim: off_out[r] + j * lim + so[r]] = got[o: o + so[r]]
+                o += so[r]
+    return recv.to(send.device) if via_host else recv
 
 
 def newref_sym_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank, world, out=None):
