@@ -402,6 +402,13 @@ int64_t wcx_format_bins_bed(const char *chr_name, int64_t n, int64_t binsize, co
 /* str(float) of n doubles, each followed by `sep`; cap >= 26 n.  Returns the bytes written or -1. */
 int64_t wcx_format_floats(const double *v, int64_t n, char sep, char *out, int64_t cap);
 
+/* Bin counts of a batch of samples laid out over the reference's bins (predict_tools.py:36-44 per sample:
+ * every chromosome truncated or zero-padded to bins_per_chr): src[s * n_chr + c] -> the int32 counts of
+ * chromosome c of sample s, len[s * n_chr + c] of them; out int32[n_samples][sum(bins_per_chr)] (host; pinned
+ * memory makes the upload that follows a true DMA).  Host code, n_threads threads over the samples. */
+int wcx_layout_counts(const int32_t *const *src, const int64_t *len, int n_samples, int n_chr,
+                      const int64_t *bins_per_chr, int32_t *out, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@ SIGNATURES = {
     "wcx_version": (C.c_int, []),
     "wcx_format_bins_bed": (c_i64, [C.c_char_p, c_i64, c_i64, vp, vp, vp, c_i64]),
     "wcx_format_floats": (c_i64, [vp, c_i64, C.c_char, vp, c_i64]),
+    "wcx_layout_counts": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]),
     "wcx_debug_flags": (C.c_int, [vp, C.c_int]),
     "wcx_sweep_event": (C.c_int, [vp, C.POINTER(vp)]),
     "wcx_wait_event": (C.c_int, [vp, vp]),

