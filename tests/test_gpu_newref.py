@@ -77,13 +77,17 @@ def test_empty_row_range(nt):
 
 
 def test_config1_size_properties(nt):
-    """BASELINE config[1] shape (100 kb bins, S=100, k=300): size-independent properties on
-    all rows + bit-exact oracle agreement on a row subsample."""
+    """BASELINE config[1] shape (100 kb bins -- the reference's default bin size, main.py:377-380 --, S=100,
+    k=300): size-independent properties on all rows, EVERY row bit for bit against the tiled C oracle,
+    and the null ratios of a tenth of the rows against the NumPy oracle."""
+    from wisecondorx_amd import _lib
     from wisecondorx_amd.synth import bins_per_chr, corrected_matrix
     bpc = [int(b * 0.93) for b in bins_per_chr(100000)[:22]]
     X, mbpc, cum = corrected_matrix(bpc, 100, seed=11)
     B, k = cum[-1], 300
     idx, dist = nt.get_ref_for_rows(X, cum, k, 0, B)
+    st = _lib.default_context().topk_stats()
+    assert st["rows"] == B and st["fallback_rows"] == 0
     assert (np.diff(dist, axis=1) >= 0).all()                      # ascending
     assert (idx >= 0).all()
     own = np.repeat(np.array(mbpc), np.array(mbpc))
@@ -91,12 +95,37 @@ def test_config1_size_properties(nt):
     srt = np.sort(idx, axis=1)
     assert (np.diff(srt, axis=1) > 0).all()                        # no duplicates
     Xs = np.ascontiguousarray(X.T)
-    rows = np.random.default_rng(0).choice(B, 40, replace=False)
-    for t in rows:
-        c = int(np.searchsorted(cum, t, side="right"))
-        cs = cum[c - 1] if c else 0
-        oi, od = CO.topk_rows(Xs, cs, cum[c], int(t), int(t) + 1, k)
-        assert np.array_equal(idx[t], oi[0]) and np.array_equal(dist[t], od[0])
+    oi, od = CO.get_reference_rows_threaded(Xs, cum, 0, B, k)
+    bad = np.flatnonzero((idx != oi).any(axis=1) | (dist != od).any(axis=1))
+    assert bad.size == 0, "{} of {} rows differ (first {})".format(bad.size, B, bad[:5])
+    ids = [3, 97, 41, 0, 58, 12, 77, 5]
+    for lo in (0, B // 3, B - B // 30):
+        hi = lo + B // 30
+        nr = nt.get_null_ratios(X, idx[lo:hi], lo, hi, ids)
+        with np.errstate(all="ignore"):
+            enr = O.null_ratios(X, oi[lo:hi], lo, hi, ids)
+        np.testing.assert_allclose(nr, enr, rtol=1e-12, atol=1e-13)
+
+
+def test_config1_bench_cohort_all_rows(nt):
+    """What bench.py's `config2_100kb` block runs: the PCA-corrected matrices of the 100-sample cohort at
+    100 kb -- the A pass, every row, and the gonosomal rows of the F and M passes -- through the default
+    policy, bit for bit against the tiled C oracle."""
+    import bench
+    from wisecondorx_amd import _lib
+    passes = bench.make_full_workload(100000, 100)[1]
+    for tag in ("A", "F", "M"):
+        p = passes[tag]
+        X = p["X"]
+        cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
+        B, k = cum[-1], 300
+        r0 = 0 if tag == "A" else cum[21]
+        idx, dist = nt.get_ref_for_rows(X, cum, k, r0, B, mode=0)
+        st = _lib.default_context().topk_stats()
+        assert st["rows"] == B - r0 and st["fallback_rows"] == 0, (tag, st)
+        oi, od = CO.get_reference_rows_threaded(np.ascontiguousarray(np.asarray(X).T), cum, r0, B, k)
+        bad = np.flatnonzero((idx != oi).any(axis=1) | (dist != od).any(axis=1))
+        assert bad.size == 0, "{} pass: {} of {} rows differ (first {})".format(tag, bad.size, B - r0, bad[:5])
 
 
 def test_null_ratio_index_space_quirk(nt):

@@ -745,6 +745,64 @@ __global__ __launch_bounds__(NT) void k_sym_regroup(const uint4 *__restrict__ po
 // exactly the ones the refine needs; else the row is flagged for the exact kernel.
 // IPL = list slots per lane: the lists hold 64 IPL entries (SymArgs::cap2); max_keep = most entries the
 // refine accepts.
+// The cut of ONE row's list by one wave, NQ slices of 64 entries in registers (NQ >= the slices that hold
+// entries).  Round 6: the kernel used to walk all 32 (64) slices of the list's CAPACITY in every one of the
+// ~25 bisection steps -- 800 ballots per row whatever the list held, which is why halving the lists
+// (890 -> 489 entries, round 5) left it at 0.96 ms; a row now pays for the slices it uses (8 at 489 entries).
+template <int NQ>
+__device__ __forceinline__ void sym_final_row(uint2 *__restrict__ row, int c, int k, const RowInfo &ri,
+                                              float e_max, float N_max, float gamma, float dest, int max_keep,
+                                              unsigned int *__restrict__ flag, int *__restrict__ cnt_r) {
+  const int lane = wcx::lane_id();
+  unsigned int key[NQ], idx[NQ];
+  const int nq = (c + 63) >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    uint2 v = make_uint2(0u, 0u);
+    if (q < nq) v = row[q * 64 + lane];
+    key[q] = (q * 64 + lane < c) ? f32_key(__uint_as_float(v.x)) : 0xffffffffu;
+    idx[q] = v.y;
+  }
+  const unsigned int kref = (unsigned int)__builtin_amdgcn_readfirstlane((int)key[0]);
+  unsigned int x = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) x |= (q * 64 + lane < c) ? (key[q] ^ kref) : 0u;
+  x = wcx::wave_or_u32(x);
+  const int hb = 31 - __builtin_clz(x | 1u);
+  unsigned int prefix = kref & ~((2u << hb) - 1u);
+  for (int bit = hb; bit >= 0; --bit) {
+    const unsigned int trial = prefix | (1u << bit);
+    int n_lt = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) n_lt += __popcll(__ballot(key[q] < trial));
+    if (n_lt < k) prefix = trial;
+  }
+  const float tk = key_f32(prefix);
+  float na, E, Q;
+  row_budget(ri, e_max, N_max, gamma, na, E, Q);
+  const float dk = tk > 0.f ? tk : 0.f;
+  const float rt = sqrtf(up(dk + Q)) * 1.0000005f + 2.f * E;
+  const float Fb = up(up(rt * rt) + Q);
+  if (!(Fb <= dest)) {                    // estimate unproven (or NaN): exact kernel
+    if (lane == 0) { *flag = 1u; *cnt_r = 0; }
+    return;
+  }
+  const unsigned int gkey = f32_key(Fb);
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const bool keep = key[q] <= gkey && (q * 64 + lane < c);
+    const unsigned long long m = __ballot(keep);
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) row[pos] = make_uint2(__float_as_uint(key_f32(key[q])), idx[q]);
+    base += __popcll(m);
+  }
+  if (lane == 0) {
+    if (base > max_keep) { *flag = 1u; *cnt_r = 0; }
+    else *cnt_r = base;
+  }
+}
+
 template <int IPL>
 __global__ __launch_bounds__(NT) void k_sym_final(const RowInfo *__restrict__ info,
                                                   const ScreenGlobals *__restrict__ glob,
@@ -766,53 +824,15 @@ __global__ __launch_bounds__(NT) void k_sym_final(const RowInfo *__restrict__ in
       continue;
     }
     uint2 *row = sl + r * (int64_t)CAPL;
-    unsigned int key[IPL], idx[IPL];
-    const int nq = (c + 63) >> 6;             // (wave-uniform: only the slices that hold entries are read)
-#pragma unroll
-    for (int q = 0; q < IPL; ++q) {
-      uint2 v = make_uint2(0u, 0u);
-      if (q < nq) v = row[q * 64 + lane];
-      key[q] = (q * 64 + lane < c) ? f32_key(__uint_as_float(v.x)) : 0xffffffffu;
-      idx[q] = v.y;
-    }
-    const unsigned int kref = (unsigned int)__builtin_amdgcn_readfirstlane((int)key[0]);
-    unsigned int x = 0;
-#pragma unroll
-    for (int q = 0; q < IPL; ++q) x |= (q * 64 + lane < c) ? (key[q] ^ kref) : 0u;
-    x = wcx::wave_or_u32(x);
-    const int hb = 31 - __builtin_clz(x | 1u);
-    unsigned int prefix = kref & ~((2u << hb) - 1u);
-    for (int bit = hb; bit >= 0; --bit) {
-      const unsigned int trial = prefix | (1u << bit);
-      int n_lt = 0;
-#pragma unroll
-      for (int q = 0; q < IPL; ++q) n_lt += __popcll(__ballot(key[q] < trial));
-      if (n_lt < k) prefix = trial;
-    }
-    const float tk = key_f32(prefix);
-    float na, E, Q;
-    row_budget(info[rowpos[r]], e_max, N_max, gamma, na, E, Q);
-    const float dk = tk > 0.f ? tk : 0.f;
-    const float rt = sqrtf(up(dk + Q)) * 1.0000005f + 2.f * E;
-    const float Fb = up(up(rt * rt) + Q);
-    if (!(Fb <= Dest[r])) {                 // estimate unproven (or NaN): exact kernel
-      if (lane == 0) { flags[r] = 1u; cnt[r] = 0; }
-      continue;
-    }
-    const unsigned int gkey = f32_key(Fb);
-    int base = 0;
-#pragma unroll
-    for (int q = 0; q < IPL; ++q) {
-      const bool keep = key[q] <= gkey && (q * 64 + lane < c);
-      const unsigned long long m = __ballot(keep);
-      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (keep) row[pos] = make_uint2(__float_as_uint(key_f32(key[q])), idx[q]);
-      base += __popcll(m);
-    }
-    if (lane == 0) {
-      if (base > max_keep) { flags[r] = 1u; cnt[r] = 0; }
-      else cnt[r] = base;
-    }
+    const RowInfo ri = info[rowpos[r]];
+    const float dest = Dest[r];
+    // (wave-uniform: c is the row's count)
+    if (c <= 64 * 8 && IPL >= 8)
+      sym_final_row<8>(row, c, k, ri, e_max, N_max, gamma, dest, max_keep, &flags[r], &cnt[r]);
+    else if (c <= 64 * 16 && IPL >= 16)
+      sym_final_row<16>(row, c, k, ri, e_max, N_max, gamma, dest, max_keep, &flags[r], &cnt[r]);
+    else
+      sym_final_row<IPL>(row, c, k, ri, e_max, N_max, gamma, dest, max_keep, &flags[r], &cnt[r]);
   }
 }
 
