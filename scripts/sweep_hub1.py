@@ -24,7 +24,8 @@ VARIANTS = [
     ("hub f32", {"WCX_HUB_FRAC": "32"}),
     ("hub f64", {"WCX_HUB_FRAC": "64"}),
 ]
-KEYS = ("WCX_SCREEN_HUB", "WCX_HUB_FRAC", "WCX_HUB1_TRIALS", "WCX_HUB_N1")
+KEYS = ("WCX_SCREEN_HUB", "WCX_HUB_FRAC", "WCX_HUB1_TRIALS", "WCX_HUB_N1", "WCX_SCREEN_SEGMENTS_SMALL",
+        "WCX_SCREEN_CHUNK_KB_SMALL")
 
 
 def run(tag, X, cum, k, r0, r1, variants, reps=4):
@@ -79,7 +80,14 @@ def main():
             p = passes[tag]
             cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
             res += run("15kb x500 " + tag, p["X"], cum, 300, cum[21], cum[-1],
-                       VARIANTS[:2] + [VARIANTS[3], VARIANTS[6], ("hub t4", {"WCX_HUB1_TRIALS": "4"})])
+                       VARIANTS[:2] + [VARIANTS[3], VARIANTS[6], ("hub t4", {"WCX_HUB1_TRIALS": "4"}),
+                                       ("hub seg2", {"WCX_SCREEN_SEGMENTS_SMALL": "2"}),
+                                       ("hub seg5", {"WCX_SCREEN_SEGMENTS_SMALL": "5"}),
+                                       ("hub seg6", {"WCX_SCREEN_SEGMENTS_SMALL": "6"}),
+                                       ("hub seg8", {"WCX_SCREEN_SEGMENTS_SMALL": "8"}),
+                                       ("hub seg8 c48", {"WCX_SCREEN_SEGMENTS_SMALL": "8", "WCX_SCREEN_CHUNK_KB_SMALL": "49152"}),
+                                       ("hub c48", {"WCX_SCREEN_CHUNK_KB_SMALL": "49152"}),
+                                       ("hub c12", {"WCX_SCREEN_CHUNK_KB_SMALL": "12288"})])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "sweep_hub1.json"), "w"), indent=1)
 

@@ -147,6 +147,9 @@ constexpr int NBUCKET = 128;            // norm buckets: float bits >> 20 (12.5 
 constexpr int NCELL = NBUCKET * 32;     // (bucket, chromosome) cells
 
 constexpr int HUB_BINS = 65536;          // histogram of (float bits of |a|^2) >> 16: 0.8 % steps in norm
+// (Round 6: four threads per row -- sample j goes to thread j mod 4 -- and a fixed-order sum of the four
+//  partials: one thread per row walked S strided loads in a chain and left two thirds of the chip idle,
+//  0.31 ms for the 192 k x 250 matrix of a gonosomal pass.  The sum order is fixed: deterministic.)
 __global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xs, int64_t B, int S,
                                                  int Sp, const double *__restrict__ cmean,
                                                  ChrTab chr, ScreenGlobals *__restrict__ glob,
@@ -154,13 +157,26 @@ __global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xs, 
                                                  int *__restrict__ rchr,
                                                  unsigned int *__restrict__ rfine = nullptr,
                                                  int *__restrict__ hubhist = nullptr) {
-  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (b >= B) return;
+  __shared__ float part[4][64];
+  const int rl = threadIdx.x & 63, qq = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 64 + rl;
   float s = 0.f;
-  for (int j = 0; j < S; ++j) {
-    const float a = (float)(Xs[(int64_t)j * B + b] - cmean[j]);   // sample-major: coalesced
-    s += a * a;
+  if (b < B) {
+    float s0 = 0.f, s1 = 0.f;
+    int j = qq;
+    for (; j + 4 < S; j += 8) {                                   // two independent chains
+      const float a0 = (float)(Xs[(int64_t)j * B + b] - cmean[j]);   // sample-major: coalesced
+      const float a1 = (float)(Xs[(int64_t)(j + 4) * B + b] - cmean[j + 4]);
+      s0 += a0 * a0;
+      s1 += a1 * a1;
+    }
+    if (j < S) { const float a0 = (float)(Xs[(int64_t)j * B + b] - cmean[j]); s0 += a0 * a0; }
+    s = s0 + s1;
   }
+  part[qq][rl] = s;
+  __syncthreads();
+  if (qq != 0 || b >= B) return;
+  s = (part[0][rl] + part[1][rl]) + (part[2][rl] + part[3][rl]);
   int c = 0;
   while (c < chr.n_chr - 1 && b >= chr.cum[c]) ++c;
   rchr[b] = c;
@@ -1213,10 +1229,10 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   const unsigned gb = (unsigned)((B + NT - 1) / NT);
   if (use_hub) {
     WCX_HIP(hipMemsetAsync(hubhist, 0, (size_t)HUB_BINS * 4, st));
-    k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr, rfine, hubhist);
+    k_row_norm<<<(unsigned)((B + 63) / 64), NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr, rfine, hubhist);
     k_hub_cut<<<1, 1024, 0, st>>>(hubhist, (int)hub_rows, glob);
   } else {
-    k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
+    k_row_norm<<<(unsigned)((B + 63) / 64), NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
   }
   // order B: (hub region | the rest) x (norm class, chromosome) cells padded to tiles
   WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
@@ -1599,7 +1615,14 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // ... except for very small shards: the gonosomal passes search ~80-100 blocks of chrX / chrY
   // rows on 512 slots; 1 / 2 / 4 segments: F pass 7.7 / 6.8 / 6.4 ms, M pass 8.8 / 7.6 / 7.4 ms
   // (15 kb, 250 samples each, profiles/r03)
-  if ((int)blocks.size() * 4 <= slots) n_seg = env_int("WCX_SCREEN_SEGMENTS_SMALL", 4);
+  // Round 6 (hub-count thresholds: the segments' lists are short, the merge cheap): as many segments as fill
+  // ONE round of workgroup slots -- F pass, 77 blocks: 4 / 5 / 6 / 8 segments = screen 1.77 / 1.65 / 1.60 /
+  // 1.95 ms; M pass, 97 blocks: 4 / 5 / 6 = 2.13 / 1.95 / 2.50 (6 x 97 > 512 slots: a second round)
+  if ((int)blocks.size() * 4 <= slots) {
+    int fill = slots / (int)blocks.size();
+    if (fill > 8) fill = 8;
+    n_seg = env_int("WCX_SCREEN_SEGMENTS_SMALL", fill);
+  }
   n_seg = env_int("WCX_SCREEN_SEGMENTS", n_seg);
   if (n_seg < 1) n_seg = 1;
   if (n_seg > 8) n_seg = 8;
@@ -1768,12 +1791,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       unsigned int *rfine = reinterpret_cast<unsigned int *>(base + o_rfin);
       int *hubhist = reinterpret_cast<int *>(base + o_hubh);
       WCX_HIP(hipMemsetAsync(hubhist, 0, (size_t)HUB_BINS * 4, st));
-      k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr, rfine, hubhist);
+      k_row_norm<<<(unsigned)((B + 63) / 64), NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr, rfine, hubhist);
       k_hub_cut<<<1, 1024, 0, st>>>(hubhist, (int)hub_rows1, glob);
       k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, 0, 0, glob, rkey, cellcnt, nullptr, rfine);
       k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, 0, nullptr, glob);
     } else {
-      k_row_norm<<<gb, NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
+      k_row_norm<<<(unsigned)((B + 63) / 64), NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
       k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, SF, n_seg > 1 ? 1 : 0, glob, rkey, cellcnt);
       k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, (int)(P_s - n_s));
     }
