@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 vector == matrix (not in the guide)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA
 SPINUP_STEPS = int(os.environ.get("WCX_BENCH_SPINUP_STEPS", "0"))   # extra untimed steps (0: only --warmup)
-TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", r_, "screen_traffic.json") for r_ in ("r05", "r04")]
+TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", r_, "screen_traffic.json") for r_ in ("r06", "r05", "r04")]
 SIMD_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: 2.4 GHz peak engine clock (1 024 SIMDs)
 
 

@@ -374,7 +374,9 @@ int wcx_set_null_matrix(wcx_ctx *ctx, const double *nr, int64_t n_bins, int m);
  * wcx_null_ratios_dev): inflated to n_bins rows on the device with the reference's mask
  * (mask[n_bins] host bytes, B of them non-zero; masked-out rows = 0, predict_tools.py:163-170).
  * Asynchronous on the context's stream: the bin -> row map is kept per mask, so only the first
- * call with a mask uploads anything and waits; `mask` is read before the call returns. */
+ * call with a mask uploads anything and waits; `mask` is read before the call returns; d_nr is read BY
+ * THE STREAM: it must stay valid (and unmodified by other streams) until the context's stream has passed
+ * this call. */
 int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
                             const unsigned char *mask, int64_t n_bins);
 int wcx_segment_z(wcx_ctx *ctx, const double *r, const double *w, const double *nr, int m,

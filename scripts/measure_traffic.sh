@@ -2,7 +2,7 @@
 # usage (on the GPU box): bash scripts/measure_traffic.sh  -- rocprofv3 evidence of the default bench
 # workloads (S=500 and S=100): kernel-trace stats + SQ / FETCH_SIZE / WRITE_SIZE counters of the screen
 # kernel, each counter group in its own pass (no trace domains mixed with --pmc).
-ROUND=${WCX_PROF_ROUND:-r05}
+ROUND=${WCX_PROF_ROUND:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$ROUND
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

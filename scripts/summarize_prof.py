@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<round> (scripts/measure_traffic.sh) into profiles/<round>/ (round = $WCX_PROF_ROUND, default r05):
+"""Condense gpurun_out/prof_<round> (scripts/measure_traffic.sh) into profiles/<round>/ (round = $WCX_PROF_ROUND, default r06):
   kernel_stats_S<S>.csv     rocprofv3 --kernel-trace --stats summary of the bench command
   pmc_S<S>.csv              per-kernel sums of every counter (all PMC passes) + dispatch counts
   screen_traffic.json       per-sweep HBM bytes and SQ breakdown of k_screen, keyed by workload, with
@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = os.environ.get("WCX_PROF_ROUND", "r05")
+ROUND = os.environ.get("WCX_PROF_ROUND", "r06")
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
 
@@ -63,6 +63,11 @@ def main():
                         name = "k_screen_sym"       # the symmetric sweep of the autosomal pass (one launch)
                     elif "k_screen_count<" in r["Kernel_Name"]:
                         name = "k_screen_count"     # its thresholds: counts over the hub region
+                    elif "k_screen_hub1<" in r["Kernel_Name"]:
+                        import re
+                        nk = int(re.search(r"k_screen_hub1<(\d+)", r["Kernel_Name"]).group(1))
+                        # thresholds of the one-directional sweep (round 6): the A pass's at S = 100
+                        name = "k_screen_hub1" if nk == (32 if S == 500 else 7) else "k_screen_hub1 (gonosomal passes)"
                     elif "k_screen<" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]:
                         # the step runs three passes: the autosomal one (all S samples: the largest
                         # NK of the run) is the dominant kernel, the two gonosomal ones (S / 2
@@ -86,13 +91,14 @@ def main():
         p = collections.defaultdict(float)
         # (with hub-count thresholds the sampled pre-pass k_screen only runs behind a gate that stays
         #  closed: its launches return at once and are counted with the sweep all the same)
-        for part in (("k_screen", "k_screen_count", "k_screen_sym") if sym else ("k_screen",)):
+        for part in (("k_screen", "k_screen_count", "k_screen_sym") if sym else ("k_screen", "k_screen_hub1")):
             for c_, v_ in agg[part].items():
                 p[c_] += v_
         wave = p.get("SQ_WAVE_CYCLES", 0.0)
         out["workloads"]["S%d" % S] = {
             "kernels": ("k_screen_count (hub-count thresholds) + k_screen_sym (+ the gated second attempt's "
-                        "empty launches)" if hub else "k_screen (sampled pre-pass) + k_screen_sym") if sym else "k_screen",
+                        "empty launches)" if hub else "k_screen (sampled pre-pass) + k_screen_sym") if sym else
+                       ("k_screen_hub1 (hub-count thresholds) + k_screen" if "k_screen_hub1" in agg else "k_screen"),
             "launches_per_sweep": (len(disp[("k_screen", 1)]) + len(disp[("k_screen_sym", 1)]) +
                                    len(disp[("k_screen_count", 1)])) / sweeps,
             "fetch_bytes_per_sweep_raw": p.get("FETCH_SIZE", 0.0) * 1024 / sweeps,

@@ -169,7 +169,12 @@ int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
       return WCX_ERR_NOMEM;
     }
   }
-  if (!(ctx->d_nullsrc && ctx->nullsrc_bins == n_bins && ctx->nullsrc_hash == h)) {
+  // (a hash hit is confirmed on the mask itself: n_bins bytes of memcmp against the kept copy -- a
+  //  collision would misplace null rows silently)
+  const bool same_mask = ctx->d_nullsrc && ctx->nullsrc_bins == n_bins && ctx->nullsrc_hash == h &&
+                         ctx->nullsrc_mask.size() == (size_t)n_bins &&
+                         memcmp(ctx->nullsrc_mask.data(), mask, (size_t)n_bins) == 0;
+  if (!same_mask) {
     std::vector<int32_t> src((size_t)n_bins, -1);
     int64_t j = 0;
     for (int64_t i = 0; i < n_bins; ++i)
@@ -187,6 +192,7 @@ int wcx_set_null_matrix_dev(wcx_ctx *ctx, const double *d_nr, int64_t B, int m,
     WCX_HIP(hipStreamSynchronize(ctx->stream));   // (src is a host temporary)
     ctx->nullsrc_bins = n_bins;
     ctx->nullsrc_hash = h;
+    ctx->nullsrc_mask.assign(mask, mask + n_bins);
   }
   k_inflate_rows<<<(unsigned)(n_bins < 65536 ? n_bins : 65536), 128, 0, ctx->stream>>>(
       d_nr, ctx->d_nullsrc, n_bins, m, ctx->d_nullm);

@@ -65,6 +65,7 @@ struct wcx_ctx {
   int32_t *d_nullsrc = nullptr;     // bin -> row of the masked table (-1: masked out), kept per mask
   int64_t nullsrc_bins = 0;
   unsigned long long nullsrc_hash = 0;
+  std::vector<unsigned char> nullsrc_mask;   // the mask the map was built from (compared on a hash hit)
   // null-sample ranking done ahead on an auxiliary stream (wcx_null_rank_prepare_dev)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_main = nullptr, ev_rank = nullptr;

@@ -365,30 +365,36 @@ def _newref_body(args, contexts, rd):
             dc.close()
             contexts[0].lib.wcx_pca_end(contexts[0].h)
             contexts[0].release_buffers()
+    # Mask skew is judged by EVERY rank (each prepared every pass itself, so each holds the three masks): a
+    # refused reference ends all ranks with the same exit status, not rank 0 alone.
+    n_aut = int(np.sum(final_ref["bins_per_chr"]))
+    skewed = []
+    for ap in (".F", ".M"):
+        if "mask" + ap in final_ref and not np.array_equal(final_ref["mask" + ap][:n_aut],
+                                                           final_ref["mask"]):
+            # the reference has the same latent skew as upstream's (newref_control.py:51-54 mutates
+            # the shared mask after the A pass kept its copy) and cannot be aligned at predict time
+            skewed.append("the PCA-distance filter of the {} pass dropped {} autosomal bin(s) the "
+                          "autosomal reference still holds".format(
+                              ap[1:], int(np.sum(final_ref["mask"]) -
+                                          np.sum(final_ref["mask" + ap][:n_aut]))))
+    refuse = bool(skewed) and not getattr(args, "reference_mask_skew", False)
     if rank != 0:
         qc_pool.shutdown(wait=False)
+        if refuse:
+            sys.exit(1)
         return                      # rank 0 holds the gathered tables and writes the file
     closing = None
     try:
         final_ref["is_nipt"] = args.nipt
         final_ref["trained_cutoff"] = trained_cutoff
-        n_aut = int(np.sum(final_ref["bins_per_chr"]))
-        skewed = []
-        for ap in (".F", ".M"):
-            if "mask" + ap in final_ref and not np.array_equal(final_ref["mask" + ap][:n_aut],
-                                                               final_ref["mask"]):
-                # the reference has the same latent skew as upstream's (newref_control.py:51-54 mutates
-                # the shared mask after the A pass kept its copy) and cannot be aligned at predict time
-                skewed.append("the PCA-distance filter of the {} pass dropped {} autosomal bin(s) the "
-                              "autosomal reference still holds".format(
-                                  ap[1:], int(np.sum(final_ref["mask"]) -
-                                              np.sum(final_ref["mask" + ap][:n_aut]))))
-        if skewed and getattr(args, "reference_mask_skew", False):
+        if skewed and not refuse:
             logging.warning("{} (upstream behaviour, kept on request): predict cannot use this "
                             "reference -- rebuild with --aligned-masks".format("; ".join(skewed)))
         elif skewed:
             # upstream writes such a reference and its predict then dies with an IndexError
             # (predict_control.py:50, tests/golden/mask_skew.npz); an unusable file is not written here
+            # (a deliberate deviation from upstream's CLI, which exits 0 with the unusable file)
             logging.critical("{}: no predict can use such a reference (upstream's raises IndexError at "
                              "predict_control.py:50), so it is NOT written.  Rebuild with --aligned-masks "
                              "(keeps the autosomal masks of the three passes equal), or with "
@@ -700,8 +706,8 @@ def build_parser():
                         "the autosomal reference still holds -- no predict can use such a reference, so "
                         "newref then stops with an error instead of writing it")
     p.add_argument("--reference-mask-skew", action="store_true",
-                   help="(deprecated) write the reference even when the gonosomal passes dropped "
-                        "autosomal bins, exactly as upstream does; predict will refuse it")
+                   help="write the reference even when the gonosomal passes dropped autosomal bins, "
+                        "exactly as upstream does (its predict then fails on it; ours refuses it)")
     p.set_defaults(func=tool_newref)
 
     p = sub.add_parser("gender", description="Returns the gender of a .npz resulting from convert",
