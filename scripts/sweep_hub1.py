@@ -25,7 +25,7 @@ VARIANTS = [
     ("hub f64", {"WCX_HUB_FRAC": "64"}),
 ]
 KEYS = ("WCX_SCREEN_HUB", "WCX_HUB_FRAC", "WCX_HUB1_TRIALS", "WCX_HUB_N1", "WCX_SCREEN_SEGMENTS_SMALL",
-        "WCX_SCREEN_CHUNK_KB_SMALL")
+        "WCX_SCREEN_CHUNK_KB_SMALL", "WCX_SCREEN_TILE", "WCX_SCREEN_SEGMENTS")
 
 
 def run(tag, X, cum, k, r0, r1, variants, reps=4):
@@ -68,12 +68,16 @@ def main():
         p = bench.make_full_workload(100000, 100)[1]["A"]
         cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
         res += run("100kb x100 A", p["X"], cum, 300, 0, cum[-1], VARIANTS[:3] + [
-            ("hub t4", {"WCX_HUB1_TRIALS": "4"})])
+            ("hub t4", {"WCX_HUB1_TRIALS": "4"}), ("hub tt2", {"WCX_SCREEN_TILE": "2,2,4,2,3"}),
+            ("hub seg2", {"WCX_SCREEN_SEGMENTS": "2"}), ("hub seg3", {"WCX_SCREEN_SEGMENTS": "3"}),
+            ("hub tt2 seg6", {"WCX_SCREEN_TILE": "2,2,4,2,3", "WCX_SCREEN_SEGMENTS": "6"}),
+            ("hub tt2 seg3", {"WCX_SCREEN_TILE": "2,2,4,2,3", "WCX_SCREEN_SEGMENTS": "3"})])
     if "S100" in which:
         p = bench.make_full_workload(15000, 100)[1]["A"]
         cum = [int(v) for v in p["masked_bins_per_chr_cum"]]
         res += run("15kb x100 A", p["X"], cum, 300, 0, cum[-1], VARIANTS + [
-            ("hub t8", {"WCX_HUB1_TRIALS": "8"})])
+            ("hub t8", {"WCX_HUB1_TRIALS": "8"}), ("hub tt2", {"WCX_SCREEN_TILE": "2,2,4,2,3"}),
+            ("sampled tt2", {"WCX_SCREEN_HUB": "0", "WCX_SCREEN_TILE": "2,2,4,2,3"})])
     if "FM" in which:
         passes = bench.make_full_workload(15000, 500)[1]
         for tag in ("F", "M"):

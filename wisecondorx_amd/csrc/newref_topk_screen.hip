@@ -1575,8 +1575,8 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   int64_t P_s = (n_s + CT - 1) / CT * CT;                     // positions of the sample region
   int64_t Bpad = P_s + ((B - n_s) + CT - 1) / CT * CT;
   // regroup the searched row ranges into workgroups of <= TGT_WG rows (same chromosome)
-  std::vector<ScreenBlock> blocks;
-  {
+  auto make_blocks = [&](int max_rows) {
+    std::vector<ScreenBlock> out;
     size_t i = 0;
     while (i < exact_blocks.size()) {
       ScreenBlock sb;
@@ -1589,15 +1589,28 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
       sb.ce = exact_blocks[i].ce;
       size_t j = i + 1;
       while (j < exact_blocks.size() && exact_blocks[j].cs == sb.cs &&
-             exact_blocks[j].row0 == sb.row0 + sb.nrows && sb.nrows + exact_blocks[j].nrows <= TGT_WG) {
+             exact_blocks[j].row0 == sb.row0 + sb.nrows && sb.nrows + exact_blocks[j].nrows <= max_rows) {
         sb.nrows += exact_blocks[j].nrows;
         ++j;
       }
-      blocks.push_back(sb);
+      out.push_back(sb);
       i = j;
     }
-  }
+    return out;
+  };
+  const std::vector<ScreenBlock> blocks = make_blocks(TGT_WG);
   int64_t n_iter_groups = Bpad / GRr;
+  // Hub-count thresholds (decided further down, needed here for the segment rule): see use_hub1
+  const int need1 = (int)(1.18 * k) + 8;
+  const int hub_frac1 = env_int("WCX_HUB_FRAC", NK >= 16 ? 32 : 12);
+  int64_t hub_rows1 = hub_frac1 > 1 ? B / hub_frac1 : 0;
+  if (hub_rows1 < 8 * (int64_t)need1 + 512) hub_rows1 = 8 * (int64_t)need1 + 512;
+  auto hub1_possible = [&]() {
+    // (an explicit sampling rate / sample rank asks for the sampled pre-pass: tests of that path)
+    const int hub1_dflt = (getenv("WCX_SCREEN_SAMPLE") || getenv("WCX_SCREEN_CUT_R")) ? 0 : 1;
+    return env_int("WCX_SCREEN_HUB", hub1_dflt) != 0 && NK >= 5 && hub_frac1 > 1 && hub_rows1 * 6 <= B &&
+           cfg.wpb == 4 && cfg.ring >= 2;
+  };
   // Candidate segments fill the chip when a row shard has few target blocks (multi-GPU builds)
   // and even out the last round of workgroups: work items = blocks x segments.
   int hw_cus = 256;
@@ -1618,7 +1631,10 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // Round 6 (hub-count thresholds: the segments' lists are short, the merge cheap): as many segments as fill
   // ONE round of workgroup slots -- F pass, 77 blocks: 4 / 5 / 6 / 8 segments = screen 1.77 / 1.65 / 1.60 /
   // 1.95 ms; M pass, 97 blocks: 4 / 5 / 6 = 2.13 / 1.95 / 2.50 (6 x 97 > 512 slots: a second round)
-  if ((int)blocks.size() * 4 <= slots) {
+  // (with hub-count thresholds already from half a round on: 100 kb x 100, 213 blocks on 768 slots, 1 / 2 / 3
+  //  segments = sweep 1.27 / 1.02 / 0.94 ms; with the sampled pre-pass segments made that shape slower, round 5)
+  const bool hub1_ahead = hub1_possible();
+  if ((int)blocks.size() * (hub1_ahead ? 2 : 4) <= slots) {
     int fill = slots / (int)blocks.size();
     if (fill > 8) fill = 8;
     n_seg = env_int("WCX_SCREEN_SEGMENTS_SMALL", fill);
@@ -1682,14 +1698,11 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   // of the sweep order is then the hub region -- 1 / WCX_HUB_FRAC of the rows, at least 8 x the entries
   // wanted below an estimate + the 512 candidates of the moment phase -- whose size only the device knows:
   // the host sizes everything for the bound (one more group of padding at most).  WCX_SCREEN_HUB=0: off.
-  const int need1 = (int)(1.18 * k) + 8;
-  const int hub_frac1 = env_int("WCX_HUB_FRAC", NK >= 16 ? 32 : 12);
-  int64_t hub_rows1 = hub_frac1 > 1 ? B / hub_frac1 : 0;
-  if (hub_rows1 < 8 * (int64_t)need1 + 512) hub_rows1 = 8 * (int64_t)need1 + 512;
-  // (an explicit sampling rate / sample rank asks for the sampled pre-pass: tests of that path)
-  const int hub1_dflt = (getenv("WCX_SCREEN_SAMPLE") || getenv("WCX_SCREEN_CUT_R")) ? 0 : 1;
-  const bool use_hub1 = env_int("WCX_SCREEN_HUB", hub1_dflt) != 0 && NK >= 5 && hub_frac1 > 1 && hub_rows1 * 6 <= B &&
-                        cfg.tt == 1 && cfg.wpb == 4 && cfg.ring >= 2;
+  const bool use_hub1 = hub1_ahead && k <= KMAX_ONE_DIR;
+  // (the count pass always runs 128-row blocks in its own configuration; a sweep with two target tiles per
+  //  wave -- WCX_SCREEN_TILE, experiments -- gets its own block list)
+  std::vector<ScreenBlock> hub_blocks;
+  if (use_hub1 && TGT_WG != 128) hub_blocks = make_blocks(128);
   if (use_hub1) {
     SF = 0;
     n_s = 0;
@@ -1724,6 +1737,7 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   const size_t o_flag = carve((size_t)n_seg * n_rows * 4);
   const size_t o_srch = carve((size_t)n_rows);
   const size_t o_blk = carve(blocks.size() * sizeof(ScreenBlock));
+  const size_t o_hblk = carve(hub_blocks.size() * sizeof(ScreenBlock));
   const size_t o_redo = carve((size_t)n_rows * sizeof(TopkBlock));
   const size_t o_nredo = carve(512);                                   // counters, see k_collect_redo
   const size_t o_rtile = carve(((size_t)n_rows / 64 + 64) * sizeof(TopkBlock));
@@ -1862,30 +1876,46 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   if (use_hub1) {
     rc = wcx_timer_begin(ctx, "topk_pre");
     if (rc) return rc;
+    // its own configuration (the default rule for this K), whatever tile the sweep was asked to use
+    ScreenCfg hc;
+    hc.nk = NK; hc.tt = 1; hc.wpb = 4; hc.prof = 0;
+    if (NK <= 8) { hc.ctg = 2; hc.lb = 3; hc.ring = 3; }
+    else if (NK <= 32) { hc.ctg = NK <= 16 ? 2 : 1; hc.lb = 2; hc.ring = 2; }
+    else { hc.ctg = 1; hc.lb = 1; hc.ring = 2; }
+    const ScreenBlock *d_hblocks = d_blocks;
+    size_t n_hblocks = blocks.size();
+    if (!hub_blocks.empty()) {
+      ScreenBlock *dh = reinterpret_cast<ScreenBlock *>(base + o_hblk);
+      rc = wcx_upload_small(ctx, dh, hub_blocks.data(), hub_blocks.size() * sizeof(ScreenBlock));
+      if (rc) return rc;
+      d_hblocks = dh;
+      n_hblocks = hub_blocks.size();
+    }
     Hub1Args ha;
-    ha.F = F; ha.glob = glob; ha.perm = perm; ha.rowpos = rowpos; ha.gmask = gmask; ha.blocks = d_blocks;
+    ha.F = F; ha.glob = glob; ha.perm = perm; ha.rowpos = rowpos; ha.gmask = gmask; ha.blocks = d_hblocks;
     ha.g_state = g_state; ha.cnt = cnt_out; ha.stats = ctx->d_stats; ha.row_begin = row_begin;
     ha.n_rows_all = n_rows; ha.n_seg = n_seg; ha.need = env_int("WCX_HUB_TEST_FAIL", 0) ? (1 << 28) : need1;
     ha.n1 = env_int("WCX_HUB_N1", 16);
     // the visit list holds the hub groups: room for twice the rows asked for (the quantile takes a whole
     // histogram bin); a bigger region is cut off there by the kernel
-    int64_t cap_g = (hub_rows1 * 2 + GRr - 1) / GRr + 2;
-    if (cap_g > n_iter_groups) cap_g = n_iter_groups;
+    const int hGR = hc.ctg * 32;
+    int64_t cap_g = (hub_rows1 * 2 + hGR - 1) / hGR + 2;
+    if (cap_g > Bpad / hGR) cap_g = Bpad / hGR;
     if (cap_g > 8192) cap_g = 8192;
     ha.glist_cap = (int)cap_g + 64;
-    const size_t lds_h = (size_t)cfg.ring * (size_t)(CTG * NK * 64) * 16 + (size_t)ha.glist_cap * 4;
+    const size_t lds_h = (size_t)hc.ring * (size_t)(hc.ctg * NK * 64) * 16 + (size_t)ha.glist_cap * 4;
     // (trial thresholds per row: eight are a finer ladder -- fewer rows whose estimate overshoots into an
     //  in-sweep cut -- but cost the count pass 2 x 8 vector instructions per output, which at K <= 128 and
     //  more than a round of workgroups is what bounds it: 15 kb x 100: 4 / 8 trials = pass 1.24 / 1.91 ms,
     //  sweep total 11.59 / 11.89; 100 kb x 100, 213 workgroups: 1.63 / 1.36 ms)
-    const int trials = env_int("WCX_HUB1_TRIALS", (NK >= 16 || (int)blocks.size() <= slots) ? 8 : 4);
-    int e = wcx_hub1_launch_k1(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
-    if (e < 0) e = wcx_hub1_launch_k2(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
-    if (e < 0) e = wcx_hub1_launch_k3(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
-    if (e < 0) e = wcx_hub1_launch_k4(NK, CTG, cfg.lb, cfg.ring, trials, ha, (unsigned)blocks.size(), lds_h, st);
+    const int trials = env_int("WCX_HUB1_TRIALS", (NK >= 16 || (int)n_hblocks <= hw_cus * hc.lb) ? 8 : 4);
+    int e = wcx_hub1_launch_k1(NK, hc.ctg, hc.lb, hc.ring, trials, ha, (unsigned)n_hblocks, lds_h, st);
+    if (e < 0) e = wcx_hub1_launch_k2(NK, hc.ctg, hc.lb, hc.ring, trials, ha, (unsigned)n_hblocks, lds_h, st);
+    if (e < 0) e = wcx_hub1_launch_k3(NK, hc.ctg, hc.lb, hc.ring, trials, ha, (unsigned)n_hblocks, lds_h, st);
+    if (e < 0) e = wcx_hub1_launch_k4(NK, hc.ctg, hc.lb, hc.ring, trials, ha, (unsigned)n_hblocks, lds_h, st);
     if (e < 0) {
       wcx_set_error("hub-count kernel (one-directional) nk=%d ctg=%d lb=%d ring=%d trials=%d is not instantiated",
-                    NK, CTG, cfg.lb, cfg.ring, trials);
+                    NK, hc.ctg, hc.lb, hc.ring, trials);
       return (int)WCX_ERR_UNSUPPORTED;
     }
     if (e != 0) {
