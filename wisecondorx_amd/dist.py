@@ -360,13 +360,17 @@ def newref_sym_sharded(local_rows, n_rows, chr_cum, k, sample_ids, backend, rank
                torch.empty((max(n, 1), k), dtype=torch.float64, device=dev),
                torch.empty((max(n, 1), len(sample_ids)), dtype=torch.float64, device=dev))
     bounds = [row_shard(r, world, n_rows)[0] for r in range(world)] + [n_rows]
-    # Measured on one device (scripts/bench_shard_sym.py, profiles/r05/shard_sym_S500.json): a rank's wall
-    # at N = 2 / 4 / 8 ranks is 35.2 / 19.1 / 11.2 ms this way against 31.6 / 17.7 / 11.9 ms with the
-    # one-directional sweep of its row range -- every hit travels as a record here (dearer than a direct
-    # append) and prep + thresholds of ALL rows (3 ms) do not shard -- so the symmetric form is the default
-    # from 8 ranks on (WCX_SYM_SHARD_MIN overrides; 2 in the tests).
+    # Measured on one device (scripts/bench_shard_sym.py): a rank's wall at N = 2 / 4 / 8 ranks, symmetric
+    # shard against one-directional shard of its row range --
+    #   round 5 (profiles/r05/shard_sym_S500.json): 35.2 / 19.1 / 11.2 ms against 31.6 / 17.7 / 11.9 ms
+    #   round 6 (profiles/r06/shard_sym_S500.json): 34.7 / 19.3 / 11.6 ms against 30.9 / 17.7 / 10.0 ms
+    # -- every hit travels as a record here (dearer than a direct append) and prep + thresholds of ALL rows
+    # (3 ms) do not shard; since the one-directional sweep takes its thresholds from hub counts (round 6:
+    # its sweep of a 22.8 k-row shard 6.8 -> 5.0 ms) it wins at every N up to 8.  The symmetric form stays
+    # available (WCX_SYM_SHARD_MIN = the rank count from which it is used; the tests and bench.py's one-rank
+    # RCCL step set it) and is no longer a default below 16 ranks.
     import os
-    sym_min = int(os.environ.get("WCX_SYM_SHARD_MIN", "8"))
+    sym_min = int(os.environ.get("WCX_SYM_SHARD_MIN", "16"))
     counts = backend.sym_sweep(Xs, n_rows, S, chr_cum, k, rank, world, bounds, sample_ids) \
         if world >= max(1 if force_collectives() else 2, sym_min) and hasattr(backend, "sym_sweep") else None
     if counts is None:
