@@ -500,7 +500,8 @@ __global__ __launch_bounds__(256) void k_cbs_pairmax(const double *__restrict__ 
                                                      const WorkItem *__restrict__ work, unsigned int cap,
                                                      const unsigned int *__restrict__ count, int minw,
                                                      ArcBest *__restrict__ res,
-                                                     unsigned long long *__restrict__ bbits) {
+                                                     unsigned long long *__restrict__ bbits,
+                                                     const unsigned int *__restrict__ Lseg) {
   const unsigned int nitem = *count < cap ? *count : cap;
   const int lane = threadIdx.x & 63;
   const unsigned int w0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwv = (gridDim.x * 256u) >> 6;
@@ -514,7 +515,13 @@ __global__ __launch_bounds__(256) void k_cbs_pairmax(const double *__restrict__ 
     const double si = i <= n ? seg_S(S, sg, i) : 0.0, wi = i <= n ? seg_W(Wp, sg, W, i) : 0.0;
     const double sJ = pj <= n ? seg_S(S, sg, pj) : 0.0, wJ = pj <= n ? seg_W(Wp, sg, W, pj) : 0.0;
     double bb = -1.0;
-    float bf = -1.f;
+    // (round 6) the fp32 screen starts at the segment's LOWER BOUND of the maximum (k_cbs_coarse: arcs between
+    // the blocks' extreme positions, rounded down) instead of at nothing: an arc below it cannot be the
+    // segment's maximum, so a pair that does not hold it never pays an fp64 division (a pair's own running
+    // maximum took ~ln 64 record-breaking arcs per lane to get there); the maximum itself, and every tie of
+    // it, passes as before (b >= L, screen margin 4e-6).  A pair without such an arc reports b = -1.
+    float bf = __uint_as_float(Lseg[wk.seg]) * 0.999996f;
+    if (!(bf > 0.f)) bf = -1.f;
     int bi = 0, bj = 0;
     const int jmax = n - j0 < PBS - 1 ? n - j0 : PBS - 1;      // last position of block J inside the segment
     for (int qj = 0; qj <= jmax; ++qj) {
@@ -1770,7 +1777,7 @@ static int cbs_batch_impl(wcx_ctx *ctx, const double *r, const double *w, const 
         k_cbs_coarse<<<rows4, 256, 0, st>>>(dS, dWp, dseg, dso, dboff, dbseg, total_blocks, dbs, P.minw, dL);
         k_cbs_prune<<<(unsigned)((total_blocks + 4 * PRW - 1) / (4 * PRW)), 256, 0, st>>>(
             dso, dboff, dbseg, total_blocks, dbs, dL, dwork, work_cap, dcount);
-        k_cbs_pairmax<<<8192, 256, 0, st>>>(dS, dWp, dseg, dso, dwork, work_cap, dcount, P.minw, dres, dbbits);
+        k_cbs_pairmax<<<8192, 256, 0, st>>>(dS, dWp, dseg, dso, dwork, work_cap, dcount, P.minw, dres, dbbits, dL);
         k_cbs_pairtie<<<2048, 256, 0, st>>>(dwork, work_cap, dcount, dres, dbbits, dbij);
         k_cbs_pairfinal<<<(unsigned)((ns + 256) / 256), 256, 0, st>>>(ns, dbbits, dbij, dbest, dfirst);
         WCX_HIP(hipGetLastError());
