@@ -60,6 +60,11 @@ constexpr int RPITCH = RCH + 2;         // LDS row pitch in doubles (144 B)
 
 // Exact distances of 64 candidate rows (row ids in g_s, one per lane) to the target row held in
 // xt_s, each summed strictly left to right; returns the lane's candidate's distance.
+// NL = how many of the eight 8-row load instructions per chunk carry a real candidate: a list's last
+// pass is partly padding (339 entries on average = five full passes + 19 lanes), and a padding group's
+// loads -- the target row again, L1 hits -- still cost the texture addresser its 16 cycles each; they
+// are left out (the lanes of an unloaded group compute on stale LDS values and are discarded).
+template <int NL>
 __device__ __forceinline__ double pass_distances(const double *__restrict__ Xr, int S, int Sp,
                                                  double *__restrict__ tile,
                                                  const double *__restrict__ xt_s,
@@ -73,13 +78,17 @@ __device__ __forceinline__ double pass_distances(const double *__restrict__ Xr, 
   // the chunk loop is a chain of L2 round trips: the next chunk's loads are issued before the
   // current one is consumed (three chunks = 24 KB per wave in flight)
   // (eight named registers per buffer: arrays carried around the loop end up in scratch)
-  double2 va0, va1, va2, va3, va4, va5, va6, va7, vb0, vb1, vb2, vb3, vb4, vb5, vb6, vb7,
-      vc0, vc1, vc2, vc3, vc4, vc5, vc6, vc7;
+  const double2 z2 = make_double2(0.0, 0.0);
+  double2 va0 = z2, va1 = z2, va2 = z2, va3 = z2, va4 = z2, va5 = z2, va6 = z2, va7 = z2, vb0 = z2, vb1 = z2,
+          vb2 = z2, vb3 = z2, vb4 = z2, vb5 = z2, vb6 = z2, vb7 = z2, vc0 = z2, vc1 = z2, vc2 = z2, vc3 = z2,
+          vc4 = z2, vc5 = z2, vc6 = z2, vc7 = z2;
 #define WCX_LD(i, C0) (*reinterpret_cast<const double2 *>(Xr + base[i] + (C0)))
+#define WCX_LDI(P, i, C0) if constexpr (NL > i) P##i = WCX_LD(i, C0);
 #define WCX_FETCH(P, C0)                                                                         \
-  P##0 = WCX_LD(0, C0); P##1 = WCX_LD(1, C0); P##2 = WCX_LD(2, C0); P##3 = WCX_LD(3, C0);        \
-  P##4 = WCX_LD(4, C0); P##5 = WCX_LD(5, C0); P##6 = WCX_LD(6, C0); P##7 = WCX_LD(7, C0);
-#define WCX_ST(i, V) *reinterpret_cast<double2 *>(&tile[((i) * 8 + sub) * RPITCH + part * 2]) = V
+  WCX_LDI(P, 0, C0) WCX_LDI(P, 1, C0) WCX_LDI(P, 2, C0) WCX_LDI(P, 3, C0)                        \
+  WCX_LDI(P, 4, C0) WCX_LDI(P, 5, C0) WCX_LDI(P, 6, C0) WCX_LDI(P, 7, C0)
+#define WCX_ST(i, V)                                                                             \
+  if constexpr (NL > i) *reinterpret_cast<double2 *>(&tile[((i) * 8 + sub) * RPITCH + part * 2]) = V
 #define WCX_PUT(P)                                                                               \
   WCX_ST(0, P##0); WCX_ST(1, P##1); WCX_ST(2, P##2); WCX_ST(3, P##3);                            \
   WCX_ST(4, P##4); WCX_ST(5, P##5); WCX_ST(6, P##6); WCX_ST(7, P##7);
@@ -125,6 +134,7 @@ __device__ __forceinline__ double pass_distances(const double *__restrict__ Xr, 
     }
   }
 #undef WCX_LD
+#undef WCX_LDI
 #undef WCX_FETCH
 #undef WCX_ST
 #undef WCX_PUT
@@ -167,22 +177,48 @@ __device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S,
   int ix[IPL];
   const double *xt = Xr + row * (int64_t)Sp;
   for (int j = lane; j < Sp; j += 64) xt_s[j] = xt[j];     // target row -> LDS (broadcast reads)
+  // full passes first (64 real candidates each), then the list's last, partly filled one with only the
+  // load groups that carry candidates
+  const int n_full = __builtin_amdgcn_readfirstlane(n >> 6);
+  const int nv = __builtin_amdgcn_readfirstlane(n & 63);   // real candidates of the last pass (0: none)
+  auto candidates = [&](int q) __attribute__((always_inline)) {
+    const int e = q * 64 + lane;
+    int g = (int)row;                                        // padding lanes read the target row
+    int id = 0x7fffffff;
+    if (e < n) {
+      g = perm[sl_row[e].y];                                // shortlists hold sweep positions
+      id = g < cs ? g : g - (int)own;                        // own-chromosome-excluded index
+    }
+    g_s[lane] = g;
+    __builtin_amdgcn_wave_barrier();
+    return id;
+  };
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
     d[q] = 0.0;
     ix[q] = 0x7fffffff;
-    if (q * 64 >= n) continue;                               // wave-uniform
-    const int e = q * 64 + lane;
-    int g = (int)row;                                        // padding lanes read the target row
-    if (e < n) {
-      g = perm[sl_row[e].y];                                // shortlists hold sweep positions
-      ix[q] = g < cs ? g : g - (int)own;                     // own-chromosome-excluded index
+    if (q >= n_full) continue;                               // wave-uniform
+    ix[q] = candidates(q);
+    d[q] = pass_distances<8>(Xr, S, Sp, tile, xt_s, g_s);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (nv) {
+    const int id = candidates(n_full);
+    double acc;
+    switch ((nv + 7) >> 3) {
+      case 1: acc = pass_distances<1>(Xr, S, Sp, tile, xt_s, g_s); break;
+      case 2: acc = pass_distances<2>(Xr, S, Sp, tile, xt_s, g_s); break;
+      case 3: acc = pass_distances<3>(Xr, S, Sp, tile, xt_s, g_s); break;
+      case 4: acc = pass_distances<4>(Xr, S, Sp, tile, xt_s, g_s); break;
+      case 5: acc = pass_distances<5>(Xr, S, Sp, tile, xt_s, g_s); break;
+      case 6: acc = pass_distances<6>(Xr, S, Sp, tile, xt_s, g_s); break;
+      case 7: acc = pass_distances<7>(Xr, S, Sp, tile, xt_s, g_s); break;
+      default: acc = pass_distances<8>(Xr, S, Sp, tile, xt_s, g_s); break;
     }
-    g_s[lane] = g;
     __builtin_amdgcn_wave_barrier();
-    const double acc = pass_distances(Xr, S, Sp, tile, xt_s, g_s);
-    d[q] = acc;
-    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < IPL; ++q)
+      if (q == n_full) { d[q] = acc; ix[q] = id; }
   }
   sort_emit<IPL>(d, ix, k, oi, od);
 }
