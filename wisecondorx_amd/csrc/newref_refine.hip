@@ -181,29 +181,50 @@ __device__ __forceinline__ void refine_row(const double *__restrict__ Xr, int S,
   // load groups that carry candidates
   const int n_full = __builtin_amdgcn_readfirstlane(n >> 6);
   const int nv = __builtin_amdgcn_readfirstlane(n & 63);   // real candidates of the last pass (0: none)
-  auto candidates = [&](int q) __attribute__((always_inline)) {
+  // every pass's candidate rows are looked up before the first pass (list entry -> sweep position ->
+  // row: two dependent gathers, paid once per row instead of once per pass; at S = 100 a pass is only
+  // seven chunks long and these round trips were a third of it)
+  constexpr bool AHEAD = IPL <= 16;                          // (IPL = 32 has no registers to spare)
+  int gq[AHEAD ? IPL : 1];
+  auto lookup = [&](int q, int &id) __attribute__((always_inline)) {
     const int e = q * 64 + lane;
     int g = (int)row;                                        // padding lanes read the target row
-    int id = 0x7fffffff;
+    id = 0x7fffffff;
     if (e < n) {
       g = perm[sl_row[e].y];                                // shortlists hold sweep positions
       id = g < cs ? g : g - (int)own;                        // own-chromosome-excluded index
     }
-    g_s[lane] = g;
-    __builtin_amdgcn_wave_barrier();
-    return id;
+    return g;
   };
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
     d[q] = 0.0;
     ix[q] = 0x7fffffff;
+    if constexpr (AHEAD) {
+      gq[q] = (int)row;
+      if (q * 64 < n) gq[q] = lookup(q, ix[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
     if (q >= n_full) continue;                               // wave-uniform
-    ix[q] = candidates(q);
+    if constexpr (AHEAD) g_s[lane] = gq[q];
+    else g_s[lane] = lookup(q, ix[q]);
+    __builtin_amdgcn_wave_barrier();
     d[q] = pass_distances<8>(Xr, S, Sp, tile, xt_s, g_s);
     __builtin_amdgcn_wave_barrier();
   }
   if (nv) {
-    const int id = candidates(n_full);
+    int id = 0x7fffffff, g = (int)row;
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int q = 0; q < IPL; ++q)
+        if (q == n_full) { g = gq[q]; id = ix[q]; }
+    } else {
+      g = lookup(n_full, id);
+    }
+    g_s[lane] = g;
+    __builtin_amdgcn_wave_barrier();
     double acc;
     switch ((nv + 7) >> 3) {
       case 1: acc = pass_distances<1>(Xr, S, Sp, tile, xt_s, g_s); break;
