@@ -978,6 +978,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(w.Xs_host, w.cum, w.k)
         out["cpu_baseline"]["predict"] = cpu_baseline_predict(w)
     if world > 1:
+        barrier()                   # (rank 0 verifies after the timed region: nobody tears the group down under it)
         dist.destroy_process_group()
     sys.stdout.flush()
     try:
