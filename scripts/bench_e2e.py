@@ -78,6 +78,8 @@ def main():
     ph.wrap(prep, "prepare_dev", "prep_pca")
     ph.wrap(newref_tools, "get_reference_dev", "gpu_search_nullratios")
     ph.wrap(ref_qc, "qc_reference", "reference_qc")
+    ph.wrap(npz_io.NpzWriter, "close", "writer_close")
+    ph.wrap(npz_io.os, "fsync", "fsync_thread_sum")            # (worker threads + close(): summed)
 
     ref_file = os.path.join(a.workdir, "ref.npz")
     import random

@@ -374,6 +374,41 @@ def test_predict_cli_batch_equals_single_runs(built, g_pipe, tmp_path, monkeypat
                                 np.testing.assert_allclose(float(u), float(v), rtol=1e-7, atol=1e-9)
 
 
+def test_newref_cli_constant_prefix_members(built, tmp_path, monkeypatch):
+    """The gonosomal passes hand their tables on as npz_io.PrefixConst (the autosomal rows of indexes.F /
+    distances.F / .M are the reference's 0 / 1 dummies, newref_tools.py:186-191, and never leave the
+    device); from 8 MB of constants on, the writer stores them as pre-built deflate blocks.  With that
+    limit lowered to the test cohort's size the file must hold the same arrays as the ordinary build for
+    np.load (what the reference's predict uses) and for load_reference, and predict must give the same
+    tables."""
+    import zipfile
+    from wisecondorx_amd import main, npz_io
+    tmp, ref1, infiles = built
+    monkeypatch.setattr(npz_io, "_BIG", 1 << 10)
+    out = str(tmp_path / "ref_hybrid.npz")
+    random.seed(11)
+    main.main(["newref"] + infiles + [out, "--binsize", "4000000", "--refsize", "60", "--yfrac", "0.004"])
+    with zipfile.ZipFile(out) as zf:
+        for name in ("indexes.F.npy", "distances.F.npy", "indexes.M.npy", "distances.M.npy"):
+            assert npz_io._hybrid_info(zf.getinfo(name).extra) is not None, name
+        assert npz_io._hybrid_info(zf.getinfo("indexes.npy").extra) is None
+        assert zf.testzip() is None
+    a, b = np.load(ref1, allow_pickle=True), np.load(out, allow_pickle=True)
+    fast = npz_io.load_reference(out)
+    assert sorted(a.files) == sorted(b.files) == sorted(fast.keys())
+    for key in a.files:
+        for other in (b[key], fast[key]):
+            assert a[key].dtype == np.asarray(other).dtype and np.array_equal(a[key], other, equal_nan=a[key].dtype.kind == "f"), key
+    monkeypatch.undo()
+    sp = infiles[3]
+    outs = []
+    for tag, ref in (("p1", ref1), ("p2", out)):
+        oid = str(tmp_path / tag)
+        main.main(["predict", sp, ref, oid, "--bed", "--minrefbins", "20", "--seed", "3"])
+        outs.append([open(oid + sfx).read() for sfx in ("_bins.bed", "_segments.bed", "_statistics.txt")])
+    assert outs[0] == outs[1]
+
+
 def test_newref_cli_multi_process_equals_one_process(built, tmp_path, monkeypatch):
     """`newref --gpus 2`: one process per rank (here gloo, both ranks on the one device), every rank
     prepares the pass, keeps its row shard of the corrected matrix, ONE all-gather per pass

@@ -635,6 +635,63 @@ def test_reference_npz_deferred_members(tmp_path):
         npz_io.ensure_loaded(ref2, ".M")
 
 
+def test_reference_npz_constant_prefix_members(tmp_path):
+    """npz_io.PrefixConst -- the tables of a gonosomal pass, whose autosomal rows are the reference's
+    dummies (newref_tools.py:186-191): written as ONE deflated member (constant rows as pre-built deflate
+    blocks, tail in stored blocks) that np.load inflates to the very array the reference's own writer
+    would have stored, that zipfile's CRC check accepts, and that load_reference rebuilds from its
+    description in the ZIP extra field (directly, deferred, and with a damaged tail detected)."""
+    import zipfile
+    from wisecondorx_amd import npz_io
+    rng = np.random.default_rng(3)
+    ct, g, k = 150000, 4111, 25
+    tail_i = rng.integers(-1, 9000, (g, k)).astype(np.int32)
+    tail_d = rng.random((g, k))
+    full_i = np.concatenate([np.zeros((ct, k), np.int32), tail_i])
+    full_d = np.concatenate([np.ones((ct, k)), tail_d])
+    pc_i, pc_d = npz_io.PrefixConst(ct, 0, tail_i), npz_io.PrefixConst(ct, 1.0, tail_d)
+    assert pc_d.shape == full_d.shape and len(pc_i) == ct + g and pc_d.nbytes == full_d.nbytes
+    assert np.array_equal(np.asarray(pc_i), full_i) and np.array_equal(pc_d[ct - 1:ct + 2], full_d[ct - 1:ct + 2])
+    arrs = {"binsize": np.array(15000), "indexes.F": pc_i, "distances.F": pc_d,
+            "indexes.M": npz_io.PrefixConst(ct, 0, tail_i[:0]),                 # (no gonosomal row at all)
+            "distances.M": npz_io.PrefixConst(7, 1.0, tail_d),                  # (short prefix: stored as ever)
+            "null_ratios.F": rng.random((ct + g, 10))}
+    path = npz_io.save_npz(str(tmp_path / "ref.npz"), arrs)
+    assert os.path.getsize(path) < full_d.nbytes // 8 + arrs["null_ratios.F"].nbytes + arrs["distances.M"].nbytes
+    with zipfile.ZipFile(path) as zf:
+        assert zf.testzip() is None                                            # (every member's CRC-32)
+        assert zf.getinfo("distances.F.npy").compress_type == zipfile.ZIP_DEFLATED
+        assert npz_io._hybrid_info(zf.getinfo("distances.F.npy").extra)["prefix_bytes"] == ct * k * 8
+        assert npz_io._hybrid_info(zf.getinfo("distances.M.npy").extra) is None     # (an ordinary member)
+    with np.load(path) as z:                                                   # what the reference's predict does
+        assert z["indexes.F"].dtype == np.int32 and np.array_equal(z["indexes.F"], full_i)
+        assert z["distances.F"].dtype == np.float64 and np.array_equal(z["distances.F"], full_d)
+        assert z["indexes.M"].shape == (ct, k) and not z["indexes.M"].any()
+        assert np.array_equal(z["distances.M"], np.concatenate([np.ones((7, k)), tail_d]))
+    ref = npz_io.load_reference(path)
+    assert np.array_equal(ref["indexes.F"], full_i) and np.array_equal(ref["distances.F"], full_d)
+    assert ref["indexes.M"].shape == (ct, k) and not ref["indexes.M"].any()
+    assert np.array_equal(ref["null_ratios.F"], arrs["null_ratios.F"])
+    ref = npz_io.load_reference(path, defer=(".F", ".M"))
+    assert "distances.F" in ref.deferred and "distances.F" not in ref
+    npz_io.ensure_loaded(ref, ".F")
+    assert np.array_equal(ref["distances.F"], full_d) and np.array_equal(ref["indexes.F"], full_i)
+    # one flipped bit in the tail's stored blocks (payload, then a block header)
+    with zipfile.ZipFile(path) as zf:
+        zi = zf.getinfo("distances.F.npy")
+        with open(path, "rb") as fh:
+            fh.seek(zi.header_offset + 26)
+            nlen, elen = np.frombuffer(fh.read(4), dtype="<u2")
+        end = zi.header_offset + 30 + int(nlen) + int(elen) + zi.compress_size
+    for back, what in ((1000, "CRC-32 mismatch"), (tail_d.nbytes % 65535 + 4, "stored-block")):
+        bad = str(tmp_path / "bad{}.npz".format(back))
+        data = bytearray(open(path, "rb").read())
+        data[end - back] ^= 0x10
+        open(bad, "wb").write(bytes(data))
+        with pytest.raises(IOError, match=what):
+            npz_io.load_reference(bad)
+
+
 class zipfile_member_offset:
     """Context manager: offset of the data of a stored member inside the archive."""
 

@@ -148,8 +148,14 @@ def get_reference_dev(ctx, n_samples, masked_bins_per_chr_cum, ref_size, sample_
     B, S, k, m = int(cum[-1]), int(n_samples), int(ref_size), len(ids)
     dX = C.c_void_p()
     _lib.check(lib.wcx_pca_corrected_dev(ctx.h, C.byref(dX)))
-    idx = np.empty((B, k), dtype=np.int32)
-    dist = np.empty((B, k), dtype=np.float64)
+    ct = int(cum[21]) if len(cum) > 22 else 0
+    # a gonosomal pass: the autosomal target rows of indexes / distances are the reference's dummies (0 / 1,
+    # newref_tools.py:186-191) -- 0.65 GB of constants per pass at 15 kb.  Only the gonosomal rows come back
+    # from the device; the tables travel on as npz_io.PrefixConst (the .npz writer stores the constant rows
+    # as a few hundred KB of deflate blocks, np.asarray() materialises them)
+    r0 = ct if 0 < ct < B else 0
+    idx = np.empty((B - r0, k), dtype=np.int32)
+    dist = np.empty((B - r0, k), dtype=np.float64)
     nr = np.empty((B, m), dtype=np.float64)
     # the result tables are 0.8 GB of fresh host pages at 15 kb: worker threads touch them (page
     # faults, the expensive part of a device -> pageable-host copy) while the device searches
@@ -161,8 +167,7 @@ def get_reference_dev(ctx, n_samples, masked_bins_per_chr_cum, ref_size, sample_
         flat = a.reshape(-1).view(np.uint8)
         touched += [ex.submit(flat[o:o + (32 << 20)].fill, 0) for o in range(0, flat.size, 32 << 20)]
     try:
-        d_idx, d_dist, d_nr = ctx.buffers([idx.nbytes, dist.nbytes, nr.nbytes])   # kept between passes
-        ct = int(cum[21]) if len(cum) > 22 else 0
+        d_idx, d_dist, d_nr = ctx.buffers([B * k * 4, B * k * 8, nr.nbytes])       # kept between passes
         if ct < B:
             _lib.check(lib.wcx_null_rank_prepare_dev(ctx.h, dX, B, S, ids_p, m))
         _lib.check(lib.wcx_newref_topk_dev(ctx.h, dX, B, S, cum_p, len(cum), 0, B, k, int(mode),
@@ -174,9 +179,12 @@ def get_reference_dev(ctx, n_samples, masked_bins_per_chr_cum, ref_size, sample_
                                                d_nr + ct * m * 8))
         for f in touched:
             f.result()
-        for b, a in zip((d_idx, d_dist, d_nr), (idx, dist, nr)):
+        for b, a in zip((d_idx + r0 * k * 4, d_dist + r0 * k * 8, d_nr), (idx, dist, nr)):
             if a.nbytes:
                 _lib.check(lib.wcx_memcpy_d2h(ctx.h, _lib.ptr(a), b, a.nbytes))
     finally:
         ex.shutdown(wait=True)
+    if r0:
+        from .npz_io import PrefixConst
+        return PrefixConst(r0, 0, idx), PrefixConst(r0, 1.0, dist), nr
     return idx, dist, nr

@@ -79,6 +79,161 @@ def _crc_chunks(mv, nparts):
     return [(o, min(o + step, n)) for o in range(0, n, step)]
 
 
+class PrefixConst:
+    """A table whose first `n_prefix` rows all hold one value and whose remaining rows are `tail` -- what a
+    gonosomal pass produces: get_reference fills the autosomal target rows of indexes / distances with 0 / 1
+    (newref_tools.py:186-191), 1.3 GB of the 2.5 GB of a 15 kb reference.  NpzWriter.add stores such a member
+    deflated -- the constant rows as a few hundred KB of pre-built deflate blocks, the tail in stored blocks --
+    without the rows ever existing on the host; np.load inflates it to the same array as ever, and
+    load_reference rebuilds it from the fill value and the tail.  np.asarray() materialises it."""
+
+    def __init__(self, n_prefix, fill, tail):
+        self.tail = np.ascontiguousarray(tail)
+        self.n_prefix = int(n_prefix)
+        self.dtype = self.tail.dtype
+        self.fill = self.dtype.type(fill)
+        self.shape = (self.n_prefix + self.tail.shape[0],) + self.tail.shape[1:]
+        self.ndim = len(self.shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def row_bytes(self):
+        return int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+
+    @property
+    def nbytes(self):
+        return self.shape[0] * self.row_bytes
+
+    def materialize(self):
+        full = np.empty(self.shape, dtype=self.dtype)
+        full[:self.n_prefix] = self.fill
+        full[self.n_prefix:] = self.tail
+        return full
+
+    def __array__(self, dtype=None, copy=None):
+        full = self.materialize()
+        return full if dtype is None else full.astype(dtype, copy=False)
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
+
+
+_HYB_ID = 0x4357                     # ZIP extra-field id of a hybrid member's description ("WC")
+_HYB_FMT = "<4sHQQQQ8s"              # magic, itemsize, header bytes, prefix bytes, tail offset, tail bytes, fill
+_HYB_CHUNK = 1 << 20                 # constant bytes per pre-built deflate piece
+_SB_MAX = 65535                      # payload of one stored deflate block
+
+
+def _stored_blocks(view, last_final):
+    """`view` as stored deflate blocks (5-byte header + <= 65535 bytes each); the last one carries BFINAL
+    if last_final.  An empty view with last_final gives one empty final block."""
+    src = np.frombuffer(view, dtype=np.uint8)
+    n = len(src)
+    n_full, rem = divmod(n, _SB_MAX)
+    n_blocks = n_full + (1 if rem or (n == 0 and last_final) else 0)
+    out = np.empty(n + 5 * n_blocks, dtype=np.uint8)
+    head_full = np.frombuffer(struct.pack("<BHH", 0, _SB_MAX, 0), dtype=np.uint8)
+    if n_full:
+        blk = out[:n_full * (_SB_MAX + 5)].reshape(n_full, _SB_MAX + 5)
+        blk[:, :5] = head_full
+        blk[:, 5:] = src[:n_full * _SB_MAX].reshape(n_full, _SB_MAX)
+    if n_blocks > n_full:
+        o = n_full * (_SB_MAX + 5)
+        out[o:o + 5] = np.frombuffer(struct.pack("<BHH", 0, rem, rem ^ 0xFFFF), dtype=np.uint8)
+        out[o + 5:] = src[n_full * _SB_MAX:]
+    if last_final and n_blocks:
+        out[(n_blocks - 1) * (_SB_MAX + 5)] = 1
+    return out
+
+
+def _unstore_blocks(buf, nbytes, dst):
+    """The inverse: `buf` = the stored blocks of `nbytes` payload bytes (last one final) -> dst (uint8 view).
+    Raises IOError if a block header is not what _stored_blocks writes."""
+    n_full, rem = divmod(nbytes, _SB_MAX)
+    n_blocks = n_full + (1 if rem or nbytes == 0 else 0)
+    if len(buf) != nbytes + 5 * n_blocks:
+        raise IOError("stored-block region has {} bytes, expected {}".format(len(buf), nbytes + 5 * n_blocks))
+    src = np.frombuffer(buf, dtype=np.uint8)
+    heads = []
+    if n_full:
+        blk = src[:n_full * (_SB_MAX + 5)].reshape(n_full, _SB_MAX + 5)
+        dst[:n_full * _SB_MAX].reshape(n_full, _SB_MAX)[:] = blk[:, 5:]
+        heads.append(blk[:, :5])
+    if n_blocks > n_full:
+        o = n_full * (_SB_MAX + 5)
+        dst[n_full * _SB_MAX:] = src[o + 5:]
+        heads.append(src[o:o + 5].reshape(1, 5))
+    h = np.concatenate(heads)
+    lens = h[:, 1].astype(np.int64) | (h[:, 2].astype(np.int64) << 8)
+    nlens = h[:, 3].astype(np.int64) | (h[:, 4].astype(np.int64) << 8)
+    want = np.full(n_blocks, _SB_MAX, dtype=np.int64)
+    if n_blocks > n_full:
+        want[-1] = rem
+    final = np.zeros(n_blocks, dtype=np.uint8)
+    final[-1] = 1
+    if not (np.array_equal(lens, want) and np.array_equal(nlens, want ^ 0xFFFF) and np.array_equal(h[:, 0], final)):
+        raise IOError("damaged stored-block header")
+
+
+def _crc_repeat(crc, length, times):
+    """CRC-32 of `times` copies of a block with CRC `crc` and `length` bytes (binary powers of crc32_combine)."""
+    out, cur, cur_len = 0, crc, length
+    while times:
+        if times & 1:
+            out = crc32_combine(out, cur, cur_len)
+        times >>= 1
+        if times:
+            cur = crc32_combine(cur, cur, cur_len)
+            cur_len *= 2
+    return out
+
+
+def _const_crc(pattern, nbytes):
+    """CRC-32 of `nbytes` bytes of the repeated `pattern` (what _const_region computes beside its blocks)."""
+    q, r = divmod(nbytes, _HYB_CHUNK)
+    crc = _crc_repeat(zlib.crc32(pattern * (_HYB_CHUNK // len(pattern))), _HYB_CHUNK, q) if q else 0
+    return crc32_combine(crc, zlib.crc32(pattern * (r // len(pattern))), r) if r else crc
+
+
+def _hybrid_info(extra):
+    """The description _add_hybrid left in a member's ZIP extra field, or None."""
+    o = 0
+    while o + 4 <= len(extra):
+        hid, n = struct.unpack_from("<HH", extra, o)
+        if hid == _HYB_ID and n == struct.calcsize(_HYB_FMT):
+            magic, itemsize, head_len, prefix_bytes, tail_off, tail_bytes, fill = struct.unpack_from(_HYB_FMT, extra, o + 4)
+            if magic == b"wcx1":
+                return {"itemsize": itemsize, "head_len": head_len, "prefix_bytes": prefix_bytes,
+                        "tail_off": tail_off, "tail_bytes": tail_bytes, "fill": fill[:itemsize]}
+        o += 4 + n
+    return None
+
+
+def _const_region(pattern, nbytes):
+    """(raw deflate blocks -- none final, byte aligned --, CRC-32) of `nbytes` bytes of the repeated
+    `pattern`: one pre-built piece of _HYB_CHUNK bytes, repeated, + one for the remainder (full flushes:
+    every piece is self-contained)."""
+    assert _HYB_CHUNK % len(pattern) == 0 and nbytes % len(pattern) == 0
+    q, r = divmod(nbytes, _HYB_CHUNK)
+
+    def piece(n):
+        data = pattern * (n // len(pattern))
+        co = zlib.compressobj(zlib.Z_DEFAULT_COMPRESSION, zlib.DEFLATED, -15)
+        return co.compress(data) + co.flush(zlib.Z_FULL_FLUSH), zlib.crc32(data)
+    comp, crc = b"", 0
+    if q:
+        zc, cc = piece(_HYB_CHUNK)
+        comp = zc * q
+        crc = _crc_repeat(cc, _HYB_CHUNK, q)
+    if r:
+        zr, cr = piece(r)
+        comp += zr
+        crc = crc32_combine(crc, cr, r)
+    return comp, crc
+
+
 class NpzWriter:
     """A .npz written member by member: add() plans the member, fixes its place in the file and hands
     its payload (CRC-32 + positional writes, in pieces) to the worker threads at once, so a table can
@@ -105,7 +260,42 @@ class NpzWriter:
         self.ex = ThreadPoolExecutor(max_workers=_THREADS)
         self.closed = False
 
+    def _add_hybrid(self, name, pc):
+        """A PrefixConst as ONE deflated member: [stored block: .npy header][pre-built blocks: the constant
+        rows][stored blocks: the tail, the last one final] + a description in the ZIP extra field (which
+        np.load / zipfile skip) so that load_reference can rebuild it without inflating."""
+        fname = (name + ".npy").encode("utf-8")
+        shell = np.lib.stride_tricks.as_strided(np.empty(1, dtype=pc.dtype), shape=pc.shape,
+                                                strides=(0,) * pc.ndim)         # (shape + dtype for the header)
+        d = np.lib.format.header_data_from_array_1_0(shell)
+        d["fortran_order"] = False
+        buf = io.BytesIO()
+        try:
+            np.lib.format.write_array_header_1_0(buf, d)
+        except ValueError:
+            buf = io.BytesIO()
+            np.lib.format.write_array_header_2_0(buf, d)
+        head = buf.getvalue()
+        pattern = pc.fill.tobytes()
+        prefix_bytes = pc.n_prefix * pc.row_bytes
+        zc, crc_p = _const_region(pattern, prefix_bytes)
+        tail = memoryview(pc.tail.reshape(-1).view(np.uint8))
+        front = _stored_blocks(memoryview(head), False).tobytes() + zc
+        comp = np.concatenate([np.frombuffer(front, dtype=np.uint8), _stored_blocks(tail, True)])
+        crc = crc32_combine(crc32_combine(zlib.crc32(head), crc_p, prefix_bytes), zlib.crc32(tail), len(tail))
+        xtra = struct.pack(_HYB_FMT, b"wcx1", pc.dtype.itemsize, len(head), prefix_bytes, len(front),
+                           len(tail), pattern.ljust(8, b"\0"))
+        m = {"name": fname, "head": b"", "raw": memoryview(comp), "method": 8,
+             "usize": len(head) + prefix_bytes + len(tail), "crc": crc,
+             "xtra": struct.pack("<HH", _HYB_ID, len(xtra)) + xtra}
+        self._place(m, None)
+
     def add(self, name, val):
+        if isinstance(val, PrefixConst):
+            if (val.n_prefix * val.row_bytes >= _BIG and val.dtype.itemsize in (1, 2, 4, 8)
+                    and not val.dtype.hasobject):
+                return self._add_hybrid(name, val)
+            val = val.materialize()
         arr = np.asanyarray(val)
         fname = (name + ".npy").encode("utf-8")
         big = (arr.nbytes >= _BIG and arr.dtype != object and not arr.dtype.hasobject
@@ -123,12 +313,16 @@ class NpzWriter:
                      "usize": len(data), "crc": zlib.crc32(data)}
             else:
                 m = {"name": fname, "head": b"", "raw": memoryview(data), "method": 0}
+        self._place(m, arr if big else None)
+
+    def _place(self, m, keep):
         # layout (stored members have known sizes: nothing depends on the CRCs yet)
         m.setdefault("usize", len(m["head"]) + len(m["raw"]))
+        m.setdefault("xtra", b"")
         m["csize"] = len(m["head"]) + len(m["raw"])
         m["offset"] = self.off
         m["z64"] = m["usize"] >= _Z64 or m["csize"] >= _Z64
-        m["lhdr_len"] = 30 + len(m["name"]) + (20 if m["z64"] else 0)
+        m["lhdr_len"] = 30 + len(m["name"]) + (20 if m["z64"] else 0) + len(m["xtra"])
         m["data_off"] = self.off + m["lhdr_len"]
         self.off = m["data_off"] + m["csize"]
         self.members.append(m)
@@ -140,7 +334,7 @@ class NpzWriter:
             base = m["data_off"] + len(m["head"])
             fs = [self.ex.submit(_crc_and_write, self.fd, m["raw"][a:b], base + a)
                   for a, b in _crc_chunks(m["raw"], 4 * _THREADS)]
-        self.jobs.append({"m": m, "fs": fs, "arr": arr if big else None})
+        self.jobs.append({"m": m, "fs": fs, "arr": keep})
 
     def _finish(self, job):
         """A member whose payload writes are done: its CRC-32 (the chunks' combined in order), and the
@@ -199,7 +393,7 @@ class NpzWriter:
             cd = b""
             for m in members:
                 # ZIP64 extra field of the local header: uncompressed, compressed size
-                extra = struct.pack("<HHQQ", 1, 16, m["usize"], m["csize"]) if m["z64"] else b""
+                extra = (struct.pack("<HHQQ", 1, 16, m["usize"], m["csize"]) if m["z64"] else b"") + m["xtra"]
                 flag = 0 if m["name"].isascii() else 0x800     # bit 11: the name is UTF-8
                 lhdr = struct.pack("<IHHHHHIIIHH", 0x04034b50, 45 if m["z64"] else 20, flag, m["method"],
                                    _DOS_TIME, _DOS_DATE, m["crc"],
@@ -213,7 +407,8 @@ class NpzWriter:
                     fields += [m["usize"], m["csize"]]
                 if m["offset"] >= _Z64:
                     fields.append(m["offset"])
-                extra = struct.pack("<HH" + "Q" * len(fields), 1, 8 * len(fields), *fields) if fields else b""
+                extra = (struct.pack("<HH" + "Q" * len(fields), 1, 8 * len(fields), *fields) if fields else b"") \
+                    + m["xtra"]
                 cd += struct.pack("<IHHHHHHIIIHHHHHII", 0x02014b50, 45, 45 if fields else 20, flag,
                                   m["method"], _DOS_TIME, _DOS_DATE, m["crc"],
                                   0xFFFFFFFF if m["z64"] else m["csize"],
@@ -406,25 +601,56 @@ class Reference(dict):
         self.deferred = {}
 
 
+def _read_tail(path, offset, region_len, tail_bytes, dst, want_crc):
+    buf = bytearray(region_len)
+    _read_into(path, offset, memoryview(buf))
+    _unstore_blocks(buf, tail_bytes, dst)
+    return zlib.crc32(dst) if want_crc else 0
+
+
 def _read_members(path, plans, check_crc, out):
-    """plans: [(key, arr, data offset, CRC of the header bytes, CRC of the directory)] -> out[key] = arr,
-    read by worker threads, CRC-32 checked.  A member enters `out` only when ALL of the plans have been
-    read and verified: another thread using `out` meanwhile never sees a half-filled table, and after an
-    I/O or CRC failure nothing of this call is in it."""
+    """plans: [(key, arr, data offset, CRC of the header bytes, CRC of the directory[, hybrid description])]
+    -> out[key] = arr, read by worker threads, CRC-32 checked.  A member enters `out` only when ALL of the
+    plans have been read and verified: another thread using `out` meanwhile never sees a half-filled table,
+    and after an I/O or CRC failure nothing of this call is in it.  A hybrid member (NpzWriter._add_hybrid)
+    is rebuilt from its fill value and the stored blocks of its tail: `offset` is then the start of the
+    member's data."""
     done = {}
     with ThreadPoolExecutor(max_workers=_THREADS) as ex:
         pending = []
-        for key, arr, off, head_crc, want in plans:
-            view = _raw_view(arr)
-            futs = [(b - a, ex.submit(_read_into, path, off + a, view[a:b], check_crc))
-                    for a, b in _crc_chunks(view, _THREADS)]
-            pending.append((key, arr, futs, head_crc, want))
+        for plan in plans:
+            key, arr, off, head_crc, want = plan[:5]
+            hyb = plan[5] if len(plan) > 5 else None
+            if hyb is None:
+                view = _raw_view(arr)
+                futs = [(b - a, ex.submit(_read_into, path, off + a, view[a:b], check_crc))
+                        for a, b in _crc_chunks(view, _THREADS)]
+                pending.append((key, arr, futs, head_crc, want))
+                continue
+            items = arr.reshape(-1)
+            n_fill = hyb["prefix_bytes"] // hyb["itemsize"]
+            value = np.frombuffer(hyb["fill"], dtype=arr.dtype)[0]
+            step = max(1 << 20, -(-n_fill // _THREADS))
+            fills = [ex.submit(items[a:min(a + step, n_fill)].fill, value) for a in range(0, n_fill, step)]
+            flat = items.view(np.uint8)
+            tail = ex.submit(_read_tail, path, off + hyb["tail_off"], hyb["region_len"], hyb["tail_bytes"],
+                             flat[hyb["prefix_bytes"]:], check_crc)
+            pending.append((key, arr, (fills, tail, hyb), head_crc, want))
         yield                                   # (the caller's own reading runs beside the workers)
         for key, arr, futs, crc, want in pending:
-            for n, f in futs:
-                c = f.result()
+            if isinstance(futs, tuple):
+                fills, tail, hyb = futs
+                for f in fills:
+                    f.result()
+                c = tail.result()
                 if check_crc:
-                    crc = crc32_combine(crc, c, n)
+                    crc = crc32_combine(crc, _const_crc(hyb["fill"], hyb["prefix_bytes"]), hyb["prefix_bytes"])
+                    crc = crc32_combine(crc, c, hyb["tail_bytes"])
+            else:
+                for n, f in futs:
+                    c = f.result()
+                    if check_crc:
+                        crc = crc32_combine(crc, c, n)
             if check_crc and crc != want:
                 raise IOError("{}: CRC-32 mismatch in member {}.npy (corrupted file)".format(path, key))
             done[key] = arr
@@ -441,8 +667,9 @@ def ensure_loaded(ref, suffix):
     keys = [k for k in list(deferred) if k.endswith(suffix)]
     plans = []
     for k in keys:
-        shape, dtype, fortran, off, head_crc, want = deferred[k]
-        plans.append((k, np.empty(shape, dtype=dtype, order="F" if fortran else "C"), off, head_crc, want))
+        shape, dtype, fortran, off, head_crc, want = deferred[k][:6]
+        plans.append((k, np.empty(shape, dtype=dtype, order="F" if fortran else "C"), off, head_crc, want)
+                     + tuple(deferred[k][6:]))
     for _ in _read_members(ref.path, plans, ref.check_crc, ref):
         pass
     for k in keys:
@@ -466,6 +693,34 @@ def load_reference(path, defer=()):
             if not info.filename.endswith(".npy"):
                 continue
             key = info.filename[:-4]
+            hyb = _hybrid_info(info.extra) if info.compress_type == zipfile.ZIP_DEFLATED else None
+            if hyb is not None:
+                # [stored block: .npy header][constant rows, deflated][stored blocks: tail] (NpzWriter._add_hybrid)
+                fh.seek(info.header_offset)
+                lh = fh.read(30)
+                nlen, elen = struct.unpack("<HH", lh[26:30])
+                data_off = info.header_offset + 30 + nlen + elen
+                fh.seek(data_off + 5)
+                head = fh.read(hyb["head_len"])
+                hfh = io.BytesIO(head)
+                version = np.lib.format.read_magic(hfh)
+                shape, fortran, dtype = (np.lib.format.read_array_header_1_0 if version == (1, 0)
+                                         else np.lib.format.read_array_header_2_0)(hfh)
+                nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+                hyb["region_len"] = info.compress_size - hyb["tail_off"]
+                n_blocks = max(1, -(-hyb["tail_bytes"] // _SB_MAX))
+                if (fortran or dtype.hasobject or dtype.itemsize != hyb["itemsize"]
+                        or hyb["prefix_bytes"] + hyb["tail_bytes"] != nbytes
+                        or hyb["head_len"] + nbytes != info.file_size
+                        or hyb["region_len"] != hyb["tail_bytes"] + 5 * n_blocks
+                        or data_off + info.compress_size > fsize):
+                    raise IOError("{}: member {} is truncated or its sizes disagree".format(path, info.filename))
+                head_crc = zlib.crc32(head)
+                if any(key.endswith(sfx) for sfx in defer):
+                    out.deferred[key] = (shape, dtype, False, data_off, head_crc, info.CRC, hyb)
+                    continue
+                direct.append((key, np.empty(shape, dtype=dtype), data_off, head_crc, info.CRC, hyb))
+                continue
             if info.compress_type != zipfile.ZIP_STORED or info.file_size < _BIG:
                 continue
             fh.seek(info.header_offset)

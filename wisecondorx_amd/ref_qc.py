@@ -35,14 +35,24 @@ def compute_metrics(ref, suf):
     the male sub-reference the same over the chrY rows."""
     if "indexes" + suf not in ref or "distances" + suf not in ref:
         return None
-    distances = np.asarray(ref["distances" + suf], dtype=float)
-    n_bins = len(distances)
+    distances = ref["distances" + suf]
+    const_rows = 0
+    if hasattr(distances, "n_prefix") and distances.ndim == 2 and distances.shape[1]:
+        # npz_io.PrefixConst (a gonosomal pass's table): the mean of a row of k equal values is that value,
+        # exactly -- the constant rows are never materialised
+        const_rows, const_mean = distances.n_prefix, float(distances.fill)
+        distances = np.asarray(distances.tail, dtype=float)
+    else:
+        distances = np.asarray(distances, dtype=float)
+    n_bins = len(distances) + const_rows
     if n_bins == 0:
         return {"n_bins": 0}
     with np.errstate(all="ignore"):
         mean_d = distances.mean(axis=1) if distances.ndim == 2 and distances.shape[1] else \
             np.full(n_bins, np.nan)
-    n_refs = np.full(n_bins, np.asarray(ref["indexes" + suf]).shape[1] if distances.ndim == 2 else 0)
+    if const_rows:
+        mean_d = np.concatenate([np.full(const_rows, const_mean), mean_d])
+    n_refs = np.full(n_bins, ref["indexes" + suf].shape[1] if distances.ndim == 2 else 0)
     if not np.isfinite(mean_d).any():
         return {"n_bins": n_bins, "n_valid": 0}
     ok = mean_d[np.isfinite(mean_d)]
