@@ -136,7 +136,15 @@ def _build_sub_reference_sharded(args, gender, total_mask, bins_per_chr, dc, sel
     out = dict(p)
     out["binsize"] = args.binsize
     if rank == 0:
-        out["indexes"], out["distances"], out["null_ratios"] = (t.cpu().numpy() for t in (idx, dist_, nr))
+        ct = cum[21] if len(cum) > 22 else 0
+        if gender != "A" and 0 < ct < B:
+            # (as get_reference_dev: the autosomal rows of a gonosomal pass are the constants 0 / 1 and stay
+            #  on the device; the writer stores them as a few deflate blocks -- npz_io.PrefixConst)
+            out["indexes"] = npz_io.PrefixConst(ct, 0, idx[ct:].cpu().numpy())
+            out["distances"] = npz_io.PrefixConst(ct, 1.0, dist_[ct:].cpu().numpy())
+            out["null_ratios"] = nr.cpu().numpy()
+        else:
+            out["indexes"], out["distances"], out["null_ratios"] = (t.cpu().numpy() for t in (idx, dist_, nr))
     else:
         torch.cuda.synchronize()
     return out
