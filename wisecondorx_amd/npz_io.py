@@ -486,7 +486,9 @@ def _member_bytes(data, zf, name):
     raw = data[start:start + zi.compress_size]
     if len(raw) != zi.compress_size:
         raise zipfile.BadZipFile("truncated member {!r}".format(name))
-    out = zlib.decompress(raw, -15) if zi.compress_type == 8 else bytes(raw)
+    # (bufsize = the announced size: ONE output allocation -- with the default 16 KB the buffer is grown
+    #  six times for a 0.8 MB member, each time under the GIL the inflate otherwise releases)
+    out = zlib.decompress(raw, -15, max(1, zi.file_size)) if zi.compress_type == 8 else bytes(raw)
     if len(out) != zi.file_size or zlib.crc32(out) != zi.CRC:
         raise zipfile.BadZipFile("Bad CRC-32 for file {!r}".format(name))
     return out
