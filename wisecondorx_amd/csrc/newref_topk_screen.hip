@@ -5,7 +5,7 @@
 // Pipeline (all on one stream):
 //   k_col_stats    per-sample mean c_j and max |x - c_j|           (centring + fp16 scale)
 //   k_transpose    Xs [S][B] -> Xr [B][S]                           (rows contiguous for refine)
-//   k_row_norm / k_row_hist / k_scan_cells / k_scatter / k_group_mask
+//   k_transpose_norm / k_row_hist / k_scan_cells / k_scatter / k_group_mask
 //                  best-first sweep order: counting sort by (norm bucket, chromosome)
 //   k_screen_prep  a~ = fp16(2^p (x - c)) in MFMA-fragment order + four augmented k-columns that
 //                  carry |a~|^2; per row: representation-error norm      (rigorous error budget)
@@ -150,45 +150,66 @@ constexpr int HUB_BINS = 65536;          // histogram of (float bits of |a|^2) >
 // (Round 6: four threads per row -- sample j goes to thread j mod 4 -- and a fixed-order sum of the four
 //  partials: one thread per row walked S strided loads in a chain and left two thirds of the chip idle,
 //  0.31 ms for the 192 k x 250 matrix of a gonosomal pass.  The sum order is fixed: deterministic.)
-__global__ __launch_bounds__(NT) void k_row_norm(const double *__restrict__ Xs, int64_t B, int S,
-                                                 int Sp, const double *__restrict__ cmean,
-                                                 ChrTab chr, ScreenGlobals *__restrict__ glob,
-                                                 unsigned int *__restrict__ rbits,
-                                                 int *__restrict__ rchr,
-                                                 unsigned int *__restrict__ rfine = nullptr,
-                                                 int *__restrict__ hubhist = nullptr) {
-  __shared__ float part[4][64];
-  const int rl = threadIdx.x & 63, qq = threadIdx.x >> 6;
-  const int64_t b = (int64_t)blockIdx.x * 64 + rl;
-  float s = 0.f;
-  if (b < B) {
-    float s0 = 0.f, s1 = 0.f;
-    int j = qq;
-    for (; j + 4 < S; j += 8) {                                   // two independent chains
-      const float a0 = (float)(Xs[(int64_t)j * B + b] - cmean[j]);   // sample-major: coalesced
-      const float a1 = (float)(Xs[(int64_t)(j + 4) * B + b] - cmean[j + 4]);
-      s0 += a0 * a0;
-      s1 += a1 * a1;
+// The row-major copy Xr and the rows' centred norms in one pass over Xs (round 6; before: k_transpose, then
+// k_row_norm reading the matrix again): a workgroup owns 32 bins and walks ALL the sample
+// blocks of 32, so that a bin's centred norm builds up in registers in a fixed order (thread ty takes the
+// samples j = 8 i + ty of every block, the eight partial sums meet in LDS) while the tiles are transposed
+// through a double-buffered LDS tile (one barrier per block).  Saves the second read of the matrix
+// (0.25 / 0.2 ms per pass at 15 kb x 500 / 250); same outputs as the two kernels.
+__global__ __launch_bounds__(256) void k_transpose_norm(const double *__restrict__ Xs, int64_t B, int S,
+                                                        int Sp, double *__restrict__ Xr,
+                                                        const double *__restrict__ cmean, ChrTab chr,
+                                                        ScreenGlobals *__restrict__ glob,
+                                                        unsigned int *__restrict__ rbits,
+                                                        int *__restrict__ rchr,
+                                                        unsigned int *__restrict__ rfine,
+                                                        int *__restrict__ hubhist) {
+  __shared__ double tile[2][32][33];
+  __shared__ float part[8][32];
+  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  const int64_t bi = b0 + tx;
+  float acc = 0.f;
+  const int nblk = (Sp + 31) / 32;
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int j0 = jb * 32, buf = jb & 1;
+    double v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + ty + 8 * i;
+      v[i] = (j < S && bi < B) ? Xs[(int64_t)j * B + bi] : 0.0;
     }
-    if (j < S) { const float a0 = (float)(Xs[(int64_t)j * B + b] - cmean[j]); s0 += a0 * a0; }
-    s = s0 + s1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + ty + 8 * i;
+      if (j < S) { const float a = (float)(v[i] - cmean[j]); acc += a * a; }
+      tile[buf][ty + 8 * i][tx] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t b = b0 + ty + 8 * i;
+      const int j = j0 + tx;
+      if (b < B && j < Sp) Xr[b * Sp + j] = tile[buf][tx][ty + 8 * i];
+    }
   }
-  part[qq][rl] = s;
+  part[ty][tx] = acc;
   __syncthreads();
-  if (qq != 0 || b >= B) return;
-  s = (part[0][rl] + part[1][rl]) + (part[2][rl] + part[3][rl]);
+  if (ty != 0 || bi >= B) return;
+  const float s = ((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])) +
+                  ((part[4][tx] + part[5][tx]) + (part[6][tx] + part[7][tx]));
   int c = 0;
-  while (c < chr.n_chr - 1 && b >= chr.cum[c]) ++c;
-  rchr[b] = c;
+  while (c < chr.n_chr - 1 && bi >= chr.cum[c]) ++c;
+  rchr[bi] = c;
   unsigned int u = 0xffffffffu;                     // non-finite rows go last
   if (s < HUGE_VALF) {
     u = __float_as_uint(s) >> 20;
     atomicMax(&glob->uinv, 0xffffffffu - u);
   }
-  rbits[b] = u;
+  rbits[bi] = u;
   if (rfine) {
     const unsigned int f = s < HUGE_VALF ? __float_as_uint(s) >> 16 : 0xffffffffu;
-    rfine[b] = f;
+    rfine[bi] = f;
     if (f < (unsigned int)HUB_BINS) atomicAdd(&hubhist[f], 1);
   }
 }
@@ -344,9 +365,17 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
     const double *__restrict__ cmean, const int *__restrict__ perm,
     ScreenGlobals *__restrict__ glob, half8 *__restrict__ F, RowInfo *__restrict__ info,
     const unsigned int *__restrict__ gate = nullptr) {
-  const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
-  if (b >= Bpad || (gate && !*gate)) return;
-  const int64_t row = perm[b];
+  // One workgroup per 32-row tile, a wave per row at a time: the 64 lanes read the row's 64 groups of
+  // eight samples -- 4 KB contiguous -- convert them, and put the half8 pieces into the tile's fragment
+  // block in LDS (NK KB), which then leaves in one contiguous stream.  (Round 6; before, a thread walked
+  // its own row twice with 32-byte loads -- 64 scattered rows per wave, 1.5 TB/s.)  The row's |a~|^2 and
+  // representation error are summed over the lanes by a butterfly: a fixed order, the same on every rank.
+  __shared__ half8 frag[NK * 64];
+  __shared__ unsigned int wmax[2][NT / 64];     // per wave: largest e / N of its rows (one atomic pair per tile)
+  if (gate && !*gate) return;
+  unsigned int my_e = 0u, my_n = 0u;
+  const int64_t tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // scale 2^p so that the largest |a| lands in [1024, 2048): |a~|^2 <= 508 * 2^22 < 2^31.1 keeps
   // nb/65536 and any threshold/65536 inside the fp16 range; with more than 508 samples (NK > 32) one
   // binade lower: |a~|^2 <= 1020 * 2^20 < 2^30
@@ -357,41 +386,57 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
     frexp(amax, &ex);            // amax = m 2^ex, m in [0.5,1)
     scale = ldexp(1.0, (NK > 32 ? 10 : 11) - ex);
   }
-  const int64_t tile = b >> 5;
-  const int rl = (int)(b & 31);
-  // (a thread walks its own row: 32-byte loads, so that the 64 scattered rows of a wave cost a
-  // quarter of the address-coalescer cycles of scalar loads; rows are 32-byte aligned, Sp % 4 == 0,
-  // and the padding columns [S, Sp) are zero)
-  const double4 *xrow = reinterpret_cast<const double4 *>(Xr + (row >= 0 ? row : 0) * Sp);
-  bool bad = false;
-  if (row >= 0)
-    for (int j4 = 0; j4 < Sp / 4; ++j4) {
-      const double4 q = xrow[j4];
-      bad = bad || !(fabs(q.x) < HUGE_VAL) || !(fabs(q.y) < HUGE_VAL) || !(fabs(q.z) < HUGE_VAL) ||
-            !(fabs(q.w) < HUGE_VAL);
-    }
-  const bool zero = row < 0 || bad;          // padding / NaN-inf rows: all-zero image
-  double n2 = 0.0, e2 = 0.0;
-#pragma unroll 1
-  for (int ks = 0; ks < NK; ++ks) {
+  constexpr int NG = 2 * NK;                    // groups of eight k-columns per row
+  constexpr int ITER = (NG + 63) / 64;
+  // a lane keeps the same groups for every row: their column means stay in registers
+  double cm[ITER][8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      half8 hi;
-      const int j0 = ks * 16 + h * 8;
-      double xv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (!zero && j0 < Sp) {
+  for (int it = 0; it < ITER; ++it)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = (it * 64 + lane) * 8 + e;
+      cm[it][e] = j < S ? cmean[j] : 0.0;
+    }
+  for (int rl = wave; rl < 32; rl += NT / 64) {
+    const int64_t b = tile * 32 + rl;
+    if (b >= Bpad) continue;                     // wave-uniform
+    const int64_t row = perm[b];
+    // (rows are 32-byte aligned, Sp % 4 == 0, and the padding columns [S, Sp) are zero)
+    const double4 *xrow = reinterpret_cast<const double4 *>(Xr + (row >= 0 ? row : 0) * Sp);
+    double xv[ITER][8];
+    bool bad = false;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int j0 = (it * 64 + lane) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[it][e] = 0.0;
+      if (row >= 0 && it * 64 + lane < NG && j0 < Sp) {
         const double4 q0 = xrow[j0 / 4];
-        xv[0] = q0.x; xv[1] = q0.y; xv[2] = q0.z; xv[3] = q0.w;
+        xv[it][0] = q0.x; xv[it][1] = q0.y; xv[it][2] = q0.z; xv[it][3] = q0.w;
         if (j0 + 4 < Sp) {
           const double4 q1 = xrow[j0 / 4 + 1];
-          xv[4] = q1.x; xv[5] = q1.y; xv[6] = q1.z; xv[7] = q1.w;
+          xv[it][4] = q1.x; xv[it][5] = q1.y; xv[it][6] = q1.z; xv[it][7] = q1.w;
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bad = bad || !(fabs(xv[it][e]) < HUGE_VAL);
       }
+    }
+    const bool zero = row < 0 || __any(bad);     // padding / NaN-inf rows: all-zero image
+    double n2 = 0.0, e2 = 0.0;
+    half8 last;                                   // the row's last half fragment (augmented columns)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) last[e] = (_Float16)0;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int g = it * 64 + lane;
+      if (g >= NG) continue;
+      const int j0 = g * 8;
+      half8 hi;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int j = j0 + e;
         double a = 0.0;
-        if (!zero && j < S) a = (xv[e] - cmean[j]) * scale;
+        if (!zero && j < S) a = (xv[it][e] - cm[it][e]) * scale;
         _Float16 hh = (_Float16)a;
         if (fabs((double)hh) < 6.103515625e-05) hh = (_Float16)0;   // no fp16 subnormals
         const double res = a - (double)hh;
@@ -399,32 +444,50 @@ __global__ __launch_bounds__(NT) void k_screen_prep(
         e2 += res * res;
         hi[e] = hh;
       }
-      if (ks < NK - 1 || h == 0) F[(tile * NK + ks) * 64 + rl + 32 * h] = hi;
+      if (g == NG - 1) last = hi;
+      else frag[(g >> 1) * 64 + (g & 1) * 32 + rl] = hi;
+    }
+    // fixed-order sums over the wave
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      n2 += __shfl_xor(n2, off);
+      e2 += __shfl_xor(e2, off);
+    }
+    if (lane == ((NG - 1) & 63)) {
+      // last half fragment: entries 4..7 are the augmented columns
+      float nbf = (float)n2;
+      if ((double)nbf > n2) nbf = __uint_as_float(__float_as_uint(nbf) - 1u);
+      _Float16 u1, u2;
+      float usum;
+      split16(nbf * (1.f / 65536.f), false, u1, u2, usum);
+      if (zero) { u1 = (_Float16)65504.f; u2 = (_Float16)65504.f; usum = 131008.f; }
+      last[4] = -u1; last[5] = -u2; last[6] = (_Float16)AUG; last[7] = (_Float16)AUG;
+      frag[(NK - 1) * 64 + 32 + rl] = last;
+      RowInfo ri;
+      ri.nb = usum * 65536.f;               // nb' exactly as the matrix pipe sees it
+      ri.L = 0.f;
+      if (zero) { ri.e = 0.f; ri.N = 0.f; }
       else {
-        // last half fragment: entries 4..7 are the augmented columns (filled below)
-        float nbf = (float)n2;
-        if ((double)nbf > n2) nbf = __uint_as_float(__float_as_uint(nbf) - 1u);
-        _Float16 u1, u2;
-        float usum;
-        split16(nbf * (1.f / 65536.f), false, u1, u2, usum);
-        if (zero) { u1 = (_Float16)65504.f; u2 = (_Float16)65504.f; usum = 131008.f; }
-        hi[4] = -u1; hi[5] = -u2; hi[6] = (_Float16)AUG; hi[7] = (_Float16)AUG;
-        F[(tile * NK + ks) * 64 + rl + 32 * h] = hi;
-        RowInfo ri;
-        ri.nb = usum * 65536.f;               // nb' exactly as the matrix pipe sees it
-        ri.L = 0.f;
-        if (zero) { ri.e = 0.f; ri.N = 0.f; }
-        else {
-          // representation error also covers the fp64 rounding of (x - c) * scale
-          ri.e = up((float)(sqrt(e2) + 1e-15 * sqrt(n2)));
-          ri.N = up((float)sqrt(n2));
-          atomicMax(&glob->e_max, __float_as_uint(ri.e));
-          atomicMax(&glob->N_max, __float_as_uint(ri.N));
-        }
-        info[b] = ri;
+        // representation error also covers the fp64 rounding of (x - c) * scale
+        ri.e = up((float)(sqrt(e2) + 1e-15 * sqrt(n2)));
+        ri.N = up((float)sqrt(n2));
+        my_e = max(my_e, __float_as_uint(ri.e));      // (non-negative floats order like their bits)
+        my_n = max(my_n, __float_as_uint(ri.N));
       }
+      info[b] = ri;
     }
   }
+  if (lane == ((NG - 1) & 63)) { wmax[0][wave] = my_e; wmax[1][wave] = my_n; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned int m = 0u;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) m = max(m, wmax[threadIdx.x][w]);
+    if (m) atomicMax(threadIdx.x == 0 ? &glob->e_max : &glob->N_max, m);
+  }
+  half8 *dst = F + tile * (int64_t)(NK * 64);
+  for (int e = threadIdx.x; e < NK * 64; e += NT)
+    if (tile * 32 + (e & 31) < Bpad) dst[e] = frag[e];
 }
 
 
@@ -470,8 +533,11 @@ __global__ __launch_bounds__(NT) void k_merge_segments(
     const RowInfo *__restrict__ info, const ScreenGlobals *__restrict__ glob,
     const int *__restrict__ rowpos, int64_t row_begin, int64_t n_rows,
     const unsigned char *__restrict__ searched, uint2 *__restrict__ sl, int *__restrict__ cnt,
-    unsigned int *__restrict__ flags, float *__restrict__ g_state, int s0, int s1, int k,
+    unsigned int *__restrict__ flags, float *__restrict__ g_state, int step, int n_seg, int k,
     float gamma, int is_root) {
+  // one level of the merge tree per launch: blockIdx.y = the pair (segments s0, s0 + step)
+  const int s0 = (int)blockIdx.y * 2 * step, s1 = s0 + step;
+  if (s1 >= n_seg) return;
   const int lane = wcx::lane_id();
   const int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * NT) >> 6;
@@ -1222,17 +1288,18 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   WCX_HIP(hipMemsetAsync(cmax, 0, (size_t)S * 8, st));
   k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, psum, pcnt, cmin, cmax);
   k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, psum, pcnt, cmin, cmax, cmean, glob);
-  k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
   ChrTab tab;
   tab.n_chr = n_chr;
   for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
   const unsigned gb = (unsigned)((B + NT - 1) / NT);
   if (use_hub) {
     WCX_HIP(hipMemsetAsync(hubhist, 0, (size_t)HUB_BINS * 4, st));
-    k_row_norm<<<(unsigned)((B + 63) / 64), NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr, rfine, hubhist);
+    k_transpose_norm<<<(unsigned)((B + 31) / 32), 256, 0, st>>>(dXs, B, S, Sp, Xr, cmean, tab, glob, rbits, rchr,
+                                                                rfine, hubhist);
     k_hub_cut<<<1, 1024, 0, st>>>(hubhist, (int)hub_rows, glob);
   } else {
-    k_row_norm<<<(unsigned)((B + 63) / 64), NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
+    k_transpose_norm<<<(unsigned)((B + 31) / 32), 256, 0, st>>>(dXs, B, S, Sp, Xr, cmean, tab, glob, rbits, rchr,
+                                                                nullptr, nullptr);
   }
   // order B: (hub region | the rest) x (norm class, chromosome) cells padded to tiles
   WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
@@ -1255,7 +1322,7 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   }
   const unsigned gprep = (unsigned)((PB + NT - 1) / NT), gprep_s = (unsigned)((P_s + NT - 1) / NT);
   auto prep_frag = [&](int64_t n_pos, const int *pm, half8 *Fo, RowInfo *io, const unsigned int *gate) {
-    const unsigned g = (unsigned)((n_pos + NT - 1) / NT);
+    const unsigned g = (unsigned)((n_pos + 31) / 32);            // one workgroup per 32-row tile
     switch (NK) {
 #define WCX_PREP_CASE(N) case N: k_screen_prep<N><<<g, NT, 0, st>>>(Xr, n_pos, S, Sp, cmean, pm, glob, Fo, io, gate); break;
       WCX_PREP_CASE(1) WCX_PREP_CASE(2) WCX_PREP_CASE(3) WCX_PREP_CASE(4) WCX_PREP_CASE(5)
@@ -1793,31 +1860,31 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   WCX_HIP(hipMemsetAsync(cmax, 0, (size_t)S * 8, st));
   k_col_sum<<<dim3((unsigned)S, CSPLIT), NT, 0, st>>>(dXs, B, psum, pcnt, cmin, cmax);
   k_col_stats<<<(unsigned)((S + 63) / 64), 64, 0, st>>>(S, psum, pcnt, cmin, cmax, cmean, glob);
-  k_transpose<<<dim3((unsigned)((B + 31) / 32), (unsigned)((Sp + 31) / 32)), 256, 0, st>>>(dXs, B, S, Sp, Xr);
   ChrTab tab;
   tab.n_chr = n_chr;
   for (int c = 0; c < 32; ++c) tab.cum[c] = c < n_chr ? chr_cum[c] : B;
   {
     const unsigned gb = (unsigned)((B + NT - 1) / NT);
+    const unsigned gtn = (unsigned)((B + 31) / 32);
     WCX_HIP(hipMemsetAsync(cellcnt, 0, (size_t)2 * NCELL * 4, st));
     WCX_HIP(hipMemsetAsync(perm, 0xff, (size_t)Bpad * 4, st));
     if (use_hub1) {
       unsigned int *rfine = reinterpret_cast<unsigned int *>(base + o_rfin);
       int *hubhist = reinterpret_cast<int *>(base + o_hubh);
       WCX_HIP(hipMemsetAsync(hubhist, 0, (size_t)HUB_BINS * 4, st));
-      k_row_norm<<<(unsigned)((B + 63) / 64), NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr, rfine, hubhist);
+      k_transpose_norm<<<gtn, 256, 0, st>>>(dXs, B, S, Sp, Xr, cmean, tab, glob, rbits, rchr, rfine, hubhist);
       k_hub_cut<<<1, 1024, 0, st>>>(hubhist, (int)hub_rows1, glob);
       k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, 0, 0, glob, rkey, cellcnt, nullptr, rfine);
       k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, 0, nullptr, glob);
     } else {
-      k_row_norm<<<(unsigned)((B + 63) / 64), NT, 0, st>>>(dXs, B, S, Sp, cmean, tab, glob, rbits, rchr);
+      k_transpose_norm<<<gtn, 256, 0, st>>>(dXs, B, S, Sp, Xr, cmean, tab, glob, rbits, rchr, nullptr, nullptr);
       k_row_hist<<<gb, NT, 0, st>>>(rbits, rchr, B, SF, n_seg > 1 ? 1 : 0, glob, rkey, cellcnt);
       k_scan_cells<<<1, 1024, 0, st>>>(cellcnt, cursor, (int)(P_s - n_s));
     }
     k_scatter<<<gb, NT, 0, st>>>(rkey, B, cursor, perm, rowpos);
     k_group_mask<<<(unsigned)((n_groups + NT - 1) / NT), NT, 0, st>>>(perm, rchr, n_groups, gmask);
   }
-  const unsigned gprep = (unsigned)((Bpad + NT - 1) / NT);
+  const unsigned gprep = (unsigned)((Bpad + 31) / 32);              // one workgroup per 32-row tile
   switch (NK) {
 #define WCX_PREP_CASE(N) case N: k_screen_prep<N><<<gprep, NT, 0, st>>>(Xr, Bpad, S, Sp, cmean, perm, glob, F, info); break;
     WCX_PREP_CASE(1) WCX_PREP_CASE(2) WCX_PREP_CASE(3) WCX_PREP_CASE(4) WCX_PREP_CASE(5)
@@ -1985,11 +2052,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   if (n_seg > 1) {
     const float gamma = (float)(16 * NK + 12) * 1.1920929e-7f;
     const unsigned gm = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
-    for (int step = 1; step < n_seg; step *= 2)
-      for (int s0 = 0; s0 + step < n_seg; s0 += 2 * step)
-        k_merge_segments<<<gm, NT, 0, st>>>(info, glob, rowpos, row_begin, n_rows, searched, sl,
-                                            cnt_out, flags, g_state, s0, s0 + step, k, gamma,
-                                            step * 2 >= n_seg ? 1 : 0);
+    for (int step = 1; step < n_seg; step *= 2) {
+      const unsigned pairs = (unsigned)((n_seg - step + 2 * step - 1) / (2 * step));
+      k_merge_segments<<<dim3(gm, pairs), NT, 0, st>>>(info, glob, rowpos, row_begin, n_rows, searched, sl,
+                                                       cnt_out, flags, g_state, step, n_seg, k, gamma,
+                                                       step * 2 >= n_seg ? 1 : 0);
+    }
   }
   if (n_streams == 2) {                                   // the second half joins the main stream
     WCX_HIP(hipEventRecord(ctx->ev_sweep1, st2));

@@ -971,15 +971,32 @@ int wcx_null_rank_prepare_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
 
 // Rows whose reference-bin row is the gonosomal passes' dummy (all indices 0, newref_tools.py:186-191):
 // the median of k copies of x[0] is x[0], so out[r][m] = log2(x[row] / x[0]) -- no gather, no selection.
+// Null ratios of rows whose reference list is the reference's dummy (all indexes 0: the autosomal target rows
+// of a gonosomal pass, newref_tools.py:186-191 + 219-221): log2(x[row] / x[0]) per null sample.  A workgroup
+// takes 32 rows: every wave reads its samples' values of those rows (sample-major: contiguous), the ratios
+// meet in LDS and leave as the rows' contiguous n_ids doubles (one thread per (row, sample) wrote 8 bytes
+// every 800: 0.8 TB/s).
+constexpr int ND_ROWS = 32;
 __global__ __launch_bounds__(256) void k_null_dummy(const double *__restrict__ Xs, int64_t B,
                                                     const int32_t *__restrict__ sids, int n_ids,
                                                     int64_t row_begin, int64_t n_rows,
                                                     double *__restrict__ out) {
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int m = blockIdx.y;
-  if (r >= n_rows) return;
-  const double *x = Xs + (int64_t)sids[m] * B;
-  out[r * n_ids + m] = log2(x[row_begin + r] / x[0]);
+  __shared__ double tile[ND_ROWS][129];
+  const int64_t r0 = (int64_t)blockIdx.x * ND_ROWS;
+  const int rl = threadIdx.x & (ND_ROWS - 1), part = threadIdx.x / ND_ROWS;      // 8 sample slots
+  const int64_t r = r0 + rl;
+  for (int m = part; m < n_ids; m += 256 / ND_ROWS) {
+    const double *x = Xs + (int64_t)sids[m] * B;
+    if (r < n_rows) tile[rl][m] = log2(x[row_begin + r] / x[0]);
+  }
+  __syncthreads();
+  const int64_t rows_here = n_rows - r0 < ND_ROWS ? n_rows - r0 : ND_ROWS;
+  const int64_t total = rows_here * n_ids;
+  double *dst = out + r0 * n_ids;
+  for (int64_t e = threadIdx.x; e < total; e += 256) {
+    const int rr = (int)(e / n_ids), mm = (int)(e - (int64_t)rr * n_ids);
+    dst[e] = tile[rr][mm];
+  }
 }
 
 // Ranking cost ~0.37 ns per (null sample, bin) when this was measured (round 3; 0.07 ns alone on the
@@ -1148,7 +1165,7 @@ int wcx_null_ratios_dummy_dev(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   if (rc) return rc;
   rc = wcx_upload_small(ctx, scr, sample_ids, (size_t)n_ids * 4);
   if (rc) return rc;
-  k_null_dummy<<<dim3((unsigned)((n_rows + 255) / 256), (unsigned)n_ids), 256, 0, ctx->stream>>>(
+  k_null_dummy<<<dim3((unsigned)((n_rows + ND_ROWS - 1) / ND_ROWS)), 256, 0, ctx->stream>>>(
       dXs, B, reinterpret_cast<const int32_t *>(scr), n_ids, row_begin, n_rows, d_out);
   WCX_HIP(hipGetLastError());
   return WCX_OK;
