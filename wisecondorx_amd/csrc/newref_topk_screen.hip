@@ -147,9 +147,6 @@ constexpr int NBUCKET = 128;            // norm buckets: float bits >> 20 (12.5 
 constexpr int NCELL = NBUCKET * 32;     // (bucket, chromosome) cells
 
 constexpr int HUB_BINS = 65536;          // histogram of (float bits of |a|^2) >> 16: 0.8 % steps in norm
-// (Round 6: four threads per row -- sample j goes to thread j mod 4 -- and a fixed-order sum of the four
-//  partials: one thread per row walked S strided loads in a chain and left two thirds of the chip idle,
-//  0.31 ms for the 192 k x 250 matrix of a gonosomal pass.  The sum order is fixed: deterministic.)
 // The row-major copy Xr and the rows' centred norms in one pass over Xs (round 6; before: k_transpose, then
 // k_row_norm reading the matrix again): a workgroup owns 32 bins and walks ALL the sample
 // blocks of 32, so that a bin's centred norm builds up in registers in a fixed order (thread ty takes the
@@ -1569,9 +1566,12 @@ static int screen_sym_path(wcx_ctx *ctx, const double *dXs, int64_t B, int S, co
   rc = wcx_timer_end(ctx, "topk_screen");
   if (rc) return rc;
   if (ctx->ev_after_sweep) WCX_HIP(hipEventRecord(ctx->ev_after_sweep, st));   // (wcx_sweep_event)
-  if (kick_at == 1) {
+  if (kick_at >= 1) {
+    const bool pending = ctx->rank_pending;
     rc = wcx_aux_kick(ctx);
     if (rc) return rc;
+    // (2: the refine waits for the ranking instead of running beside it -- an experiment switch)
+    if (kick_at == 2 && pending) WCX_HIP(hipStreamWaitEvent(st, ctx->ev_rank, 0));
   }
   rc = wcx_timer_begin(ctx, "topk_refine");
   if (rc) return rc;
@@ -2067,9 +2067,12 @@ int wcx_topk_screen_launch(wcx_ctx *ctx, const double *dXs, int64_t B, int S,
   rc = wcx_timer_end(ctx, "topk_screen");
   if (rc) return rc;
   if (ctx->ev_after_sweep) WCX_HIP(hipEventRecord(ctx->ev_after_sweep, st));   // (wcx_sweep_event)
-  if (kick_at == 1) {
+  if (kick_at >= 1) {
+    const bool pending = ctx->rank_pending;
     rc = wcx_aux_kick(ctx);
     if (rc) return rc;
+    // (2: the refine waits for the ranking instead of running beside it -- an experiment switch)
+    if (kick_at == 2 && pending) WCX_HIP(hipStreamWaitEvent(st, ctx->ev_rank, 0));
   }
   rc = wcx_timer_begin(ctx, "topk_refine");
   if (rc) return rc;
