@@ -151,6 +151,24 @@ def test_symmetric_sweep_wide_norm_spread(nt, monkeypatch):
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
 
 
+def test_symmetric_sweep_list_overflow_rows_go_to_the_exact_kernel(nt):
+    """A third of the rows are copies of one far-away vector: each of them meets > CAP2 = 2048 candidates at
+    distance 0 on other chromosomes, so its list overflows in the sweep (the store loop of an overflowing
+    row compares against +inf and writes nothing; the row is flagged) -- those rows must come back from
+    the exact kernel, and the rows sharing their tiles and events must be untouched."""
+    from wisecondorx_amd.synth import corrected_matrix
+    X, mbpc, cum = corrected_matrix([1900, 1700, 1500, 1300, 1100, 900, 700], 100, seed=77)
+    X = np.array(X, order="F")
+    rng = np.random.default_rng(5)
+    dup = np.arange(0, X.shape[0], 3)
+    X[dup] = 3.0 + rng.standard_normal(X.shape[1])
+    k = 100
+    oi, od = _oracle(X, cum, k)
+    idx, dist, st = _run(nt, X, cum, k)
+    assert st["sym_gates"] > 0 and st["fallback_rows"] >= len(dup)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
 @pytest.fixture(scope="module")
 def bench_cohort_500():
     """bench.py's default workload (15 kb x 500 samples): the prepared A / F / M passes."""

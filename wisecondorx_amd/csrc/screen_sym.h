@@ -259,33 +259,34 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
       ++C.n_slow;
       C.n_cg += col_gate ? 1u : 0u;
       C.n_rg += row_gate ? 1u : 0u;
-      if (excl && col_gate && !row_gate && !(A.dbg & 16)) {
+      if (excl && col_gate && !row_gate) {
         // The common event -- column hits only, in an exclusive item (85 % of all events at 15 kb x 500):
         // one compare + one add per output for the lane's hit count (the gate is exact in this direction:
         // some lane has a hit), slots from the register counter, then per output one compare whose VCC
         // is both the scalar "anybody?" test and the store's lane mask -- no pass-bit words, no wave-wide
         // OR (six DPP steps), no second direction.  The event path costs the sweep 3.4 ms of its 21 (the
-        // stores themselves 0.6: ablations 32 / 1), so its instruction count is what counts.
+        // stores themselves 0.6: ablations), so its INSTRUCTION COUNT is what counts: the store loop
+        // carries no capacity test (a row whose list would overflow compares against +inf instead of its
+        // threshold -- it stores nothing and is flagged below, its list is never read) and walks a
+        // pointer (one 64-bit add per hit output instead of sign extension + shift-add).
         unsigned int pc = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) pc += (acc[s][r] >= thj) ? 1u : 0u;
         ++C.n_ce;
         C.n_app += pc;
         const auto pcs = __builtin_amdgcn_permlane32_swap(pc, pc, false, false);
-        int ofs = cntr + (hf ? (int)pcs[0] : 0);
+        uint2 *p = mine + (cntr + (hf ? (int)pcs[0] : 0));
         cntr += (int)(pcs[0] + pcs[1]);
+        const float the = cntr <= A.cap2 ? thj : HUGE_VALF;
         const unsigned int cposb = (unsigned int)((g * CTG + s) * 32 + 4 * hf);
-        if (A.dbg & 64) continue;                        // (ablation: the event without its store loop)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const bool hit = acc[s][r] >= thj;
+          const bool hit = acc[s][r] >= the;
           if (__any(hit)) {
             asm volatile("" ::: "memory");               // (keeps the two tests separate)
             if (hit) {
-              if (ofs < A.cap2 && !(A.dbg & 32))
-                mine[ofs] = make_uint2(__float_as_uint(-2.f * acc[s][r]),
-                                       cposb + (unsigned int)(8 * (r >> 2) + (r & 3)));
-              ++ofs;
+              *p = make_uint2(__float_as_uint(-2.f * acc[s][r]), cposb + (unsigned int)(8 * (r >> 2) + (r & 3)));
+              ++p;
             }
           }
         }
@@ -295,13 +296,13 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
       // per-lane pass bits, bit (15 - r) = output r: column direction (my row is the target, the
       // streamed rows are candidates) and row direction (a streamed row is the target)
       unsigned int pm = 0, rm = 0;
-      if (col_gate && !(A.dbg & 16)) {
+      if (col_gate) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           pm = __builtin_amdgcn_alignbit(pm, ~__float_as_uint(acc[s][r] - thj), 31);
         pm &= 0xffffu;
       }
-      if (row_gate && !(A.dbg & 8)) {
+      if (row_gate) {
 #pragma unroll
         for (int a4 = 0; a4 < 4; ++a4) {
           const uint4 tv = *reinterpret_cast<const uint4 *>(ti + 8 * a4 + 4 * hf);
@@ -329,6 +330,7 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
           const auto pcs = __builtin_amdgcn_permlane32_swap(pc, pc, false, false);
           ofs = cntr + (hf ? (int)pcs[0] : 0);
           cntr += (int)(pcs[0] + pcs[1]);
+          if (cntr > A.cap2) pm = 0;               // (overflowing row: flagged below, nothing stored)
         }
         if (rany) {
           const int incl = wcx::wave_incl_scan_i((int)rc);
@@ -360,9 +362,8 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
             if (anym & (0x8000u >> r)) {
               asm volatile("" ::: "memory");               // (keeps the two tests separate)
               if (pm & (0x8000u >> r)) {
-                if (ofs < A.cap2 && !(A.dbg & 32))           // (dbg 32: everything but the store itself)
-                  mine[ofs] = make_uint2(__float_as_uint(-2.f * acc[s][r]),
-                                         cposb + (unsigned int)(8 * (r >> 2) + (r & 3)));
+                mine[ofs] = make_uint2(__float_as_uint(-2.f * acc[s][r]),
+                                       cposb + (unsigned int)(8 * (r >> 2) + (r & 3)));
                 ++ofs;
               }
             }
