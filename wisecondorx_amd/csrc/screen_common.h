@@ -151,6 +151,38 @@ int wcx_screen_launch_k6(const ScreenCfg &c, const ScreenArgs &a, unsigned grid,
 int wcx_screen_launch_k7(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
 int wcx_screen_launch_k8(const ScreenCfg &c, const ScreenArgs &a, unsigned grid, size_t lds, hipStream_t st);
 
+// LDS-DMA staging of one candidate group (NF fragment pieces of 1 KiB, laid out in LDS as in HBM) by the
+// WPB waves of a workgroup: wave w copies the NFW = ceil(NF / WPB) CONSECUTIVE pieces from
+// min(w NFW, NF - NFW) on (the last waves overlap their neighbours when NF is no multiple: same bytes,
+// same place) -- one base address per four pieces, the others in the instruction's immediate offset,
+// which the hardware adds on the global and on the LDS side alike.  No per-piece scalar address
+// arithmetic or branches: ~3 scalar instructions per four pieces (the strided form -- piece w, w + WPB,
+// ... -- cost 5-7 per piece, and a chain of branches where the piece kind depended on the wave).
+// Every wave issues exactly NFW loads (the counted s_waitcnt of the rings relies on it).
+template <int NF, int WPB>
+__device__ __forceinline__ int stage_piece0(int wave_u) {
+  constexpr int NFW = (NF + WPB - 1) / WPB;
+  const int b = wave_u * NFW;
+  return b < NF - NFW ? b : NF - NFW;
+}
+template <int NF, int WPB>
+__device__ __forceinline__ void stage_group(const half8 *src_group, half8 *dst_group, int piece0, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NFW = (NF + WPB - 1) / WPB;
+  const char *src = reinterpret_cast<const char *>(src_group) + (int64_t)piece0 * 1024 + lane * 16;
+  char *dst = reinterpret_cast<char *>(dst_group) + piece0 * 1024;
+#pragma unroll
+  for (int i0 = 0; i0 < NFW; i0 += 4) {
+    const char *s4 = src + i0 * 1024;
+    auto *d4 = (__attribute__((address_space(3))) void *)(dst + i0 * 1024);
+    __builtin_amdgcn_global_load_lds(s4, d4, 16, 0, 0);
+    if (i0 + 1 < NFW) __builtin_amdgcn_global_load_lds(s4, d4, 16, 1024, 0);
+    if (i0 + 2 < NFW) __builtin_amdgcn_global_load_lds(s4, d4, 16, 2048, 0);
+    if (i0 + 3 < NFW) __builtin_amdgcn_global_load_lds(s4, d4, 16, 3072, 0);
+  }
+#endif
+}
+
 struct ChrTab {
   int n_chr;
   int64_t cum[32];

@@ -109,16 +109,9 @@ __global__ __launch_bounds__(256, LBW) void k_screen_hub1(const Hub1Args A) {
               th[NK - 1][6] = (_Float16)0; th[NK - 1][7] = (_Float16)0; }
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int piece0 = stage_piece0<NPIECE, WPB>(wave_u);
   auto fetch = [&](int g, int slot) {
-    const half8 *src = A.F + (int64_t)g * TILE_H8;
-    half8 *dst = sbuf + slot * TILE_H8;
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      int p = wave_u + i * WPB;
-      if ((i + 1) * WPB > NPIECE && p >= NPIECE) p %= NPIECE;
-      __builtin_amdgcn_global_load_lds(src + p * 64 + lane,
-                                       (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 0);
-    }
+    stage_group<NPIECE, WPB>(A.F + (int64_t)g * TILE_H8, sbuf + slot * TILE_H8, piece0, lane);
   };
   __builtin_amdgcn_s_waitcnt(0x0F70);
 #if defined(__HIP_DEVICE_COMPILE__)

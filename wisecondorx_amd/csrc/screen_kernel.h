@@ -342,18 +342,11 @@ __global__ __launch_bounds__(64 * WPB, LBW) void k_screen(
 
   half8 pre[DMA ? 1 : NPT];
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int piece0 = stage_piece0<CTG * NK, WPB>(wave_u);
   auto fetch = [&](int gix, int slot) {
     const half8 *src = A.F + (int64_t)gix * TILE_H8;
     if constexpr (DMA) {
-      half8 *dst = sbuf + slot * TILE_H8;
-#pragma unroll
-      for (int i = 0; i < NPW; ++i) {
-        int p = wave_u + i * WPB;
-        if ((i + 1) * WPB > CTG * NK && p >= CTG * NK) p %= CTG * NK;   // repeat a piece (uniform count)
-        __builtin_amdgcn_global_load_lds(src + p * 64 + lane,
-                                         (__attribute__((address_space(3))) void *)(dst + p * 64),
-                                         16, 0, 0);
-      }
+      stage_group<CTG * NK, WPB>(src, sbuf + slot * TILE_H8, piece0, lane);
     } else {
 #pragma unroll
       for (int p = 0; p < NPT; ++p)

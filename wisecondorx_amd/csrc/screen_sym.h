@@ -156,43 +156,12 @@ __device__ __forceinline__ void sym_item(const SymArgs &A, unsigned char *smem, 
     return o;
   };
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  // A wave copies NFW CONSECUTIVE 1 KiB fragment pieces of the group (one base per four pieces, the
-  // rest in the instruction's immediate offset -- it applies to the global and the LDS address alike)
-  // and one tile-info piece: no per-piece branches, ~20 scalar instructions per group instead of ~110.
-  // Every wave issues the same NPW loads (a wave short of pieces repeats the last one: same bytes, same
-  // place), so the counted s_waitcnt below is a literal.
-  constexpr int NF = CTG * NK, NFW = (NF + WPB - 1) / WPB;
-  static_assert(NPW == NFW + 1, "pieces per wave");
-  const int piece0 = wave_u * NFW;
+  // staging: stage_group (screen_common.h) + one tile-info piece per wave; every wave issues NPW loads
+  static_assert(NPW == (CTG * NK + WPB - 1) / WPB + 1, "pieces per wave");
+  const int piece0 = stage_piece0<CTG * NK, WPB>(wave_u);
+  const int ip = CTG > 1 ? wave_u % CTG : 0;
   auto fetch = [&](int g, int slot) {
-    const char *src = reinterpret_cast<const char *>(A.F + (int64_t)g * TILE_H8);
-    char *dst = reinterpret_cast<char *>(sbuf + slot * TILE_H8);
-#pragma unroll
-    for (int i0 = 0; i0 < NFW; i0 += 4) {
-      const int last = i0 + 3 < NFW - 1 ? i0 + 3 : NFW - 1;
-      if ((WPB - 1) * NFW + last < NF) {         // (compile-time: these pieces exist for every wave)
-        const char *s4 = src + (int64_t)(piece0 + i0) * 1024 + lane * 16;
-        char *d4 = dst + (piece0 + i0) * 1024;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (i0 + j < NFW) {
-            if (j == 0) __builtin_amdgcn_global_load_lds(s4, (__attribute__((address_space(3))) void *)d4, 16, 0, 0);
-            if (j == 1) __builtin_amdgcn_global_load_lds(s4, (__attribute__((address_space(3))) void *)d4, 16, 1024, 0);
-            if (j == 2) __builtin_amdgcn_global_load_lds(s4, (__attribute__((address_space(3))) void *)d4, 16, 2048, 0);
-            if (j == 3) __builtin_amdgcn_global_load_lds(s4, (__attribute__((address_space(3))) void *)d4, 16, 3072, 0);
-          }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (i0 + j < NFW) {
-            int pp = piece0 + i0 + j;
-            pp = pp < NF ? pp : NF - 1;
-            __builtin_amdgcn_global_load_lds(src + (int64_t)pp * 1024 + lane * 16,
-                                             (__attribute__((address_space(3))) void *)(dst + pp * 1024), 16, 0, 0);
-          }
-      }
-    }
-    const int ip = CTG > 1 ? wave_u % CTG : 0;
+    stage_group<CTG * NK, WPB>(A.F + (int64_t)g * TILE_H8, sbuf + slot * TILE_H8, piece0, lane);
     __builtin_amdgcn_global_load_lds(A.tinfo + ((int64_t)g * CTG + ip) * 64 + lane,
                                      (__attribute__((address_space(3))) void *)(tinf + (slot * CTG + ip) * 64), 4, 0, 0);
   };
