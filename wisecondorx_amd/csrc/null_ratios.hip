@@ -333,21 +333,35 @@ __device__ __forceinline__ unsigned int select_u32_bisect(const unsigned int (&v
   return prefix;
 }
 
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 // The two middle order statistics (ranks r0 = (n-1)/2 and r1 = n/2) of the active values: entry
 // q * 64 + lane is active iff it is < n (one compare against a scalar; `act` is that as a per-lane
 // bit mask, for the general path).
 // hist: int[64], slots: unsigned[64], wave-private LDS.  hi_out = the maximum (NaN detection).
+// Slices of 64 list entries that are full whatever the refsize, given the launch rule IPL = the
+// instantiated size for ceil(k / 64) (1 .. 6, 8, 16, 32): k > 64 NFULL<IPL>.  Their "is this entry
+// active?" test is a compile-time true -- at k = 300 four of five slices lose their compare + select +
+// mask arithmetic in every loop below (the predicates were a third of the kernel's vector instructions).
+template <int IPL>
+struct NFull { static constexpr int value = IPL <= 6 ? IPL - 1 : (IPL == 8 ? 6 : IPL / 2); };
+
 template <int IPL>
 __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], unsigned int act,
                                                 int n, int *hist, unsigned int *slots,
                                                 unsigned int &a0, unsigned int &a1,
                                                 unsigned int &hi_out) {
   const int lane = wcx::lane_id();
+  constexpr int NF = NFull<IPL>::value;                    // (callers: n > 64 NF)
   const int r0 = (n - 1) >> 1, r1 = n >> 1;
   unsigned int lo = 0xffffffffu, nhi = 0xffffffffu;
 #pragma unroll
   for (int q = 0; q < IPL; ++q)
-    if (q * 64 + lane < n) { lo = v[q] < lo ? v[q] : lo; nhi = ~v[q] < nhi ? ~v[q] : nhi; }
+    if (q < NF || q * 64 + lane < n) { lo = v[q] < lo ? v[q] : lo; nhi = ~v[q] < nhi ? ~v[q] : nhi; }
   lo = wave_min_u32(lo);
   const unsigned int hi = ~wave_min_u32(nhi);
   hi_out = hi;
@@ -355,11 +369,11 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
   const float scale = 64.0f / ((float)(hi - lo) * 1.0000002f + 1.0f);   // bucket(hi) <= 63
   hist[lane] = 0;
   __builtin_amdgcn_wave_barrier();
-  int b[IPL];
+  int b[IPL];                                               // bucket of the entry; -1: not active
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
-    b[q] = 0;
-    if (q * 64 + lane < n) {
+    b[q] = -1;
+    if (q < NF || q * 64 + lane < n) {
       int bb = (int)((float)(v[q] - lo) * scale);          // monotone in v
       bb = bb > 63 ? 63 : bb;
       b[q] = bb;
@@ -382,7 +396,7 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
   int base = 0;
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
-    const bool m = q * 64 + lane < n && b[q] == B0;
+    const bool m = b[q] == B0;
     const unsigned long long mm = __ballot(m);
     if (m) slots[base + __popcll(mm & ((1ull << lane) - 1ull))] = v[q];
     base += __popcll(mm);
@@ -405,16 +419,10 @@ __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], un
       unsigned int mn = 0xffffffffu;
 #pragma unroll
       for (int q = 0; q < IPL; ++q)
-        if (q * 64 + lane < n && b[q] > B0 && v[q] < mn) mn = v[q];
+        if (b[q] > B0 && v[q] < mn) mn = v[q];
       a1 = wave_min_u32(mn);
     }
   }
-}
-
-__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
-  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
-  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
-  return ((unsigned long long)hi << 32) | lo;
 }
 
 // The two middle order statistics of an ARBITRARY active set (bit q of `act` <-> element v[q] of this
@@ -684,7 +692,7 @@ __global__ __launch_bounds__(NT) void k_null_ratios_hi(
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
     const int t = q * 64 + lane;
-    const bool valid = t < k;
+    const bool valid = q < NFull<IPL>::value || t < k;      // (k > 64 NFull: launch rule)
     int64_t c = valid ? (int64_t)idx[r * (int64_t)k + t] : 0;
     if (c < 0) c += B;  // NumPy negative index
     cc[q] = (int)c;
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(NT) void k_null_ratios_hi(
     int below = 0, t0 = 0, t1 = 0, c0 = 0, c1 = 0;
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
-      const bool on = q * 64 + lane < k;
+      const bool on = q < NFull<IPL>::value || q * 64 + lane < k;
       below += __popcll(__ballot(on && v[s][q] < a0));
       const unsigned long long e0 = __ballot(on && v[s][q] == a0);
       if (e0) {
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(NT) void k_null_ratios(
 #pragma unroll
   for (int q = 0; q < IPL; ++q) {
     const int t = q * 64 + lane;
-    const bool valid = t < k;
+    const bool valid = q < NFull<IPL>::value || t < k;      // (k > 64 NFull: launch rule)
     int64_t c = valid ? (int64_t)idx[r * (int64_t)k + t] : 0;
     if (c < 0) c += B;  // NumPy negative index
     act |= valid ? (1u << q) : 0u;
