@@ -349,6 +349,11 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 // mask arithmetic in every loop below (the predicates were a third of the kernel's vector instructions).
 template <int IPL>
 struct NFull { static constexpr int value = IPL <= 6 ? IPL - 1 : (IPL == 8 ? 6 : IPL / 2); };
+// The launch rule (WCX_NR_LAUNCH / WCX_NRH_LAUNCH below): ceil(k / 64) in (P, IPL] runs instantiation IPL, with
+// P the next smaller instantiated size -- so k >= 64 P + 1, and NFull<IPL> <= P is what the kernels rely on.
+static_assert(NFull<1>::value <= 0 && NFull<2>::value <= 1 && NFull<3>::value <= 2 && NFull<4>::value <= 3 &&
+              NFull<5>::value <= 4 && NFull<6>::value <= 5 && NFull<8>::value <= 6 && NFull<16>::value <= 8 &&
+              NFull<32>::value <= 16, "NFull must stay below the smallest refsize an instantiation is launched for");
 
 template <int IPL>
 __device__ __forceinline__ void wave_middle_u32(const unsigned int (&v)[IPL], unsigned int act,
